@@ -1,0 +1,229 @@
+#!/usr/bin/env python
+"""Headline benchmark: SDF (value + gradient) queries/sec -- BASELINE.json configs[1] ("C2"):
+CachedSDF at 0.01 m voxels on the YCB power drill, 1M query points per GPU per step.
+
+One "step" = one pass of the hot path over one batch: a single `pvamd_cached_query` C-ABI call (one kernel launch)
+over the rank's 1,048,576 resident query points, writing sdf_val [P] and sdf_grad [P,3].  Inputs are in HBM before
+the timed region.  N > 1: one process per GPU, each with its own batch (weak scaling), no data-path collective
+(pass --gather to time the RCCL all-gather of (val, grad) as well).
+
+Prints ONE JSON line (rank 0) with `roofline` (HBM, algorithmic 28 B/query over the per-launch duration measured with
+HIP events on the launch stream) and `cpu_baseline` (the C oracle on the host cores, bounded sample).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+HBM_PEAK_GBS = 8000.0  # MI355X datasheet (MI355X_MICROARCH.md); ~6290 GB/s is the measured float4-copy ceiling
+BYTES_PER_QUERY = 28   # 12 B point read + 4 B value + 12 B gradient written
+
+
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--points", type=int, default=1 << 20, help="query points per GPU per step")
+    ap.add_argument("--gather", action="store_true", help="all-gather (val, grad) across ranks inside each step")
+    ap.add_argument("--no-graph", action="store_true", help="time eager launches instead of one hipGraph of K steps")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-large", action="store_true", help="skip the secondary 64M-point (cache-exceeding) run")
+    ap.add_argument("--cpu-seconds", type=float, default=4.0, help="wall budget of the CPU baseline sample")
+    return ap.parse_args()
+
+
+def build_workload(points_per_gpu, rank):
+    import pytorch_volumetric_amd as pv
+    from tests import helpers as H
+    obj = pv.MeshObjectFactory(H.mesh_path("ycb_power_drill.npz"))
+    # the cache is filled on-device by the brute-force mesh kernel (48,840 voxel centres x 15,728 triangles)
+    cached = pv.CachedSDF("YcbPowerDrill", 0.01, obj.bounding_box(padding=0.1), pv.MeshSDF(obj), device="cuda",
+                          cache_path=None)
+    lo = np.array([r[0] for r in cached.ranges]) - 0.05
+    hi = np.array([r[1] for r in cached.ranges]) + 0.05
+    g = torch.Generator(device="cuda").manual_seed(1234 + rank)
+    lo_t = torch.tensor(lo, dtype=torch.float32, device="cuda")
+    hi_t = torch.tensor(hi, dtype=torch.float32, device="cuda")
+    pts = torch.rand((points_per_gpu, 3), generator=g, device="cuda") * (hi_t - lo_t) + lo_t
+    return cached, pts.contiguous()
+
+
+def time_eager_kernel(cached, pts, val, grad, reps):
+    """Average duration of ONE launch, HIP events recorded on the launch stream around each launch."""
+    starts = [torch.cuda.Event(enable_timing=True) for _ in range(reps)]
+    ends = [torch.cuda.Event(enable_timing=True) for _ in range(reps)]
+    torch.cuda.synchronize()
+    for i in range(reps):
+        starts[i].record()
+        cached.query_into(pts, val, grad)
+        ends[i].record()
+    torch.cuda.synchronize()
+    ms = [s.elapsed_time(e) for s, e in zip(starts, ends)]
+    return float(np.mean(ms)), float(np.median(ms)), float(np.min(ms))
+
+
+def cpu_baseline(cached, pts, seconds):
+    from oracle import oracle
+    from tests import helpers as H
+    og = H.oracle_grid_from_cached(cached)
+    host_pts = pts.cpu().numpy()
+    oracle.cached_query(og, host_pts[:1000])  # warm
+    reps, t0 = 0, time.perf_counter()
+    while True:
+        oracle.cached_query(og, host_pts)
+        reps += 1
+        dt = time.perf_counter() - t0
+        if dt >= seconds and reps >= 3:
+            break
+    return {"value": len(host_pts) * reps / dt, "unit": "queries/s", "cores": oracle.num_threads(), "kind": "port",
+            "host_cpus": os.cpu_count(),
+            "sample": f"{reps} x {len(host_pts)} of the same query points through oracle/pvamd_oracle.c "
+                      f"(OpenMP, {oracle.num_threads()} threads), {dt:.1f} s wall"}
+
+
+def main():
+    args = parse_args()
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X visible to PyTorch-ROCm (no CPU path exists)")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    cached, pts = build_workload(args.points, rank)
+    P = pts.shape[0]
+    val = torch.empty((P,), dtype=torch.float32, device="cuda")
+    grad = torch.empty((P, 3), dtype=torch.float32, device="cuda")
+    gathered = None
+    if args.gather and world > 1:
+        packed = torch.empty((P, 4), dtype=torch.float32, device="cuda")
+        gathered = torch.empty((world, P, 4), dtype=torch.float32, device="cuda")
+
+    def step():
+        cached.query_into(pts, val, grad)
+        if gathered is not None:
+            packed[:, 0] = val
+            packed[:, 1:] = grad
+            dist.all_gather_into_tensor(gathered, packed)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+
+    use_graph = not args.no_graph and gathered is None
+    graph = None
+    if use_graph:
+        # the launch-bound inner loop (a ~5 us kernel) captured once: K launches, one replay
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph, stream=side):
+                for _ in range(args.steps):
+                    cached.query_into(pts, val, grad)
+        torch.cuda.current_stream().wait_stream(side)
+        graph.replay()  # untimed: first replay uploads the graph
+        torch.cuda.synchronize()
+
+    barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    if graph is not None:
+        graph.replay()
+    else:
+        for _ in range(args.steps):
+            step()
+    torch.cuda.synchronize()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = t.item()
+
+    # per-launch kernel duration for the roofline (HIP events on the launch stream, eager launches of the same step)
+    k_mean, k_med, k_min = time_eager_kernel(cached, pts, val, grad, min(args.steps, 200))
+
+    # parity spot check inside the bench: GPU result of the timed workload vs the oracle on a slice
+    from oracle import oracle
+    from tests import helpers as H
+    n_chk = min(P, 50_000)
+    oval, ograd, ooob = oracle.cached_query(H.oracle_grid_from_cached(cached), pts[:n_chk].cpu().numpy())
+    max_err = float(np.nanmax(np.abs(val[:n_chk].cpu().numpy() - oval)))
+    grad_mismatch = int((~np.isclose(grad[:n_chk].cpu().numpy(), ograd, rtol=0, atol=0, equal_nan=True)).sum())
+
+    out = None
+    if rank == 0:
+        qps = world * P * args.steps / elapsed
+        achieved = BYTES_PER_QUERY * P / (k_mean * 1e-3) / 1e9
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "traffic.json")
+        if os.path.exists(tpath):
+            try:
+                tj = json.load(open(tpath))
+                if tj.get("points") == P:
+                    traffic = tj.get("hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        out = {
+            "metric": "SDF (val+grad) queries/sec", "value": qps, "unit": "queries/s", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "C2: CachedSDF 0.01 m voxels (37x33x40, packed 16 B/voxel) on YcbPowerDrill, "
+                                   f"{P} uniform query points per GPU per step, BOUNDING_BOX out-of-range fallback",
+                       "points_per_gpu": P, "oob_fraction": float(ooob.mean()),
+                       "index_dtype": "f64" if cached._view.index_f64 else "f32",
+                       "launch": "hipGraph of K steps" if graph is not None else "eager",
+                       "gather": bool(gathered is not None), "parallelism": f"points x{world}"},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "kernel": "cached_query_vec4", "kernel_ms_mean": k_mean, "kernel_ms_median": k_med,
+                         "kernel_ms_min": k_min, "algorithmic_bytes_per_launch": BYTES_PER_QUERY * P},
+            "parity": {"checked_points": n_chk, "max_abs_val_err_vs_oracle": max_err,
+                       "grad_mismatches_vs_oracle": grad_mismatch},
+        }
+        if not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(cached, pts, args.cpu_seconds)
+
+    if not args.no_large and rank == 0 and world == 1:
+        # secondary: a batch far beyond the 256 MB Infinity Cache, where the kernel is HBM- rather than launch-bound
+        PL = 1 << 26
+        g = torch.Generator(device="cuda").manual_seed(99)
+        lo = torch.tensor([r[0] for r in cached.ranges], dtype=torch.float32, device="cuda") - 0.05
+        hi = torch.tensor([r[1] for r in cached.ranges], dtype=torch.float32, device="cuda") + 0.05
+        big = (torch.rand((PL, 3), generator=g, device="cuda") * (hi - lo) + lo).contiguous()
+        bval = torch.empty((PL,), dtype=torch.float32, device="cuda")
+        bgrad = torch.empty((PL, 3), dtype=torch.float32, device="cuda")
+        for _ in range(3):
+            cached.query_into(big, bval, bgrad)
+        m, md, mn = time_eager_kernel(cached, big, bval, bgrad, 20)
+        out["large_batch"] = {"points": PL, "kernel_ms_mean": m, "queries_per_s": PL / (m * 1e-3),
+                              "achieved_GBs": BYTES_PER_QUERY * PL / (m * 1e-3) / 1e9,
+                              "frac_of_8TBs": BYTES_PER_QUERY * PL / (m * 1e-3) / 1e9 / HBM_PEAK_GBS}
+        del big, bval, bgrad
+
+    if rank == 0:
+        print(json.dumps(out))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,148 @@
+/*
+ * pvamd.h -- C ABI of libpvamd.so, the MI355X (gfx950) batched SDF query engine.
+ *
+ * The reference (UM-ARM-Lab/pytorch_volumetric @ 0.5.2) has no FFI: its boundary is the Python
+ * ObjectFrameSDF protocol (sdf.py:217-246).  These entry points are what the Python classes in
+ * pytorch_volumetric_amd/ bind with ctypes; each one replaces a *sequence* of stock torch ops /
+ * Embree calls in the reference, cited per function below (paths relative to
+ * src/pytorch_volumetric/ in the reference).
+ *
+ * Conventions (all entry points):
+ *   - extern "C"; return 0 on success, <0 = invalid argument (PVAMD_E_*), >0 = hipError_t.
+ *   - every pointer documented "device" is a device (HBM) address; "host" is ordinary memory.
+ *   - fp32 buffers are dense row-major; points are AoS [P][3].
+ *   - work is enqueued on `stream` (a hipStream_t passed as void*) and the call returns without
+ *     synchronising; nothing is allocated or freed; no static mutable state (re-entrant).
+ *   - 4x4 transforms are row-major, column-vector convention: x' = M[:3,:3] x + M[:3,3]
+ *     (chamfer.py:14, tests/test_model_to_sdf.py:277-279).
+ */
+#ifndef PVAMD_H
+#define PVAMD_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PVAMD_ABI_VERSION 1
+
+#define PVAMD_E_NULL      (-1)  /* a required pointer is NULL            */
+#define PVAMD_E_SHAPE     (-2)  /* a size/shape argument is out of range */
+#define PVAMD_E_ALIGN     (-3)  /* a pointer is not 4-byte aligned       */
+#define PVAMD_E_MODE      (-4)  /* unknown enum value                    */
+
+/* sdf.py:436-438 OutOfBoundsStrategy */
+#define PVAMD_OOB_LOOKUP_GT_SDF 0   /* kernel writes zeros + sets out_oob; caller queries gt_sdf on that subset */
+#define PVAMD_OOB_BOUNDING_BOX  1   /* distance to the (unpadded) surface bounding box, sdf.py:555-571          */
+
+/*
+ * One cached voxel grid = the read-only state of a CachedSDF (sdf.py:441-525) plus the value-range
+ * view the reference wraps around it (multidim_indexing TorchMultidimView, constructed sdf.py:521).
+ *
+ * HBM layout: ONE 16-byte record per voxel, vox[flat] = (val, gx, gy, gz), flat = (kx*ny + ky)*nz + kz
+ * (C order: x slowest, z fastest -- voxel.py:20-25 cartesian_prod, sdf.py:504-505).  The reference keeps
+ * two arrays (val [nx,ny,nz] and grad [n,3]); packing makes a query one 16-B gather.
+ *
+ * Index arithmetic is carried out in the dtype the reference's torch promotion would use:
+ * index_f64 = 1 when the value range reached the view as float64 (numpy ranges, the README flow),
+ * 0 when it reached it as float32 (python-float ranges).  Both triples are always filled in.
+ */
+typedef struct pvamd_grid {
+    const float* vox;        /* device, [nx*ny*nz][4]                                              */
+    double       dmin[3];    /* range minimum per dim (float64 view)                               */
+    double       dmax[3];    /* range maximum per dim                                              */
+    double       dres[3];    /* (dmax-dmin)/(shape-1) evaluated in float64                         */
+    float        fmin[3];    /* float32(range min)                                                 */
+    float        fmax[3];    /* float32(range max)                                                 */
+    float        fres[3];    /* (fmax-fmin)/float32(shape-1) evaluated in float32                  */
+    float        bb_min[3];  /* gt_sdf.surface_bounding_box()[:,0], NO padding (sdf.py:525)        */
+    float        bb_max[3];  /* ...[:,1]                                                           */
+    int32_t      shape[3];   /* nx, ny, nz (each >= 2)                                             */
+    int32_t      index_f64;  /* see above                                                          */
+    int32_t      oob_mode;   /* PVAMD_OOB_*                                                        */
+    int32_t      reserved;
+} pvamd_grid_t;
+
+/*
+ * One triangle mesh = the read-only state of an ObjectFactory after precompute_sdf (sdf.py:97-120).
+ * tri:    device [F][3][3] fp32 triangle soup (vertex a, b, c of face f; already scaled / rotated / translated)
+ * normal: device [F][3] fp32 unit face normals (sdf.py:119-120)
+ * ray_dir: the reference passes bounding_box(padding=1.0)[:,1] as the last three floats of each ray
+ *          (sdf.py:147-152); open3d reads those as the ray DIRECTION (tnear=0, tfar=inf).  Kept as float64
+ *          because the reference adds its jitter in float64 before rounding to float32 (sdf.py:149-150).
+ */
+typedef struct pvamd_mesh {
+    const float* tri;        /* device */
+    const float* normal;     /* device */
+    int32_t      F;
+    int32_t      reserved;
+    double       ray_dir[3];
+} pvamd_mesh_t;
+
+int         pvamd_abi_version(void);
+const char* pvamd_build_info(void);      /* static string: arch, compiler, build flags */
+/* number of devices visible / name of device 0 -- lets a host language check the GPU without a HIP binding */
+int         pvamd_device_count(void);
+
+/* Build the packed voxel layout on device: out[i] = (val[i], grad[i][0..2]).  Replaces nothing in the
+ * reference (layout choice); feeds every grid entry point.  val: device [n], grad: device [n][3], out: device [n][4]. */
+int pvamd_pack_grid(const float* val, const float* grad, int64_t n, float* out, void* stream);
+
+/* CachedSDF.__call__ (sdf.py:535-571): nearest-voxel lookup of (val, grad) with out-of-bounds handling.
+ * grid: host.  points: device [P][3].  out_val: device [P].  out_grad: device [P][3].
+ * out_oob: device [P] bytes or NULL; 1 where the point failed the range test (sdf.py:540-541).        */
+int pvamd_cached_query(const pvamd_grid_t* grid, const float* points, int64_t P,
+                       float* out_val, float* out_grad, uint8_t* out_oob, void* stream);
+
+/* CachedSDF.outside_surface (sdf.py:593-602): OOB -> 1, else vox.val > level.  out: device [P] bytes. */
+int pvamd_cached_outside(const pvamd_grid_t* grid, const float* points, int64_t P, float level,
+                         uint8_t* out, void* stream);
+
+/* Voxel index arithmetic alone (TorchMultidimView.ensure_index_key / ravel_multi_index / get_valid_values as
+ * used at sdf.py:537-540): out_key device [P][3] int64, out_flat device [P] int64, out_valid device [P] bytes.
+ * Any output may be NULL.  This is the entry point the bit-exact index tests call.                     */
+int pvamd_voxel_index(const pvamd_grid_t* grid, const float* points, int64_t P,
+                      int64_t* out_key, int64_t* out_flat, uint8_t* out_valid, void* stream);
+
+/* ComposedSDF.__call__ over CachedSDF leaves (sdf.py:392-433 + 535-571 fused; also RobotSDF.__call__,
+ * model_to_sdf.py:117-125): per configuration a and point p, x_s = T[s*A+a] p for every leaf s, look up leaf
+ * s at x_s, rotate that gradient back with R^T, keep the first minimum over s.
+ * grids: device [S] pvamd_grid_t (every oob_mode must be BOUNDING_BOX).  tf: device [S*A][4][4] obj->leaf,
+ * leaf-major (model_to_sdf.py:100-113).  out_val: device [A][P].  out_grad: device [A][P][3].
+ * out_leaf: device [A][P] int32 or NULL (arg-min leaf, for tests).                                      */
+int pvamd_composed_query(const pvamd_grid_t* grids, int32_t S, const float* tf, int32_t A,
+                         const float* points, int64_t P,
+                         float* out_val, float* out_grad, int32_t* out_leaf, void* stream);
+
+/* ObjectFactory._do_object_frame_closest_point (sdf.py:122-172): closest surface point, signed distance by
+ * ray-hit parity, gradient, face id, optional face normal.
+ * mesh: host struct with device pointers.  jitter_seed: counter-based replacement for the reference's unseeded
+ * np.random.randn (sdf.py:149); index_base = global index of points[0], so that a query sharded across GPUs
+ * draws the jitter an unsharded one would.  out_closest: device [P][3] or NULL.  out_dist: device [P].  out_grad: device
+ * [P][3].  out_face: device [P] int32 or NULL.  out_normal: device [P][3] or NULL (compute_normal=True).     */
+int pvamd_mesh_query(const pvamd_mesh_t* mesh, const float* points, int64_t P, uint64_t jitter_seed,
+                     int64_t index_base, float* out_closest, float* out_dist, float* out_grad, int32_t* out_face,
+                     float* out_normal, void* stream);
+
+/* batch_chamfer_dist (chamfer.py:79-94) against a mesh: for each of B world->object transforms, transform the
+ * N points, unsigned distance to the mesh, accumulate sum_n (scale*d)^2.  The caller divides by the GLOBAL N
+ * (after an all-reduce when the points are sharded across GPUs).
+ * W: device [B][4][4].  points: device [N][3].  out_sum: device [B] float64, ZEROED by this call.       */
+int pvamd_chamfer_mesh(const pvamd_mesh_t* mesh, const float* W, int32_t B, const float* points, int64_t N,
+                       float scale, double* out_sum, void* stream);
+
+/* Same against a cached grid (obj_sdf branch, chamfer.py:84-85).  grid: host.                            */
+int pvamd_chamfer_grid(const pvamd_grid_t* grid, const float* W, int32_t B, const float* points, int64_t N,
+                       float scale, double* out_sum, void* stream);
+
+/* RobotSDF.set_joint_configuration's contraction (model_to_sdf.py:104-113): out[s*A+a] = offset_inv[s] @
+ * rigid_inverse(link_world[s*A+a]).  offset_inv: device [S][4][4].  link_world: device [S*A][4][4] leaf-major.
+ * out: device [S*A][4][4].  The 4x4x4 products run on the f32 MFMA (v_mfma_f32_4x4x1_16b_f32).            */
+int pvamd_transform_stack(const float* offset_inv, const float* link_world, int32_t S, int32_t A,
+                          float* out, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PVAMD_H */

@@ -1,0 +1,197 @@
+"""numpy-facing loader for oracle/libpvamd_oracle.so (the C restatement of the reference's hot path).
+
+TEST INFRASTRUCTURE ONLY: the checker for the HIP kernels and the timed CPU baseline in bench.py.  Parity status of
+the oracle itself: third-party arithmetic UNPINNED (the reference cannot be imported here); see the header of
+pvamd_oracle.c and DESIGN.md section "Oracle".
+"""
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libpvamd_oracle.so")
+
+
+class OracleGrid(ctypes.Structure):
+    _fields_ = [
+        ("val", ctypes.c_void_p), ("grad", ctypes.c_void_p),
+        ("dmin", ctypes.c_double * 3), ("dmax", ctypes.c_double * 3), ("dres", ctypes.c_double * 3),
+        ("fmin", ctypes.c_float * 3), ("fmax", ctypes.c_float * 3), ("fres", ctypes.c_float * 3),
+        ("bb_min", ctypes.c_float * 3), ("bb_max", ctypes.c_float * 3),
+        ("shape", ctypes.c_int32 * 3), ("index_f64", ctypes.c_int32), ("oob_mode", ctypes.c_int32),
+        ("reserved", ctypes.c_int32),
+    ]
+
+
+class OracleMesh(ctypes.Structure):
+    _fields_ = [("tri", ctypes.c_void_p), ("normal", ctypes.c_void_p), ("F", ctypes.c_int32),
+                ("reserved", ctypes.c_int32), ("ray_dir", ctypes.c_double * 3)]
+
+
+_lib = None
+
+
+def build():
+    subprocess.run(["make", "-s", "-C", _HERE], check=True)
+
+
+def load():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            build()
+        _lib = ctypes.CDLL(LIB_PATH)
+        _lib.oracle_num_threads.restype = ctypes.c_int
+    return _lib
+
+
+def num_threads():
+    return load().oracle_num_threads()
+
+
+def set_num_threads(n):
+    load().oracle_set_num_threads(int(n))
+
+
+def _f32(a):
+    return np.ascontiguousarray(a, dtype=np.float32)
+
+
+def _p(a):
+    return ctypes.c_void_p(a.ctypes.data) if a is not None else ctypes.c_void_p(0)
+
+
+class Grid:
+    """A cached grid in the REFERENCE's layout: val [nx,ny,nz] + grad [n,3] (sdf.py:504-505), plus the view numbers.
+
+    range_min / range_max: length-3 sequences; their numpy dtype (float32 / float64) selects the index dtype the way
+    torch promotion does in the reference."""
+
+    def __init__(self, val, grad, range_min, range_max, bb, oob_mode=1, index_f64=None):
+        self.val = _f32(val)
+        self.shape = tuple(self.val.shape)
+        self.grad = _f32(grad).reshape(-1, 3)
+        rmin, rmax = np.asarray(range_min), np.asarray(range_max)
+        if index_f64 is None:
+            index_f64 = rmin.dtype == np.float64
+        self.index_f64 = bool(index_f64)
+        g = OracleGrid()
+        g.val, g.grad = self.val.ctypes.data, self.grad.ctypes.data
+        cells = np.array(self.shape, dtype=np.int64) - 1
+        if self.index_f64:
+            dmin, dmax = rmin.astype(np.float64), rmax.astype(np.float64)
+            dres = (dmax - dmin) / cells
+            fmin, fmax, fres = dmin.astype(np.float32), dmax.astype(np.float32), dres.astype(np.float32)
+        else:
+            fmin, fmax = rmin.astype(np.float32), rmax.astype(np.float32)
+            fres = ((fmax - fmin) / cells.astype(np.float32)).astype(np.float32)
+            dmin, dmax, dres = fmin.astype(np.float64), fmax.astype(np.float64), fres.astype(np.float64)
+        bb = np.asarray(bb, dtype=np.float32).reshape(3, 2)
+        for d in range(3):
+            g.dmin[d], g.dmax[d], g.dres[d] = dmin[d], dmax[d], dres[d]
+            g.fmin[d], g.fmax[d], g.fres[d] = fmin[d], fmax[d], fres[d]
+            g.bb_min[d], g.bb_max[d] = bb[d, 0], bb[d, 1]
+            g.shape[d] = self.shape[d]
+        g.index_f64 = int(self.index_f64)
+        g.oob_mode = int(oob_mode)
+        self.c = g
+
+
+def voxel_index(grid, pts):
+    pts = _f32(pts).reshape(-1, 3)
+    P = len(pts)
+    key = np.empty((P, 3), np.int64)
+    flat = np.empty((P,), np.int64)
+    valid = np.empty((P,), np.uint8)
+    load().oracle_voxel_index(ctypes.byref(grid.c), _p(pts), ctypes.c_int64(P), _p(key), _p(flat), _p(valid))
+    return key, flat, valid.astype(bool)
+
+
+def cached_query(grid, pts):
+    pts = _f32(pts).reshape(-1, 3)
+    P = len(pts)
+    val = np.empty((P,), np.float32)
+    grad = np.empty((P, 3), np.float32)
+    oob = np.empty((P,), np.uint8)
+    load().oracle_cached_query(ctypes.byref(grid.c), _p(pts), ctypes.c_int64(P), _p(val), _p(grad), _p(oob))
+    return val, grad, oob.astype(bool)
+
+
+def cached_outside(grid, pts, level=0.0):
+    pts = _f32(pts).reshape(-1, 3)
+    out = np.empty((len(pts),), np.uint8)
+    load().oracle_cached_outside(ctypes.byref(grid.c), _p(pts), ctypes.c_int64(len(pts)), ctypes.c_float(level), _p(out))
+    return out.astype(bool)
+
+
+def composed_query(grids, tf, A, pts):
+    """grids: list of S Grid; tf: [S*A,4,4] obj->leaf leaf-major; returns val [A,P], grad [A,P,3], leaf [A,P]."""
+    S = len(grids)
+    arr = (OracleGrid * S)(*[g.c for g in grids])
+    tf = _f32(tf).reshape(S * A, 16)
+    pts = _f32(pts).reshape(-1, 3)
+    P = len(pts)
+    val = np.empty((A, P), np.float32)
+    grad = np.empty((A, P, 3), np.float32)
+    leaf = np.empty((A, P), np.int32)
+    load().oracle_composed_query(arr, ctypes.c_int32(S), _p(tf), ctypes.c_int32(A), _p(pts), ctypes.c_int64(P), _p(val),
+                                 _p(grad), _p(leaf))
+    return val, grad, leaf
+
+
+class Mesh:
+    def __init__(self, tri, normal, ray_dir):
+        self.tri = _f32(tri).reshape(-1, 3, 3)
+        self.normal = _f32(normal).reshape(-1, 3)
+        m = OracleMesh()
+        m.tri, m.normal, m.F = self.tri.ctypes.data, self.normal.ctypes.data, len(self.tri)
+        for d in range(3):
+            m.ray_dir[d] = float(ray_dir[d])
+        self.c = m
+
+
+def mesh_query(mesh, pts, seed=0, index_base=0):
+    pts = _f32(pts).reshape(-1, 3)
+    P = len(pts)
+    closest = np.empty((P, 3), np.float32)
+    dist = np.empty((P,), np.float32)
+    grad = np.empty((P, 3), np.float32)
+    face = np.empty((P,), np.int32)
+    normal = np.empty((P, 3), np.float32)
+    load().oracle_mesh_query(ctypes.byref(mesh.c), _p(pts), ctypes.c_int64(P), ctypes.c_uint64(seed),
+                             ctypes.c_int64(index_base), _p(closest), _p(dist), _p(grad), _p(face), _p(normal))
+    return closest, dist, grad, face, normal
+
+
+def jitter_dir(mesh, seed, index):
+    out = np.empty((3,), np.float32)
+    load().oracle_jitter_dir(ctypes.byref(mesh.c), ctypes.c_uint64(seed), ctypes.c_int64(index), _p(out))
+    return out
+
+
+def chamfer_mesh(mesh, W, pts, scale=1000.0):
+    W = _f32(W).reshape(-1, 16)
+    pts = _f32(pts).reshape(-1, 3)
+    out = np.empty((len(W),), np.float64)
+    load().oracle_chamfer_mesh(ctypes.byref(mesh.c), _p(W), ctypes.c_int32(len(W)), _p(pts), ctypes.c_int64(len(pts)),
+                               ctypes.c_float(scale), _p(out))
+    return out
+
+
+def chamfer_grid(grid, W, pts, scale=1000.0):
+    W = _f32(W).reshape(-1, 16)
+    pts = _f32(pts).reshape(-1, 3)
+    out = np.empty((len(W),), np.float64)
+    load().oracle_chamfer_grid(ctypes.byref(grid.c), _p(W), ctypes.c_int32(len(W)), _p(pts), ctypes.c_int64(len(pts)),
+                               ctypes.c_float(scale), _p(out))
+    return out
+
+
+def transform_stack(offset_inv, link_world, S, A):
+    offset_inv = _f32(offset_inv).reshape(S, 16)
+    link_world = _f32(link_world).reshape(S * A, 16)
+    out = np.empty((S * A, 4, 4), np.float32)
+    load().oracle_transform_stack(_p(offset_inv), _p(link_world), ctypes.c_int32(S), ctypes.c_int32(A), _p(out))
+    return out

@@ -1,0 +1,145 @@
+"""ctypes binding of libpvamd.so (C ABI in include/pvamd.h).
+
+The HIP library is the only compute path of this package: there is no CPU or eager-PyTorch fallback.  Loading
+fails loudly if the shared object is missing, and every query raises if no MI355X is visible.
+"""
+import ctypes
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libpvamd.so")
+
+ABI_VERSION = 1
+OOB_LOOKUP_GT_SDF = 0
+OOB_BOUNDING_BOX = 1
+
+_c_float_p = ctypes.POINTER(ctypes.c_float)
+
+
+class GridDesc(ctypes.Structure):
+    """pvamd_grid_t"""
+    _fields_ = [
+        ("vox", ctypes.c_void_p),
+        ("dmin", ctypes.c_double * 3),
+        ("dmax", ctypes.c_double * 3),
+        ("dres", ctypes.c_double * 3),
+        ("fmin", ctypes.c_float * 3),
+        ("fmax", ctypes.c_float * 3),
+        ("fres", ctypes.c_float * 3),
+        ("bb_min", ctypes.c_float * 3),
+        ("bb_max", ctypes.c_float * 3),
+        ("shape", ctypes.c_int32 * 3),
+        ("index_f64", ctypes.c_int32),
+        ("oob_mode", ctypes.c_int32),
+        ("reserved", ctypes.c_int32),
+    ]
+
+
+class MeshDesc(ctypes.Structure):
+    """pvamd_mesh_t"""
+    _fields_ = [
+        ("tri", ctypes.c_void_p),
+        ("normal", ctypes.c_void_p),
+        ("F", ctypes.c_int32),
+        ("reserved", ctypes.c_int32),
+        ("ray_dir", ctypes.c_double * 3),
+    ]
+
+
+# name -> (restype, argtypes); the test-suite checks every one of these is exported by the .so and declared in
+# include/pvamd.h
+SIGNATURES = {
+    "pvamd_abi_version": (ctypes.c_int, []),
+    "pvamd_build_info": (ctypes.c_char_p, []),
+    "pvamd_device_count": (ctypes.c_int, []),
+    "pvamd_pack_grid": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p,
+                                       ctypes.c_void_p]),
+    "pvamd_cached_query": (ctypes.c_int, [ctypes.POINTER(GridDesc), ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p,
+                                          ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]),
+    "pvamd_cached_outside": (ctypes.c_int, [ctypes.POINTER(GridDesc), ctypes.c_void_p, ctypes.c_int64,
+                                            ctypes.c_float, ctypes.c_void_p, ctypes.c_void_p]),
+    "pvamd_voxel_index": (ctypes.c_int, [ctypes.POINTER(GridDesc), ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p,
+                                         ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]),
+    "pvamd_composed_query": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int32, ctypes.c_void_p, ctypes.c_int32,
+                                            ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p,
+                                            ctypes.c_void_p, ctypes.c_void_p]),
+    "pvamd_mesh_query": (ctypes.c_int, [ctypes.POINTER(MeshDesc), ctypes.c_void_p, ctypes.c_int64, ctypes.c_uint64,
+                                        ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
+                                        ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]),
+    "pvamd_chamfer_mesh": (ctypes.c_int, [ctypes.POINTER(MeshDesc), ctypes.c_void_p, ctypes.c_int32, ctypes.c_void_p,
+                                          ctypes.c_int64, ctypes.c_float, ctypes.c_void_p, ctypes.c_void_p]),
+    "pvamd_chamfer_grid": (ctypes.c_int, [ctypes.POINTER(GridDesc), ctypes.c_void_p, ctypes.c_int32, ctypes.c_void_p,
+                                          ctypes.c_int64, ctypes.c_float, ctypes.c_void_p, ctypes.c_void_p]),
+    "pvamd_transform_stack": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int32, ctypes.c_int32,
+                                             ctypes.c_void_p, ctypes.c_void_p]),
+}
+
+_ERRORS = {-1: "a required pointer is NULL", -2: "a size/shape argument is out of range",
+           -3: "a pointer is misaligned", -4: "unknown enum value"}
+
+_lib = None
+
+
+class PvamdError(RuntimeError):
+    pass
+
+
+def load():
+    """Load libpvamd.so once; raise if it has not been built (python __graft_entry__.py build)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise PvamdError(
+            f"{LIB_PATH} not found: the HIP extension has not been built. Run `python -c 'import __graft_entry__ as g; "
+            f"g.build()'` (or `make -C pytorch_volumetric_amd/csrc`) from the repository root. There is no CPU fallback.")
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (restype, argtypes) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the symbol is missing
+        fn.restype = restype
+        fn.argtypes = argtypes
+    if lib.pvamd_abi_version() != ABI_VERSION:
+        raise PvamdError(f"libpvamd ABI {lib.pvamd_abi_version()} != binding ABI {ABI_VERSION}; rebuild")
+    _lib = lib
+    return lib
+
+
+def check(code, what):
+    if code == 0:
+        return
+    if code < 0:
+        raise PvamdError(f"{what}: invalid argument ({_ERRORS.get(code, code)})")
+    raise PvamdError(f"{what}: hipError_t {code}")
+
+
+def require_gpu():
+    """The compute device of this package.  No GPU -> loud failure (never a silent CPU path)."""
+    if not torch.cuda.is_available():
+        raise PvamdError("pytorch_volumetric_amd needs an AMD MI355X (gfx950) visible to PyTorch-ROCm; "
+                         "torch.cuda.is_available() is False and there is no CPU fallback")
+    return torch.device("cuda", torch.cuda.current_device())
+
+
+def stream_ptr():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def ptr(t):
+    """Device address of a tensor (None -> NULL)."""
+    if t is None:
+        return ctypes.c_void_p(0)
+    return ctypes.c_void_p(t.data_ptr())
+
+
+def as_query_points(points):
+    """[..., 3] any float dtype / device  ->  (contiguous fp32 [P,3] on the GPU, leading shape, dtype, device)."""
+    if not torch.is_tensor(points):
+        points = torch.as_tensor(points)
+    if points.shape[-1] != 3:
+        raise ValueError(f"query points must have last dimension 3, got {tuple(points.shape)}")
+    dev = require_gpu()
+    lead = points.shape[:-1]
+    flat = points.detach().reshape(-1, 3).to(device=dev, dtype=torch.float32).contiguous()
+    return flat, lead, points.dtype if points.dtype.is_floating_point else torch.float32, points.device

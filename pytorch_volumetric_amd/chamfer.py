@@ -1,0 +1,145 @@
+"""Unidirectional points -> object chamfer distance and the pose-set metrics built on it
+(reference chamfer.py:12-195).  `batch_chamfer_dist` is one fused kernel per call (transform, distance, squared
+reduction); the callers stay thin Python like the reference's."""
+from typing import NamedTuple
+
+import ctypes
+import torch
+
+from pytorch_volumetric_amd import _lib
+from pytorch_volumetric_amd import transforms as tf
+from pytorch_volumetric_amd.sdf import ObjectFactory, ObjectFrameSDF, CachedSDF, OutOfBoundsStrategy, \
+    sample_mesh_points
+
+
+def _matrix_to_rotation_6d(r):
+    return r[..., :2, :].clone().reshape(*r.shape[:-2], 6)
+
+
+def pairwise_distance(world_to_link_tfs):
+    """cdist over (translation, 6-D rotation) pose vectors (chamfer.py:12-17)."""
+    m = tf.as_matrix(world_to_link_tfs)
+    cont_rep = torch.cat((m[:, :3, 3], _matrix_to_rotation_6d(m[:, :3, :3])), dim=1)
+    return torch.cdist(cont_rep, cont_rep)
+
+
+def batch_chamfer_dist(world_to_object: torch.tensor, model_points_world_frame_eval: torch.tensor,
+                       obj_factory: ObjectFactory = None, obj_sdf: ObjectFrameSDF = None, viewing_delay=0, scale=1000.,
+                       print_err=False, vis=None, reduce_group=None):
+    """
+    Batched unidirectional chamfer distance between world-frame surface points and an object under B candidate
+    world->object transforms (chamfer.py:62-94).
+
+    :param world_to_object: B x 4 x 4 transforms from world to object frame
+    :param model_points_world_frame_eval: N x 3 points
+    :param obj_factory: object (mesh) to evaluate against
+    :param obj_sdf: SDF of the object to evaluate against (faster, less accurate); takes precedence like the reference
+    :param scale: unit conversion applied to the distance before squaring (1000: m -> mm)
+    :param reduce_group: optional torch.distributed group over which the N points are sharded: partial sums are
+        all-reduced and divided by the global N
+    :return: B chamfer errors, mean over the N points of (scale * d)^2
+    """
+    W = tf.as_matrix(world_to_object)
+    out_dtype, out_device = W.dtype, W.device
+    B = W.shape[0]
+    if obj_sdf is None and obj_factory is None:
+        raise ValueError("Either obj_sdf or obj_factory must be given")
+    lib = _lib.load()
+    dev = _lib.require_gpu()
+    pts = torch.as_tensor(model_points_world_frame_eval).detach().reshape(-1, 3).to(device=dev, dtype=torch.float32)
+    pts = pts.contiguous()
+    N = pts.shape[0]
+    Wd = W.detach().to(device=dev, dtype=torch.float32).contiguous()
+    sums = torch.empty((B,), dtype=torch.float64, device=dev)
+
+    fused_grid = isinstance(obj_sdf, CachedSDF) and obj_sdf.out_of_bounds_strategy == OutOfBoundsStrategy.BOUNDING_BOX
+    with torch.cuda.device(dev):
+        if fused_grid:
+            desc = obj_sdf._grid_desc()
+            _lib.check(lib.pvamd_chamfer_grid(ctypes.byref(desc), _lib.ptr(Wd), B, _lib.ptr(pts), N, float(scale),
+                                              _lib.ptr(sums), _lib.stream_ptr()), "pvamd_chamfer_grid")
+        elif obj_sdf is not None:
+            # arbitrary SDF object: transform on device, query it, reduce
+            x = pts.unsqueeze(0) @ Wd[:, :3, :3].transpose(-1, -2) + Wd[:, None, :3, 3]
+            d, _ = obj_sdf(x)
+            sums = ((float(scale) * d.to(device=dev, dtype=torch.float32)) ** 2).double().sum(dim=-1)
+        else:
+            desc = obj_factory._mesh_desc()
+            _lib.check(lib.pvamd_chamfer_mesh(ctypes.byref(desc), _lib.ptr(Wd), B, _lib.ptr(pts), N, float(scale),
+                                              _lib.ptr(sums), _lib.stream_ptr()), "pvamd_chamfer_mesh")
+    total_n = N
+    if reduce_group is not None:
+        import torch.distributed as dist
+        count = torch.tensor([float(N)], dtype=torch.float64, device=dev)
+        dist.all_reduce(sums, op=dist.ReduceOp.SUM, group=reduce_group)
+        dist.all_reduce(count, op=dist.ReduceOp.SUM, group=reduce_group)
+        total_n = count.item()
+    return (sums / total_n).to(device=out_device, dtype=out_dtype)
+
+
+def pairwise_distance_chamfer(A_link_to_world_tfs, B_world_to_link_tfs=None,
+                              obj_factory: ObjectFactory = None, obj_sdf: ObjectFrameSDF = None,
+                              model_points_eval: torch.tensor = None, vis=None, scale=1000):
+    """B x P chamfer matrix between two sets of poses of one object (chamfer.py:20-59)."""
+    T = tf.as_matrix(A_link_to_world_tfs)
+    if model_points_eval is None:
+        model_points_eval, _, _ = sample_mesh_points(obj_factory, num_points=500, name=obj_factory.name,
+                                                     device=T.device)
+    T_inv = tf.rigid_inverse(T) if B_world_to_link_tfs is None else tf.as_matrix(B_world_to_link_tfs)
+    Iapprox = torch.einsum("bij,pjk->bpik", T_inv, T)
+    B, P = len(T), len(T_inv)
+    errors = batch_chamfer_dist(Iapprox.reshape(B * P, 4, 4), model_points_eval, obj_factory=obj_factory,
+                                obj_sdf=obj_sdf, viewing_delay=0, vis=vis, scale=scale)
+    return errors.view(B, P)
+
+
+class PlausibleDiversityReturn(NamedTuple):
+    plausibility: torch.tensor
+    coverage: torch.tensor
+    most_plausible_per_estimated: torch.tensor
+    most_covered_per_plausible: torch.tensor
+
+
+class PlausibleDiversity:
+    """Plausibility / coverage of an estimated pose set against a plausible pose set, in squared distance units
+    (chamfer.py:130-195)."""
+
+    def __init__(self, obj_factory: ObjectFactory, model_points_eval: torch.tensor = None, num_model_points_eval=500,
+                 obj_sdf: ObjectFrameSDF = None):
+        self.obj_factory = obj_factory
+        self.obj_sdf = obj_sdf
+        if model_points_eval is None:
+            model_points_eval, _, _ = sample_mesh_points(obj_factory, num_points=num_model_points_eval,
+                                                         name=obj_factory.name)
+        self.model_points_eval = model_points_eval
+
+    def __call__(self, T_est_inv, T_p, bidirectional=False, scale=1000.):
+        errors = self.compute_tf_pairwise_error_per_batch(T_est_inv, T_p, scale=scale)
+        ret = self.do_evaluate_plausible_diversity_on_pairwise_chamfer_dist(errors)
+        if bidirectional:
+            errors_rev = self.compute_tf_pairwise_error_per_batch(T_p, T_est_inv, scale=scale)
+            ret2 = self.do_evaluate_plausible_diversity_on_pairwise_chamfer_dist(errors_rev)
+            # plausibility and coverage swap roles when the two sets are swapped
+            ret = PlausibleDiversityReturn(
+                plausibility=(ret.plausibility + ret2.coverage) / 2,
+                coverage=(ret.coverage + ret2.plausibility) / 2,
+                most_plausible_per_estimated=ret.most_plausible_per_estimated,
+                most_covered_per_plausible=ret.most_covered_per_plausible,
+            )
+        return ret
+
+    def compute_tf_pairwise_error_per_batch(self, T_est_inv, T_p, scale=1000.):
+        Iapprox = torch.einsum("bij,pjk->bpik", T_est_inv, T_p)
+        B, P = Iapprox.shape[:2]
+        self.model_points_eval = self.model_points_eval.to(device=Iapprox.device, dtype=Iapprox.dtype)
+        errors = batch_chamfer_dist(Iapprox.reshape(B * P, 4, 4), self.model_points_eval, self.obj_factory,
+                                    obj_sdf=self.obj_sdf, viewing_delay=0, vis=None, scale=scale)
+        return errors.view(B, P)
+
+    @staticmethod
+    def do_evaluate_plausible_diversity_on_pairwise_chamfer_dist(errors_per_batch):
+        B, P = errors_per_batch.shape
+        best_per_sampled = errors_per_batch.min(dim=1)
+        best_per_plausible = errors_per_batch.min(dim=0)
+        return PlausibleDiversityReturn(best_per_sampled.values.sum() / B, best_per_plausible.values.sum() / P,
+                                        best_per_sampled, best_per_plausible)

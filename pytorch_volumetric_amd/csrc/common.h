@@ -1,0 +1,36 @@
+// Host-side helpers shared by the C-ABI translation units.  gfx950 (MI355X) only.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/pvamd.h"
+
+namespace pvamd {
+
+// native clang vectors: the non-temporal builtins and 16-B global_load/store_dwordx4 want these, not HIP's structs
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+constexpr int kNumCU = 256;         // MI355X: 8 XCDs x 32 CUs
+constexpr int kMaxBlocksPerCU = 8;  // memory-bound kernels: cap the grid at 256 CU x 8 and grid-stride the rest
+
+static inline bool aligned_to(const void* p, uintptr_t a) { return (reinterpret_cast<uintptr_t>(p) % a) == 0; }
+
+// grid size for a streaming kernel over n items with `block` threads
+static inline unsigned stream_grid(int64_t n, int block) {
+    const int64_t need = (n + block - 1) / block;
+    const int64_t cap = (int64_t)kNumCU * kMaxBlocksPerCU;
+    return (unsigned)(need < cap ? (need < 1 ? 1 : need) : cap);
+}
+
+static inline int check_grid(const pvamd_grid_t& g, bool need_vox = true) {
+    if (need_vox && !g.vox) return PVAMD_E_NULL;
+    if (need_vox && !aligned_to(g.vox, 16)) return PVAMD_E_ALIGN;
+    for (int d = 0; d < 3; ++d) {
+        if (g.shape[d] < 2) return PVAMD_E_SHAPE;
+    }
+    if ((int64_t)g.shape[0] * g.shape[1] * g.shape[2] > (int64_t)INT32_MAX) return PVAMD_E_SHAPE;
+    if (g.oob_mode != PVAMD_OOB_LOOKUP_GT_SDF && g.oob_mode != PVAMD_OOB_BOUNDING_BOX) return PVAMD_E_MODE;
+    return 0;
+}
+
+}  // namespace pvamd

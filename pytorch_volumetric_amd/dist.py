@@ -1,0 +1,94 @@
+"""Multi-GPU sharding of SDF queries: one process per GPU, query points split across ranks, one all-gather
+(RCCL over xGMI when the backend is "nccl") to reassemble (sdf_val, sdf_grad).
+
+Every query point is independent (reference sdf.py:535-591, 392-433, 122-172 have no cross-point term), the
+read-only state (voxel grids, meshes, transforms) is small and replicated on every GPU, so the only communication
+is the gather of the outputs -- or none at all with gather=False, when the consumer can use sharded results.
+"""
+import torch
+import torch.distributed as dist
+
+
+def shard_range(num_points, world_size, rank):
+    """Rank r owns [r*chunk, min(P, (r+1)*chunk)) with chunk = ceil(P / W); returns (start, stop, chunk)."""
+    chunk = (num_points + world_size - 1) // world_size if num_points > 0 else 0
+    start = min(num_points, rank * chunk)
+    stop = min(num_points, start + chunk)
+    return start, stop, chunk
+
+
+def _all_gather_cat(local, point_dim, group):
+    """Gather equal-shaped `local` tensors from all ranks and concatenate them along `point_dim`."""
+    world = dist.get_world_size(group)
+    out = torch.empty((world,) + tuple(local.shape), dtype=local.dtype, device=local.device)
+    try:
+        dist.all_gather_into_tensor(out, local.contiguous(), group=group)  # one collective, no list of buffers
+    except (RuntimeError, NotImplementedError):
+        parts = [out[r] for r in range(world)]
+        dist.all_gather(parts, local.contiguous(), group=group)
+    # (W, ..., chunk, ...) -> (..., W*chunk, ...): the strided copy that restores the global point order
+    point_dim = point_dim % local.dim()
+    out = out.movedim(0, point_dim)  # (..., W, chunk, ...)
+    shape = list(local.shape)
+    shape[point_dim] = world * local.shape[point_dim]
+    return out.reshape(shape)
+
+
+class ShardedSDF:
+    """Wrap any ObjectFrameSDF so that __call__ evaluates only this rank's slice of the (flattened) query points and
+    all-gathers the results.
+
+    Output shapes match the wrapped SDF's for the full input: leading configuration dims (RobotSDF / batched
+    ComposedSDF) are preserved, the point dims come back in the original order.
+    """
+
+    def __init__(self, sdf, group=None, gather=True, compute_device=None):
+        self.sdf = sdf
+        self.group = group
+        self.gather = gather
+        self.compute_device = compute_device  # where gathered tensors live (nccl needs GPU tensors)
+
+    def surface_bounding_box(self, **kwargs):
+        return self.sdf.surface_bounding_box(**kwargs)
+
+    def __call__(self, points_in_object_frame):
+        world = dist.get_world_size(self.group)
+        rank = dist.get_rank(self.group)
+        lead = tuple(points_in_object_frame.shape[:-1])
+        flat = points_in_object_frame.reshape(-1, 3)
+        P = flat.shape[0]
+        start, stop, chunk = shard_range(P, world, rank)
+        mine = flat[start:stop]
+        if mine.shape[0] < chunk:  # pad the tail so every rank contributes the same count (all-gather needs it)
+            pad = flat[:1].expand(chunk - mine.shape[0], 3) if P > 0 else flat.new_zeros((chunk, 3))
+            mine = torch.cat((mine, pad), dim=0)
+        val, grad = self._query(mine, start)
+        # leaf / composed-without-batch: val (chunk,), grad (chunk,3); with a configuration batch: (A..., chunk[,3])
+        if not self.gather:
+            n_valid = stop - start
+            return val[..., :n_valid], grad[..., :n_valid, :], (start, stop)
+        if self.compute_device is not None:
+            val, grad = val.to(self.compute_device), grad.to(self.compute_device)
+        val = _all_gather_cat(val, -1, self.group)[..., :P]
+        grad = _all_gather_cat(grad, -2, self.group)[..., :P, :]
+        batch = tuple(val.shape[:-1])
+        return val.reshape(*batch, *lead), grad.reshape(*batch, *lead, 3)
+
+    def _query(self, pts, index_base):
+        # MeshSDF's sign jitter is indexed by the global point number so sharding does not change the result
+        factory = getattr(self.sdf, "obj_factory", None)
+        if factory is not None and hasattr(factory, "object_frame_closest_point"):
+            res = factory.object_frame_closest_point(pts, index_base=index_base)
+            return res.distance, res.gradient
+        return self.sdf(pts)
+
+
+def sharded_chamfer(world_to_object, points, obj_factory=None, obj_sdf=None, scale=1000., group=None):
+    """batch_chamfer_dist with the N source points sharded across ranks: each rank reduces its slice, the B partial
+    sums are all-reduced (a few KB) and divided by the global N."""
+    from pytorch_volumetric_amd.chamfer import batch_chamfer_dist
+    world = dist.get_world_size(group)
+    rank = dist.get_rank(group)
+    start, stop, _ = shard_range(points.shape[0], world, rank)
+    return batch_chamfer_dist(world_to_object, points[start:stop], obj_factory=obj_factory, obj_sdf=obj_sdf,
+                              scale=scale, reduce_group=group if group is not None else dist.group.WORLD)

@@ -1,0 +1,139 @@
+"""RobotSDF: an SDF of an articulated robot, conditioned on (batched) joint configurations
+(reference model_to_sdf.py:12-133).  One leaf per mesh visual; forward kinematics gives world_T_link per
+configuration; `pvamd_transform_stack` (f32 MFMA) contracts them with the visual offsets into the leaf-major
+object->leaf stack that the fused ComposedSDF kernel consumes."""
+import logging
+import typing
+
+import numpy as np
+import torch
+
+from pytorch_volumetric_amd import _lib
+from pytorch_volumetric_amd import sdf
+from pytorch_volumetric_amd import transforms as tf
+
+logger = logging.getLogger(__file__)
+
+
+class RobotSDF(sdf.ObjectFrameSDF):
+    """SDF for a robot model described by a kinematic chain (pytorch_volumetric_amd.kinematics.Chain or a
+    pytorch_kinematics.Chain); the joint configuration must be set before querying."""
+
+    def __init__(self, chain, default_joint_config=None, path_prefix='',
+                 link_sdf_cls: typing.Callable[[sdf.ObjectFactory], sdf.ObjectFrameSDF] = sdf.MeshSDF):
+        """
+        :param chain: robot description; links with non-mesh visuals are ignored (with a warning)
+        :param default_joint_config: joint values used until set_joint_configuration is called; None = zeros
+        :param path_prefix: prefix for the relative mesh paths found in the robot description
+        :param link_sdf_cls: factory of each link's SDF from its ObjectFactory (MeshSDF, or cache_link_sdf_factory())
+        """
+        self.chain = chain
+        self.dtype = self.chain.dtype
+        self.device = self.chain.device
+        self.q = None
+        self.object_to_link_frames: typing.Optional[tf.Transform3d] = None
+        self.joint_names = self.chain.get_joint_parameter_names()
+        self.frame_names = self.chain.get_frame_names(exclude_fixed=False)
+        self.sdf: typing.Optional[sdf.ComposedSDF] = None
+        self.sdf_to_link_name = []
+        self.configuration_batch = None
+
+        sdfs = []
+        offsets = []
+        for frame_name in self.frame_names:
+            frame = self.chain.find_frame(frame_name)
+            for link_vis in frame.link.visuals:
+                if link_vis.geom_type == "mesh":
+                    logger.info(f"{frame.link.name} offset {link_vis.offset}")
+                    link_obj = sdf.MeshObjectFactory(link_vis.geom_param[0], scale=link_vis.geom_param[1],
+                                                     path_prefix=path_prefix)
+                    sdfs.append(link_sdf_cls(link_obj))
+                    self.sdf_to_link_name.append(frame.link.name)
+                    offsets.append(link_vis.offset)
+                else:
+                    logger.warning(f"Cannot handle non-mesh link visual type {link_vis} for {frame.link.name}")
+        if not sdfs:
+            raise RuntimeError("robot description has no mesh visuals to build an SDF from")
+
+        self.offset_transforms = tf.Transform3d(matrix=torch.cat([tf.as_matrix(o) for o in offsets], dim=0)).to(
+            device=self.device, dtype=self.dtype)
+        self.sdf = sdf.ComposedSDF(sdfs, self.object_to_link_frames)
+        self.set_joint_configuration(default_joint_config)
+
+    def surface_bounding_box(self, **kwargs):
+        return self.sdf.surface_bounding_box(**kwargs)
+
+    def link_bounding_boxes(self):
+        """[A x] S x 8 x 3 corner points of each link's bounding box in the robot frame under the current
+        configuration (model_to_sdf.py:65-80)."""
+        tfs = tf.Transform3d(matrix=tf.rigid_inverse(tf.as_matrix(self.sdf.obj_frame_to_link_frame)))
+        bbs = []
+        for i in range(len(self.sdf.sdfs)):
+            bb = aabb_to_ordered_end_points(np.asarray(self.sdf.sdfs[i].surface_bounding_box(padding=0)))
+            bb = torch.tensor(bb, device=tfs.device, dtype=tfs.dtype)
+            bbs.append(tfs[self.sdf.ith_transform_slice(i)].transform_points(bb))
+        return torch.stack(bbs).squeeze()
+
+    def set_joint_configuration(self, joint_config=None):
+        """
+        :param joint_config: [A x] M joint values; A may be any number of batch dimensions (model_to_sdf.py:82-115)
+        """
+        M = len(self.joint_names)
+        if joint_config is None:
+            joint_config = torch.zeros(M, device=self.device, dtype=self.dtype)
+        joint_config = torch.as_tensor(joint_config)
+        if len(joint_config.shape) > 1:
+            self.configuration_batch = tuple(joint_config.shape[:-1])
+            joint_config = joint_config.reshape(-1, M)
+        else:
+            self.configuration_batch = None
+        self.q = joint_config
+        fk = self.chain.forward_kinematics(joint_config, end_only=False)
+        link_world = torch.cat([tf.as_matrix(fk[name]) for name in self.sdf_to_link_name])  # (S*A,4,4) leaf-major
+        S = len(self.sdf_to_link_name)
+        A = link_world.shape[0] // S
+
+        # object_to_link[s*A+a] = offset[s]^-1 @ world_T_link[s,a]^-1 on the matrix cores
+        lib = _lib.load()
+        dev = _lib.require_gpu()
+        offset_inv = tf.rigid_inverse(self.offset_transforms.get_matrix()).to(device=dev, dtype=torch.float32)
+        link_world_d = link_world.to(device=dev, dtype=torch.float32).contiguous()
+        stack = torch.empty_like(link_world_d)
+        with torch.cuda.device(dev):
+            _lib.check(lib.pvamd_transform_stack(_lib.ptr(offset_inv.contiguous()), _lib.ptr(link_world_d), S, A,
+                                                 _lib.ptr(stack), _lib.stream_ptr()), "pvamd_transform_stack")
+        self.object_to_link_frames = tf.Transform3d(matrix=stack)
+        if self.sdf is not None:
+            self.sdf.set_transforms(self.object_to_link_frames, batch_dim=self.configuration_batch)
+
+    def __call__(self, points_in_object_frame):
+        """
+        :param points_in_object_frame: [B x] N x 3 points in the robot frame
+        :return: [A x] [B x] N values and [A x] [B x] N x 3 gradients (A = configuration batch dims)
+        """
+        return self.sdf(points_in_object_frame)
+
+
+def cache_link_sdf_factory(resolution=0.01, padding=0.1, **kwargs):
+    """model_to_sdf.py:128-133"""
+
+    def create_sdf(obj_factory: sdf.ObjectFactory):
+        gt_sdf = sdf.MeshSDF(obj_factory)
+        return sdf.CachedSDF(obj_factory.name, resolution, obj_factory.bounding_box(padding=padding), gt_sdf, **kwargs)
+
+    return create_sdf
+
+
+_CORNER_ORDER = ((0, 0, 0), (1, 0, 0), (0, 1, 0), (0, 0, 1), (0, 1, 1), (1, 0, 1), (1, 1, 0), (1, 1, 1))
+_SEQUENTIAL_ORDER = ((0, 0, 0), (1, 0, 0), (1, 1, 0), (0, 1, 0), (0, 0, 0), (0, 0, 1), (1, 0, 1), (1, 0, 0),
+                     (1, 0, 1), (1, 1, 1), (1, 1, 0), (1, 1, 1), (0, 1, 1), (0, 1, 0), (0, 1, 1), (0, 0, 1))
+
+
+def aabb_to_ordered_end_points(aabb, arrange_in_sequential_order=False):
+    """8 corners (or the 16-vertex wireframe polyline) of a (3,2) [[min,max],...] box, in the reference's order
+    (model_to_sdf.py:136-171)."""
+    order = _SEQUENTIAL_ORDER if arrange_in_sequential_order else _CORNER_ORDER
+    arr = [[aabb[d, pick[d]] for d in range(3)] for pick in order]
+    if torch.is_tensor(aabb):
+        return torch.tensor(arr, device=aabb.device, dtype=aabb.dtype)
+    return np.array(arr)

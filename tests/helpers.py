@@ -1,0 +1,93 @@
+"""Shared builders for the parity tests: the same synthetic grids / meshes / inputs for the HIP path and the oracle."""
+import os
+
+import numpy as np
+import torch
+
+from oracle import oracle
+from pytorch_volumetric_amd import mesh_io
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+MESHES = os.path.join(GOLDEN, "meshes")
+
+DRILL_BB = np.array([[-0.067981, 0.095006], [-0.041332, 0.081863], [-0.003716, 0.183718]])
+
+
+def mesh_path(name):
+    return os.path.join(MESHES, name)
+
+
+class AnalyticEllipsoidSDF:
+    """A cheap closed-form stand-in for a mesh SDF: a sphere SDF in a stretched space (not a true distance, but
+    smooth, signed, with a unit gradient) -- only used to fill voxel grids deterministically on the CPU."""
+
+    def __init__(self, center, radii, bb):
+        self.center = torch.tensor(center, dtype=torch.float64)
+        self.radii = torch.tensor(radii, dtype=torch.float64)
+        self.bb = torch.tensor(bb, dtype=torch.float64)
+
+    def __call__(self, pts):
+        center, radii = self.center.to(pts.device), self.radii.to(pts.device)
+        p = (pts.double() - center) / radii
+        n = torch.linalg.norm(p, dim=-1)
+        val = (n - 1.0) * radii.min()
+        g = p / radii
+        g = g / (torch.linalg.norm(g, dim=-1, keepdim=True) + 1e-12)
+        return val.to(pts.dtype), g.to(pts.dtype)
+
+    def surface_bounding_box(self, padding=0., padding_ratio=0.):
+        bb = self.bb.clone()
+        ext = bb[:, 1] - bb[:, 0]
+        bb[:, 0] -= padding + padding_ratio * ext
+        bb[:, 1] += padding + padding_ratio * ext
+        return bb
+
+
+def drill_like_gt():
+    c = DRILL_BB.mean(axis=1)
+    r = (DRILL_BB[:, 1] - DRILL_BB[:, 0]) / 2
+    return AnalyticEllipsoidSDF(c, r, DRILL_BB)
+
+
+def padded_range(bb, padding, as_numpy=True):
+    r = np.array(bb, dtype=np.float64)
+    r[:, 0] -= padding
+    r[:, 1] += padding
+    return r if as_numpy else [(float(a), float(b)) for a, b in r]
+
+
+def oracle_grid_from_cached(cached, oob_mode=None):
+    """Build the oracle's grid (reference layout: separate val / grad arrays) from a CachedSDF instance."""
+    packed = cached._packed.cpu().numpy()
+    view = cached._view
+    val = packed[:, 0].reshape(view.shape)
+    grad = packed[:, 1:4]
+    if view.index_f64:
+        rmin, rmax = view.dmin.numpy().astype(np.float64), view.dmax.numpy().astype(np.float64)
+    else:
+        rmin, rmax = view.fmin.numpy().astype(np.float32), view.fmax.numpy().astype(np.float32)
+    bb = cached.bb.cpu().numpy()
+    if oob_mode is None:
+        oob_mode = 1 if cached.out_of_bounds_strategy.value == 1 else 0
+    return oracle.Grid(val, grad, rmin, rmax, bb, oob_mode=oob_mode, index_f64=view.index_f64)
+
+
+def oracle_mesh_from_factory(obj):
+    m = obj._mesh
+    return oracle.Mesh(m.triangle_soup().astype(np.float32), obj._face_normals.astype(np.float32),
+                       obj.bounding_box(padding=1.0)[:, 1])
+
+
+def random_rigid(n, seed, trans=0.3):
+    g = torch.Generator().manual_seed(seed)
+    from pytorch_volumetric_amd import transforms as tf
+    m = torch.eye(4).repeat(n, 1, 1)
+    m[:, :3, :3] = tf.random_rotations(n, generator=g)
+    m[:, :3, 3] = (torch.rand(n, 3, generator=g) * 2 - 1) * trans
+    return m
+
+
+def uniform_points(n, lo, hi, seed):
+    g = torch.Generator().manual_seed(seed)
+    lo, hi = torch.as_tensor(lo, dtype=torch.float32), torch.as_tensor(hi, dtype=torch.float32)
+    return torch.rand(n, 3, generator=g) * (hi - lo) + lo

@@ -1,0 +1,191 @@
+"""-m gpu: CachedSDF HIP path (through the C ABI) vs the CPU oracle, bit-exact (BASELINE config C2)."""
+import numpy as np
+import pytest
+import torch
+
+import pytorch_volumetric_amd as pv
+from oracle import oracle
+from tests import helpers as H
+
+pytestmark = pytest.mark.gpu
+
+
+def make_cached(resolution=0.01, padding=0.1, f64=True, oob=pv.OutOfBoundsStrategy.BOUNDING_BOX, device="cuda"):
+    gt = H.drill_like_gt()
+    rng = H.padded_range(H.DRILL_BB, padding, as_numpy=f64)
+    return pv.CachedSDF("drill_like", resolution, rng, gt, out_of_bounds_strategy=oob, device=device, cache_path=None)
+
+
+def query_points(cached, n, seed, margin=0.05):
+    lo = np.array([r[0] for r in cached.ranges]) - margin
+    hi = np.array([r[1] for r in cached.ranges]) + margin
+    return H.uniform_points(n, lo, hi, seed)
+
+
+@pytest.mark.parametrize("f64", [True, False])
+def test_grid_shape_is_the_c2_grid(f64):
+    c = make_cached(f64=f64)
+    assert c._view.shape == (37, 33, 40)  # drill, res 0.01, pad 0.1
+    assert c._view.index_f64 == f64
+
+
+@pytest.mark.parametrize("f64", [True, False])
+def test_voxel_index_bit_exact(f64):
+    c = make_cached(f64=f64)
+    og = H.oracle_grid_from_cached(c)
+    pts = query_points(c, 200_003, seed=1)
+    key = c.voxels.ensure_index_key(pts.cuda())
+    valid = c.voxels.get_valid_values(pts.cuda())
+    okey, oflat, ovalid = oracle.voxel_index(og, pts.numpy())
+    assert np.array_equal(key.cpu().numpy(), okey)
+    assert np.array_equal(valid.cpu().numpy(), ovalid)
+    flat = c.voxels.ravel_multi_index(key, c.voxels.shape)
+    assert np.array_equal(flat.cpu().numpy(), oflat)
+    assert 0.05 < (~ovalid).mean() < 0.95  # the sample exercises both branches
+
+
+@pytest.mark.parametrize("f64", [True, False])
+def test_half_voxel_boundaries_round_half_even(f64):
+    """Points placed on and next to the half-voxel planes and the range edges: the rounding mode and the inclusive
+    range test are where index arithmetic can go wrong."""
+    c = make_cached(f64=f64)
+    og = H.oracle_grid_from_cached(c)
+    v = c._view
+    mn = (v.dmin if f64 else v.fmin).double().numpy()
+    res = (v.dres if f64 else v.fres).double().numpy()
+    mx = (v.dmax if f64 else v.fmax).double().numpy()
+    ks = np.arange(0, 33)
+    base = []
+    for off in (0.5, 0.5 - 1e-7, 0.5 + 1e-7, 0.0, 1.0):
+        base.append(mn[None, :] + (ks[:, None] + off) * res[None, :])
+    pts = np.concatenate(base + [mn[None], mx[None], np.nextafter(mn.astype(np.float32), -1)[None].astype(np.float64),
+                                 np.nextafter(mx.astype(np.float32), 10)[None].astype(np.float64)]).astype(np.float32)
+    key = c.voxels.ensure_index_key(torch.from_numpy(pts).cuda()).cpu().numpy()
+    valid = c.voxels.get_valid_values(torch.from_numpy(pts).cuda()).cpu().numpy()
+    okey, _, ovalid = oracle.voxel_index(og, pts)
+    assert np.array_equal(key, okey)
+    assert np.array_equal(valid, ovalid)
+
+
+@pytest.mark.parametrize("f64", [True, False])
+@pytest.mark.parametrize("n", [0, 1, 3, 4, 5, 1023, 100_001])
+def test_cached_query_matches_oracle_bitwise(f64, n):
+    c = make_cached(f64=f64)
+    og = H.oracle_grid_from_cached(c)
+    pts = query_points(c, n, seed=n + 7)
+    val, grad = c(pts.cuda())
+    assert val.shape == (n,) and grad.shape == (n, 3) and val.device.type == "cuda"
+    oval, ograd, _ = oracle.cached_query(og, pts.numpy())
+    assert np.array_equal(val.cpu().numpy(), oval, equal_nan=True)
+    assert np.array_equal(grad.cpu().numpy(), ograd, equal_nan=True)
+
+
+def test_misaligned_and_strided_inputs_take_the_scalar_path():
+    c = make_cached()
+    og = H.oracle_grid_from_cached(c)
+    big = query_points(c, 4099, seed=3).cuda()
+    sl = big[1:]  # data_ptr offset by 12 B: not 16-byte aligned
+    val, grad = c(sl)
+    oval, ograd, _ = oracle.cached_query(og, sl.cpu().numpy())
+    assert np.array_equal(val.cpu().numpy(), oval, equal_nan=True)
+    assert np.array_equal(grad.cpu().numpy(), ograd, equal_nan=True)
+    strided = big[::2]
+    val, grad = c(strided)
+    oval, ograd, _ = oracle.cached_query(og, strided.cpu().numpy())
+    assert np.array_equal(val.cpu().numpy(), oval, equal_nan=True)
+
+
+def test_batch_dims_dtype_and_device_follow_the_reference():
+    c = make_cached(device="cuda")
+    pts = query_points(c, 6 * 50, seed=5).reshape(2, 3, 50, 3)
+    val, grad = c(pts.cuda())
+    assert val.shape == (2, 3, 50) and grad.shape == (2, 3, 50, 3)
+    v64, g64 = c(pts.double().cuda())
+    assert v64.dtype == torch.float64 and g64.dtype == torch.float64  # output dtype = query dtype (sdf.py:545-547)
+    c_cpu = make_cached(device="cpu")
+    v, g = c_cpu(pts)  # cpu in, self.device out
+    assert v.device.type == "cpu" and torch.equal(v, val.cpu())
+
+
+def test_nan_and_inf_points_are_out_of_bounds():
+    c = make_cached()
+    og = H.oracle_grid_from_cached(c)
+    pts = query_points(c, 64, seed=9)
+    pts[3, 1] = float("nan")
+    pts[10, 0] = float("inf")
+    pts[11, 2] = -float("inf")
+    val, grad = c(pts.cuda())
+    oval, ograd, ooob = oracle.cached_query(og, pts.numpy())
+    assert ooob[3] and ooob[10] and ooob[11]
+    assert np.array_equal(val.cpu().numpy(), oval, equal_nan=True)
+    assert np.array_equal(grad.cpu().numpy(), ograd, equal_nan=True)
+
+
+def test_voxel_centres_map_to_themselves():
+    """The invariant the reference asserts under debug_check_sdf (sdf.py:508-512)."""
+    c = make_cached()
+    _, centres = pv.get_coordinates_and_points_in_grid(c.resolution, c.ranges)
+    val, grad = c(centres.cuda())
+    packed = c._packed
+    assert torch.equal(val, packed[:, 0])
+    assert torch.equal(grad, packed[:, 1:4])
+
+
+def test_bounding_box_fallback_properties():
+    """sdf.py:574-582: the fallback under-approximates the true distance and points away from the box."""
+    c = make_cached()
+    lo = np.array([r[0] for r in c.ranges]) - 0.3
+    hi = np.array([r[1] for r in c.ranges]) + 0.3
+    pts = H.uniform_points(50_000, lo, hi, seed=11).cuda()
+    val, grad = c(pts)
+    oob = ~c.voxels.get_valid_values(pts)
+    bb = c.bb.float()
+    q = torch.maximum(bb[:, 0] - pts[oob], pts[oob] - bb[:, 1]).clamp(min=0)
+    assert torch.allclose(val[oob], q.norm(dim=-1), atol=1e-6)
+    assert torch.allclose(grad[oob].norm(dim=-1), torch.ones_like(val[oob]), atol=1e-5)
+    assert (val[oob] > 0).all()
+
+
+def test_lookup_gt_sdf_strategy_queries_ground_truth_out_of_range():
+    gt = H.drill_like_gt()
+    c = make_cached(oob=pv.OutOfBoundsStrategy.LOOKUP_GT_SDF)
+    pts = query_points(c, 10_000, seed=13).cuda()
+    val, grad = c(pts)
+    oob = ~c.voxels.get_valid_values(pts)
+    gv, gg = gt(pts[oob])
+    assert torch.equal(val[oob], gv) and torch.equal(grad[oob], gg)
+    og = H.oracle_grid_from_cached(c, oob_mode=0)
+    oval, ograd, ooob = oracle.cached_query(og, pts.cpu().numpy())
+    inb = ~ooob
+    assert np.array_equal(val.cpu().numpy()[inb], oval[inb])
+    assert np.array_equal(oob.cpu().numpy(), ooob)
+
+
+def test_outside_surface_matches_oracle():
+    c = make_cached()
+    og = H.oracle_grid_from_cached(c)
+    pts = query_points(c, 30_001, seed=17)
+    for level in (0.0, 0.01, -0.005):
+        out = c.outside_surface(pts.cuda(), surface_level=level)
+        assert np.array_equal(out.cpu().numpy(), oracle.cached_outside(og, pts.numpy(), level))
+
+
+def test_full_size_c2_properties():
+    """BASELINE C2 at full size (1M points): parity through size-independent properties -- determinism, agreement of
+    the vector and scalar code paths, and permutation equivariance."""
+    c = make_cached()
+    pts = query_points(c, 1_000_000, seed=21).cuda()
+    v1, g1 = c(pts)
+    v2, g2 = c(pts)
+    assert torch.equal(v1, v2) and torch.equal(g1.nan_to_num(7.0), g2.nan_to_num(7.0))
+    shifted = torch.cat((pts[:1], pts))[1:]  # same values at a 12-byte-shifted address: scalar kernel
+    v3, g3 = c(shifted)
+    assert torch.equal(v1, v3) and torch.equal(g1.nan_to_num(7.0), g3.nan_to_num(7.0))
+    perm = torch.randperm(pts.shape[0], device="cuda", generator=torch.Generator(device="cuda").manual_seed(0))
+    v4, _ = c(pts[perm])
+    assert torch.equal(v1[perm], v4)
+    # and a 100k-point slice against the oracle
+    og = H.oracle_grid_from_cached(c)
+    oval, ograd, _ = oracle.cached_query(og, pts[:100_000].cpu().numpy())
+    assert np.array_equal(v1[:100_000].cpu().numpy(), oval, equal_nan=True)
+    assert np.array_equal(g1[:100_000].cpu().numpy(), ograd, equal_nan=True)

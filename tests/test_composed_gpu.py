@@ -1,0 +1,121 @@
+"""-m gpu: fused ComposedSDF / RobotSDF kernel vs the CPU oracle (BASELINE configs C3, C4), bit-exact."""
+import numpy as np
+import pytest
+import torch
+
+import pytorch_volumetric_amd as pv
+from oracle import oracle
+from tests import helpers as H
+
+pytestmark = pytest.mark.gpu
+
+
+def make_leaf(f64=True, res=0.01, padding=0.1):
+    gt = H.drill_like_gt()
+    return pv.CachedSDF("drill_like", res, H.padded_range(H.DRILL_BB, padding, as_numpy=f64), gt, device="cuda",
+                        cache_path=None)
+
+
+def scene_points(n, seed, extent=0.5):
+    return H.uniform_points(n, [-extent] * 3, [extent] * 3, seed)
+
+
+@pytest.mark.parametrize("S,A,P", [(1, 1, 17), (2, 1, 1000), (8, 1, 40_000), (8, 5, 4096), (3, 7, 1001)])
+def test_composed_matches_oracle_bitwise(S, A, P):
+    leaves = [make_leaf(f64=(s % 2 == 0)) for s in range(S)]  # mixed float64 / float32 index arithmetic
+    tfm = H.random_rigid(S * A, seed=S * 100 + A)
+    comp = pv.ComposedSDF(leaves, pv.Transform3d(matrix=tfm))
+    if A > 1:
+        comp.set_transforms(pv.Transform3d(matrix=tfm), batch_dim=(A,))
+    pts = scene_points(P, seed=P)
+    val, grad = comp(pts.cuda())
+    ogrids = [H.oracle_grid_from_cached(l) for l in leaves]
+    oval, ograd, oleaf = oracle.composed_query(ogrids, tfm.numpy(), A, pts.numpy())
+    if A == 1:
+        assert val.shape == (P,) and grad.shape == (P, 3)  # flat without a transform batch (sdf.py:418-433)
+        oval, ograd = oval[0], ograd[0]
+    else:
+        assert val.shape == (A, P) and grad.shape == (A, P, 3)
+    assert np.array_equal(val.cpu().numpy(), oval, equal_nan=True)
+    assert np.array_equal(grad.cpu().numpy(), ograd, equal_nan=True)
+    assert len(np.unique(oleaf)) == min(S, len(np.unique(oleaf)))  # sanity: argmin ran
+
+
+def test_translation_only_compose_is_min_of_shifted_leaves():
+    """Known answer without any oracle (pattern of the reference's tests/test_sdf.py:61-80):
+    sdf(p) = min(sdf1(p + t1), sdf2(p + t2)) for pure translations."""
+    leaf = make_leaf()
+    t1, t2 = torch.tensor([0.1, 0.0, 0.0]), torch.tensor([-0.2, 0.0, 0.2])
+    tsf = pv.Translate(*t1.tolist()).stack(pv.Translate(*t2.tolist()))
+    comp = pv.ComposedSDF([leaf, leaf], tsf)
+    pts = scene_points(20_000, seed=3, extent=0.35).cuda()
+    val, grad = comp(pts)
+    v1, g1 = leaf(pts + t1.cuda())
+    v2, g2 = leaf(pts + t2.cuda())
+    take2 = v2 < v1
+    assert torch.equal(val, torch.where(take2, v2, v1))
+    assert torch.equal(grad.nan_to_num(9.0), torch.where(take2.unsqueeze(-1), g2, g1).nan_to_num(9.0))
+
+
+def test_config_batch_equals_per_config_loop_and_shapes():
+    """tests/test_model_to_sdf.py:173-212 and :301-326 of the reference, headless."""
+    S, A = 4, 6
+    leaves = [make_leaf() for _ in range(S)]
+    tfm = H.random_rigid(S * A, seed=42).reshape(S, A, 4, 4)
+    comp = pv.ComposedSDF(leaves, None)
+    comp.set_transforms(pv.Transform3d(matrix=tfm.reshape(-1, 4, 4)), batch_dim=(2, 3))
+    pts = scene_points(5 * 64, seed=8).reshape(5, 64, 3).cuda()
+    val, grad = comp(pts)
+    assert val.shape == (2, 3, 5, 64) and grad.shape == (2, 3, 5, 64, 3)
+    flat_val, flat_grad = comp(pts.reshape(-1, 3))
+    assert torch.equal(flat_val.reshape(val.shape), val)
+    for a in range(A):
+        single = pv.ComposedSDF(leaves, pv.Transform3d(matrix=tfm[:, a]))
+        v, g = single(pts.reshape(-1, 3))
+        assert torch.equal(v, val.reshape(A, -1)[a])
+        assert torch.equal(g.nan_to_num(9.0), grad.reshape(A, -1, 3)[a].nan_to_num(9.0))
+
+
+def test_generic_path_with_uncached_leaves_agrees_with_fused_path():
+    leaves = [make_leaf() for _ in range(3)]
+    tfm = H.random_rigid(3, seed=5)
+
+    class Opaque(pv.ObjectFrameSDF):  # hides the CachedSDF type -> forces the per-leaf path
+        def __init__(self, inner):
+            self.inner = inner
+
+        def __call__(self, p):
+            return self.inner(p)
+
+        def surface_bounding_box(self, **kw):
+            return self.inner.surface_bounding_box(**kw)
+
+    fused = pv.ComposedSDF(leaves, pv.Transform3d(matrix=tfm))
+    generic = pv.ComposedSDF([Opaque(l) for l in leaves], pv.Transform3d(matrix=tfm))
+    pts = scene_points(10_000, seed=2).cuda()
+    v1, g1 = fused(pts)
+    v2, g2 = generic(pts)
+    # torch's matmul rounds differently from the kernel's fma chain: indices can differ on voxel boundaries
+    close = torch.isclose(v1, v2, atol=1e-5)
+    assert close.float().mean() > 0.995
+    assert torch.allclose(g1[close].nan_to_num(0.), g2[close].nan_to_num(0.), atol=1e-4)
+
+
+def test_full_size_c3_properties():
+    """BASELINE C3 at full size (8 leaves, 4M points): determinism + slice vs oracle + leaf-permutation invariance
+    of the minimum value."""
+    S = 8
+    leaf = make_leaf()
+    tfm = H.random_rigid(S, seed=0)
+    comp = pv.ComposedSDF([leaf] * S, pv.Transform3d(matrix=tfm))
+    pts = scene_points(4_000_000, seed=0).cuda()
+    v1, g1 = comp(pts)
+    v2, _ = comp(pts)
+    assert torch.equal(v1, v2)
+    rev = pv.ComposedSDF([leaf] * S, pv.Transform3d(matrix=tfm.flip(0)))
+    v3, _ = rev(pts)
+    assert torch.equal(v1, v3)  # min over leaves does not depend on their order
+    og = H.oracle_grid_from_cached(leaf)
+    oval, ograd, _ = oracle.composed_query([og] * S, tfm.numpy(), 1, pts[:50_000].cpu().numpy())
+    assert np.array_equal(v1[:50_000].cpu().numpy(), oval[0], equal_nan=True)
+    assert np.array_equal(g1[:50_000].cpu().numpy(), ograd[0], equal_nan=True)
