@@ -106,11 +106,10 @@ extern "C" int pvamd_pack_grid(const float* val, const float* grad, int64_t n, f
 
 extern "C" int pvamd_cached_query(const pvamd_grid_t* grid, const float* points, int64_t P, float* out_val,
                                   float* out_grad, uint8_t* out_oob, void* stream) {
-    if (!grid || !out_val || !out_grad) return PVAMD_E_NULL;
     if (P < 0) return PVAMD_E_SHAPE;
+    if (P == 0) return 0;  // empty query: nothing to read or write (torch hands out NULL for empty tensors)
+    if (!grid || !out_val || !out_grad || !points) return PVAMD_E_NULL;
     if (int e = check_grid(*grid)) return e;
-    if (P == 0) return 0;
-    if (!points) return PVAMD_E_NULL;
     if (!aligned_to(points, 4) || !aligned_to(out_val, 4) || !aligned_to(out_grad, 4)) return PVAMD_E_ALIGN;
     hipStream_t s = (hipStream_t)stream;
     const bool f64 = grid->index_f64 != 0;
@@ -142,11 +141,10 @@ extern "C" int pvamd_cached_query(const pvamd_grid_t* grid, const float* points,
 
 extern "C" int pvamd_cached_outside(const pvamd_grid_t* grid, const float* points, int64_t P, float level,
                                     uint8_t* out, void* stream) {
-    if (!grid || !out) return PVAMD_E_NULL;
     if (P < 0) return PVAMD_E_SHAPE;
-    if (int e = check_grid(*grid)) return e;
     if (P == 0) return 0;
-    if (!points) return PVAMD_E_NULL;
+    if (!grid || !out || !points) return PVAMD_E_NULL;
+    if (int e = check_grid(*grid)) return e;
     const dim3 grid_dim(stream_grid(P, 256)), block(256);
     if (grid->index_f64) hipLaunchKernelGGL((cached_outside_kernel<true>), grid_dim, block, 0, (hipStream_t)stream, *grid, points, P, level, out);
     else hipLaunchKernelGGL((cached_outside_kernel<false>), grid_dim, block, 0, (hipStream_t)stream, *grid, points, P, level, out);
@@ -155,11 +153,10 @@ extern "C" int pvamd_cached_outside(const pvamd_grid_t* grid, const float* point
 
 extern "C" int pvamd_voxel_index(const pvamd_grid_t* grid, const float* points, int64_t P, int64_t* out_key,
                                  int64_t* out_flat, uint8_t* out_valid, void* stream) {
-    if (!grid) return PVAMD_E_NULL;
     if (P < 0) return PVAMD_E_SHAPE;
-    if (int e = check_grid(*grid, /*need_vox=*/false)) return e;
     if (P == 0) return 0;
-    if (!points) return PVAMD_E_NULL;
+    if (!grid || !points) return PVAMD_E_NULL;
+    if (int e = check_grid(*grid, /*need_vox=*/false)) return e;
     const dim3 grid_dim(stream_grid(P, 256)), block(256);
     if (grid->index_f64) hipLaunchKernelGGL((voxel_index_kernel<true>), grid_dim, block, 0, (hipStream_t)stream, *grid, points, P, out_key, out_flat, out_valid);
     else hipLaunchKernelGGL((voxel_index_kernel<false>), grid_dim, block, 0, (hipStream_t)stream, *grid, points, P, out_key, out_flat, out_valid);

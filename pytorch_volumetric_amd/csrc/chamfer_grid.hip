@@ -21,8 +21,8 @@ __global__ __launch_bounds__(256) void chamfer_grid_kernel(const pvamd_grid_t g,
         const float z = affine_row(M[8], M[9], M[10], M[11], px, py, pz);
         bool valid;
         const float4 r = cached_lookup<F64>(g, x, y, z, valid);
-        const float sd = __fmul_rn(scale, r.x);
-        acc += (double)__fmul_rn(sd, sd);
+        const float sd = mul_rn(scale, r.x);
+        acc += (double)mul_rn(sd, sd);
     }
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off, 64);

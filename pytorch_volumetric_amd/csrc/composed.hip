@@ -39,9 +39,9 @@ PVAMD_DEV void visit_leaf(const pvamd_grid_t& g, const float* __restrict__ M, in
 
 // g_obj = R^T g_leaf with R the obj->leaf rotation (sdf.py:409 transform_normals by the inverse transform)
 PVAMD_DEV void rotate_back(const float* __restrict__ M, const Best& b, float& ox, float& oy, float& oz) {
-    ox = fmaf(M[8], b.gz, fmaf(M[4], b.gy, __fmul_rn(M[0], b.gx)));
-    oy = fmaf(M[9], b.gz, fmaf(M[5], b.gy, __fmul_rn(M[1], b.gx)));
-    oz = fmaf(M[10], b.gz, fmaf(M[6], b.gy, __fmul_rn(M[2], b.gx)));
+    ox = fmaf(M[8], b.gz, fmaf(M[4], b.gy, mul_rn(M[0], b.gx)));
+    oy = fmaf(M[9], b.gz, fmaf(M[5], b.gy, mul_rn(M[1], b.gx)));
+    oz = fmaf(M[10], b.gz, fmaf(M[6], b.gy, mul_rn(M[2], b.gx)));
 }
 
 template <bool ANY_F64>
@@ -114,10 +114,9 @@ using namespace pvamd;
 extern "C" int pvamd_composed_query(const pvamd_grid_t* grids, int32_t S, const float* tf, int32_t A,
                                     const float* points, int64_t P, float* out_val, float* out_grad,
                                     int32_t* out_leaf, void* stream) {
-    if (!grids || !tf || !out_val || !out_grad) return PVAMD_E_NULL;
     if (S < 1 || A < 1 || A > 65535 || P < 0) return PVAMD_E_SHAPE;
     if (P == 0) return 0;
-    if (!points) return PVAMD_E_NULL;
+    if (!grids || !tf || !out_val || !out_grad || !points) return PVAMD_E_NULL;
     if (!aligned_to(grids, 8) || !aligned_to(tf, 4) || !aligned_to(points, 4)) return PVAMD_E_ALIGN;
     hipStream_t s = (hipStream_t)stream;
     const bool vec_ok = (P % 4 == 0) && aligned_to(points, 16) && aligned_to(out_val, 16) && aligned_to(out_grad, 16) &&

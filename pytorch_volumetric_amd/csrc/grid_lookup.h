@@ -7,6 +7,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include "exact_math.h"
 #include "../../include/pvamd.h"
 
 namespace pvamd {
@@ -24,7 +25,7 @@ PVAMD_DEV bool voxel_index_1d(const pvamd_grid_t& g, int d, float p, long long& 
         return valid;
     } else {
         const bool valid = (g.fmin[d] <= p) && (p <= g.fmax[d]);
-        k = (long long)__builtin_rintf(__fdiv_rn(__fsub_rn(p, g.fmin[d]), g.fres[d]));
+        k = (long long)__builtin_rintf(div_rn(sub_rn(p, g.fmin[d]), g.fres[d]));
         return valid;
     }
 }
@@ -60,17 +61,17 @@ PVAMD_DEV float4 bounding_box_sdf(const pvamd_grid_t& g, float x, float y, float
     float t[3];
 #pragma unroll
     for (int d = 0; d < 3; ++d) {
-        float lo = __fsub_rn(g.bb_min[d], p[d]);
+        float lo = sub_rn(g.bb_min[d], p[d]);
         const bool lo_active = lo > 0.f;
         lo = lo_active ? lo : 0.f;
-        float hi = __fsub_rn(p[d], g.bb_max[d]);
+        float hi = sub_rn(p[d], g.bb_max[d]);
         hi = (hi > 0.f) ? hi : 0.f;
-        const float s = __fadd_rn(lo, hi);
+        const float s = add_rn(lo, hi);
         t[d] = lo_active ? -s : s;
     }
-    const float n2 = fmaf(t[2], t[2], fmaf(t[1], t[1], __fmul_rn(t[0], t[0])));
-    const float n = __fsqrt_rn(n2);
-    return make_float4(n, __fdiv_rn(t[0], n), __fdiv_rn(t[1], n), __fdiv_rn(t[2], n));
+    const float n2 = fmaf(t[2], t[2], fmaf(t[1], t[1], mul_rn(t[0], t[0])));
+    const float n = sqrt_rn(n2);
+    return make_float4(n, div_rn(t[0], n), div_rn(t[1], n), div_rn(t[2], n));
 }
 
 // (val, gx, gy, gz) for one point in the leaf frame; `valid` reports the range test.
@@ -90,7 +91,7 @@ PVAMD_DEV float4 cached_lookup(const pvamd_grid_t& g, float x, float y, float z,
 // x' = M p for a row-major 4x4 (column-vector convention), k-ordered fma chain -- the rounding sequence of an
 // f32 MFMA / a bmm k-loop: ((m0*px (+) m1*py) (+) m2*pz) + m3.
 PVAMD_DEV float affine_row(float m0, float m1, float m2, float m3, float px, float py, float pz) {
-    return __fadd_rn(fmaf(m2, pz, fmaf(m1, py, __fmul_rn(m0, px))), m3);
+    return add_rn(fmaf(m2, pz, fmaf(m1, py, mul_rn(m0, px))), m3);
 }
 
 }  // namespace pvamd

@@ -35,7 +35,7 @@ PVAMD_DEV void load_tri(const float* __restrict__ lds, int j, V3& a, V3& b, V3& 
 
 // np.linalg.norm of a float32 3-vector (sdf.py:141): products and sums rounded separately, left to right
 PVAMD_DEV float norm3_unfused(V3 g) {
-    return __fsqrt_rn(__fadd_rn(__fadd_rn(__fmul_rn(g.x, g.x), __fmul_rn(g.y, g.y)), __fmul_rn(g.z, g.z)));
+    return sqrt_rn(add_rn(add_rn(mul_rn(g.x, g.x), mul_rn(g.y, g.y)), mul_rn(g.z, g.z)));
 }
 
 template <int PTS>
@@ -92,7 +92,7 @@ __global__ __launch_bounds__(256) void mesh_query_kernel(MeshArgs m, const float
         V3 g = sub(best_q[k], p[k]);                 // sdf.py:139
         float d = norm3_unfused(g);                  // :141
         if (d > 0.f) {                               // :143-144
-            g = v3(__fdiv_rn(g.x, d), __fdiv_rn(g.y, d), __fdiv_rn(g.z, d));
+            g = v3(div_rn(g.x, d), div_rn(g.y, d), div_rn(g.z, d));
         }
         if (hits[k] & 1) d = -d;                     // :154-155 inside: negative distance
         else g = v3(-g.x, -g.y, -g.z);               // :157 outside: point away from the surface
@@ -150,9 +150,9 @@ __global__ __launch_bounds__(256) void chamfer_mesh_kernel(MeshArgs m, const flo
         const int64_t ii = live[k] ? i : 0;
         const float px = pts[3 * ii], py = pts[3 * ii + 1], pz = pts[3 * ii + 2];
         // chamfer.py:81-82 transform_points, k-ordered fma chain
-        x[k] = v3(__fadd_rn(fmaf(M[2], pz, fmaf(M[1], py, __fmul_rn(M[0], px))), M[3]),
-                  __fadd_rn(fmaf(M[6], pz, fmaf(M[5], py, __fmul_rn(M[4], px))), M[7]),
-                  __fadd_rn(fmaf(M[10], pz, fmaf(M[9], py, __fmul_rn(M[8], px))), M[11]));
+        x[k] = v3(add_rn(fmaf(M[2], pz, fmaf(M[1], py, mul_rn(M[0], px))), M[3]),
+                  add_rn(fmaf(M[6], pz, fmaf(M[5], py, mul_rn(M[4], px))), M[7]),
+                  add_rn(fmaf(M[10], pz, fmaf(M[9], py, mul_rn(M[8], px))), M[11]));
         best_d2[k] = INFINITY;
         best_q[k] = v3(NAN, NAN, NAN);
     }
@@ -180,8 +180,8 @@ __global__ __launch_bounds__(256) void chamfer_mesh_kernel(MeshArgs m, const flo
 #pragma unroll
     for (int k = 0; k < PTS; ++k) {
         if (!live[k]) continue;
-        const float sd = __fmul_rn(scale, norm3_unfused(sub(best_q[k], x[k])));  // chamfer.py:92
-        acc += (double)__fmul_rn(sd, sd);
+        const float sd = mul_rn(scale, norm3_unfused(sub(best_q[k], x[k])));  // chamfer.py:92
+        acc += (double)mul_rn(sd, sd);
     }
     __syncthreads();
     const double total = block_sum(acc, scratch);
@@ -209,9 +209,10 @@ using namespace pvamd;
 extern "C" int pvamd_mesh_query(const pvamd_mesh_t* mesh, const float* points, int64_t P, uint64_t jitter_seed,
                                 int64_t index_base, float* out_closest, float* out_dist, float* out_grad,
                                 int32_t* out_face, float* out_normal, void* stream) {
-    if (!mesh || !out_dist || !out_grad) return PVAMD_E_NULL;
-    if (P < 0 || mesh->F < 0) return PVAMD_E_SHAPE;
+    if (P < 0) return PVAMD_E_SHAPE;
     if (P == 0) return 0;
+    if (!mesh || !out_dist || !out_grad) return PVAMD_E_NULL;
+    if (mesh->F < 0) return PVAMD_E_SHAPE;
     if (!points || (mesh->F > 0 && (!mesh->tri || !mesh->normal))) return PVAMD_E_NULL;
     const MeshArgs m = mesh_args(*mesh);
     // enough blocks to fill 256 CUs decides how many points a lane owns

@@ -8,6 +8,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include "exact_math.h"
 
 namespace pvamd {
 
@@ -20,11 +21,11 @@ struct V3 {
 };
 
 PVAMD_DEV V3 v3(float x, float y, float z) { return V3{x, y, z}; }
-PVAMD_DEV V3 sub(V3 a, V3 b) { return V3{__fsub_rn(a.x, b.x), __fsub_rn(a.y, b.y), __fsub_rn(a.z, b.z)}; }
-PVAMD_DEV float dot(V3 a, V3 b) { return fmaf(a.z, b.z, fmaf(a.y, b.y, __fmul_rn(a.x, b.x))); }
+PVAMD_DEV V3 sub(V3 a, V3 b) { return V3{sub_rn(a.x, b.x), sub_rn(a.y, b.y), sub_rn(a.z, b.z)}; }
+PVAMD_DEV float dot(V3 a, V3 b) { return fmaf(a.z, b.z, fmaf(a.y, b.y, mul_rn(a.x, b.x))); }
 PVAMD_DEV V3 cross(V3 a, V3 b) {
-    return V3{fmaf(a.y, b.z, -__fmul_rn(a.z, b.y)), fmaf(a.z, b.x, -__fmul_rn(a.x, b.z)),
-              fmaf(a.x, b.y, -__fmul_rn(a.y, b.x))};
+    return V3{fmaf(a.y, b.z, -mul_rn(a.z, b.y)), fmaf(a.z, b.x, -mul_rn(a.x, b.z)),
+              fmaf(a.x, b.y, -mul_rn(a.y, b.x))};
 }
 PVAMD_DEV V3 madd(float s, V3 d, V3 o) { return V3{fmaf(s, d.x, o.x), fmaf(s, d.y, o.y), fmaf(s, d.z, o.z)}; }
 
@@ -39,21 +40,21 @@ PVAMD_DEV V3 closest_point_triangle(V3 p, V3 a, V3 b, V3 c) {
     const V3 cp = sub(p, c);
     const float d5 = dot(ab, cp), d6 = dot(ac, cp);
     if (d6 >= 0.f && d5 <= d6) return c;
-    const float vc = fmaf(d1, d4, -__fmul_rn(d3, d2));
+    const float vc = fmaf(d1, d4, -mul_rn(d3, d2));
     if (vc <= 0.f && d1 >= 0.f && d3 <= 0.f) {
-        return madd(__fdiv_rn(d1, __fsub_rn(d1, d3)), ab, a);
+        return madd(div_rn(d1, sub_rn(d1, d3)), ab, a);
     }
-    const float vb = fmaf(d5, d2, -__fmul_rn(d1, d6));
+    const float vb = fmaf(d5, d2, -mul_rn(d1, d6));
     if (vb <= 0.f && d2 >= 0.f && d6 <= 0.f) {
-        return madd(__fdiv_rn(d2, __fsub_rn(d2, d6)), ac, a);
+        return madd(div_rn(d2, sub_rn(d2, d6)), ac, a);
     }
-    const float va = fmaf(d3, d6, -__fmul_rn(d5, d4));
-    const float d43 = __fsub_rn(d4, d3), d56 = __fsub_rn(d5, d6);
+    const float va = fmaf(d3, d6, -mul_rn(d5, d4));
+    const float d43 = sub_rn(d4, d3), d56 = sub_rn(d5, d6);
     if (va <= 0.f && d43 >= 0.f && d56 >= 0.f) {
-        return madd(__fdiv_rn(d43, __fadd_rn(d43, d56)), sub(c, b), b);
+        return madd(div_rn(d43, add_rn(d43, d56)), sub(c, b), b);
     }
-    const float denom = __fdiv_rn(1.f, __fadd_rn(__fadd_rn(va, vb), vc));
-    const float v = __fmul_rn(vb, denom), w = __fmul_rn(vc, denom);
+    const float denom = div_rn(1.f, add_rn(add_rn(va, vb), vc));
+    const float v = mul_rn(vb, denom), w = mul_rn(vc, denom);
     return madd(w, ac, madd(v, ab, a));
 }
 
@@ -66,10 +67,10 @@ PVAMD_DEV int ray_hits_triangle(V3 org, V3 dir, V3 v0, V3 v1, V3 v2) {
     const float den = dot(Ng, dir);
     const float absden = fabsf(den);
     const float sgn = den < 0.f ? -1.f : 1.f;
-    const float U = __fmul_rn(dot(R, e2), sgn);
-    const float V = __fmul_rn(dot(R, e1), sgn);
-    const float T = __fmul_rn(dot(Ng, C), sgn);
-    const bool hit = (den != 0.f) && (U >= 0.f) && (V >= 0.f) && (__fadd_rn(U, V) <= absden) && (T > 0.f);
+    const float U = mul_rn(dot(R, e2), sgn);
+    const float V = mul_rn(dot(R, e1), sgn);
+    const float T = mul_rn(dot(Ng, C), sgn);
+    const bool hit = (den != 0.f) && (U >= 0.f) && (V >= 0.f) && (add_rn(U, V) <= absden) && (T > 0.f);
     return hit ? 1 : 0;
 }
 
@@ -89,7 +90,7 @@ PVAMD_DEV float jitter_normal(uint64_t seed, int64_t index, int c) {
         const uint64_t h = splitmix64(seed ^ splitmix64((uint64_t)index * 9u + (uint64_t)(c * 3 + k)));
         s += (int)(h & 0xFFFF) + (int)((h >> 16) & 0xFFFF) + (int)((h >> 32) & 0xFFFF) + (int)((h >> 48) & 0xFFFF);
     }
-    return __fmul_rn((float)(s - 393210), 1.0f / 65536.0f);
+    return mul_rn((float)(s - 393210), 1.0f / 65536.0f);
 }
 
 // ray direction = float32(bounding_box(padding=1.0).max + 1e-4 * N(0,1)), the sum taken in float64 (sdf.py:147-150)

@@ -5,6 +5,7 @@
 // exact k-ordered fmaf chain, i.e. bit-identical to the scalar statement in oracle/pvamd_oracle.c (matmul4).
 // S*A is at most a few thousand matrices: this kernel is about exactness and keeping the stack on device, not speed.
 #include "common.h"
+#include "exact_math.h"
 
 namespace pvamd {
 
@@ -37,7 +38,7 @@ __global__ __launch_bounds__(64) void transform_stack_kernel(const float* __rest
 #pragma unroll
         for (int i = 0; i < 3; ++i) {
             // -(R^T t)_i = -(R[0][i] t0 + R[1][i] t1 + R[2][i] t2), k-ordered fma chain
-            bcol[i] = -fmaf(L[8 + i], L[11], fmaf(L[4 + i], L[7], __fmul_rn(L[i], L[3])));
+            bcol[i] = -fmaf(L[8 + i], L[11], fmaf(L[4 + i], L[7], mul_rn(L[i], L[3])));
         }
         bcol[3] = 1.f;
     }

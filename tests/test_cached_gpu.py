@@ -123,12 +123,21 @@ def test_nan_and_inf_points_are_out_of_bounds():
 
 def test_voxel_centres_map_to_themselves():
     """The invariant the reference asserts under debug_check_sdf (sdf.py:508-512)."""
-    c = make_cached()
-    _, centres = pv.get_coordinates_and_points_in_grid(c.resolution, c.ranges)
-    val, grad = c(centres.cuda())
-    packed = c._packed
-    assert torch.equal(val, packed[:, 0])
-    assert torch.equal(grad, packed[:, 1:4])
+    for f64 in (False, True):
+        c = make_cached(f64=f64)
+        coords, centres = pv.get_coordinates_and_points_in_grid(c.resolution, c.ranges)
+        val, grad = c(centres.cuda())
+        packed = c._packed
+        valid = c.voxels.get_valid_values(centres.cuda())
+        # fp32 centre coordinates on the boundary planes can round to just outside a float64 range (and then take the
+        # out-of-range branch, as they would in the reference); every interior centre must be in range
+        idx = torch.cartesian_prod(*[torch.arange(len(x)) for x in coords])
+        interior = ((idx > 0) & (idx < torch.tensor(c._view.shape) - 1)).all(dim=-1).cuda()
+        assert valid[interior].all()
+        assert torch.equal(val[valid], packed[valid, 0])
+        assert torch.equal(grad[valid], packed[valid, 1:4])
+        key = c.voxels.ensure_index_key(centres.cuda())
+        assert torch.equal(key.cpu(), idx)  # centre i -> index i, in range or not
 
 
 def test_bounding_box_fallback_properties():

@@ -1,0 +1,104 @@
+"""-m gpu: RobotSDF (FK -> MFMA transform stack -> fused composed query), BASELINE config C4 shape."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import pytorch_volumetric_amd as pv
+from oracle import oracle
+from pytorch_volumetric_amd import mesh_io
+from pytorch_volumetric_amd import transforms as tf
+from tests import helpers as H
+
+pytestmark = pytest.mark.gpu
+
+
+def test_transform_stack_mfma_matches_oracle_bitwise():
+    lib = pv._lib.load()
+    S, A = 8, 37  # not a multiple of the 16 matrices one wave handles
+    offs = H.random_rigid(S, seed=1, trans=0.05)
+    world = H.random_rigid(S * A, seed=2, trans=1.0)
+    off_inv = tf.rigid_inverse(offs).cuda().contiguous()
+    world_d = world.cuda().contiguous()
+    out = torch.empty_like(world_d)
+    pv._lib.check(lib.pvamd_transform_stack(pv._lib.ptr(off_inv), pv._lib.ptr(world_d), S, A, pv._lib.ptr(out),
+                                            pv._lib.stream_ptr()), "pvamd_transform_stack")
+    expect = oracle.transform_stack(off_inv.cpu().numpy(), world.numpy(), S, A)
+    assert np.array_equal(out.cpu().numpy(), expect)
+    # and it is what the reference computes: offset^-1 @ world^-1
+    ref = (tf.rigid_inverse(offs).double()[:, None] @ tf.rigid_inverse(world).double().reshape(S, A, 4, 4)).reshape(-1, 4, 4)
+    assert np.allclose(out.cpu().double().numpy(), ref.numpy(), atol=1e-6)
+
+
+def synthetic_arm(tmp_path, n_links=8):
+    """KUKA-like 7-revolute serial chain with 8 mesh links (the KUKA assets are not available offline)."""
+    names = []
+    for i in range(n_links):
+        m = mesh_io.uv_sphere_mesh(1.0, 16, 8, scale=(0.05, 0.05, 0.09), center=(0, 0, 0.08))
+        p = os.path.join(tmp_path, f"link_{i}.obj")
+        mesh_io.save_obj(p, m)
+        names.append(f"link_{i}.obj")
+    axes = ["0 0 1", "0 1 0", "0 0 1", "0 -1 0", "0 0 1", "0 1 0", "0 0 1"]
+    parts = ['<robot name="arm7">']
+    for i in range(n_links):
+        parts.append(f'<link name="link_{i}"><visual><origin xyz="0 0 0.01" rpy="0 0 0.1"/><geometry>'
+                     f'<mesh filename="{names[i]}"/></geometry></visual></link>')
+    for i in range(n_links - 1):
+        parts.append(f'<joint name="j{i}" type="revolute"><parent link="link_{i}"/><child link="link_{i + 1}"/>'
+                     f'<origin xyz="0 0 0.18" rpy="0 0 0"/><axis xyz="{axes[i]}"/></joint>')
+    parts.append('</robot>')
+    return pv.build_serial_chain_from_urdf("\n".join(parts), f"link_{n_links - 1}")
+
+
+def test_robot_sdf_config_batch_equals_loop_and_shapes(tmp_path):
+    """tests/test_model_to_sdf.py:173-212, 301-326 of the reference, headless."""
+    chain = synthetic_arm(str(tmp_path))
+    s = pv.RobotSDF(chain, path_prefix=str(tmp_path),
+                    link_sdf_cls=pv.cache_link_sdf_factory(resolution=0.02, padding=0.2, device="cuda",
+                                                           cache_path=None))
+    assert len(s.sdf.sdfs) == 8 and len(s.joint_names) == 7
+    th0 = torch.tensor([0.0, -np.pi / 4, 0.0, np.pi / 2, 0.0, np.pi / 4, 0.0])
+    N = 20
+    g = torch.Generator().manual_seed(0)
+    th = torch.cat((th0.view(1, -1), th0 + torch.randn(N - 1, 7, generator=g) * 0.1))
+    _, pts = pv.get_coordinates_and_points_in_grid(0.02, [(-0.6, 0.6), (0.02, 0.02), (-0.2, 1.4)])
+    pts = pts.cuda()
+    s.set_joint_configuration(th)
+    all_val, all_grad = s(pts)
+    assert all_val.shape == (N, len(pts)) and all_grad.shape == (N, len(pts), 3)
+    for i in range(N):
+        s.set_joint_configuration(th[i])
+        v, gr = s(pts)
+        assert v.shape == (len(pts),)
+        assert torch.allclose(v, all_val[i])
+        assert torch.allclose(gr.nan_to_num(0.), all_grad[i].nan_to_num(0.), atol=1e-6)
+    # multi-dim configuration and point batches (reference :301-326)
+    s.set_joint_configuration(th.view(4, 5, 7))
+    bv, bg = s(pts[:600].view(2, 300, 3))
+    assert bv.shape == (4, 5, 2, 300) and bg.shape == (4, 5, 2, 300, 3)
+    assert torch.equal(bv.reshape(N, -1), all_val[:, :600])
+    bbs = s.link_bounding_boxes()
+    assert bbs.shape == (8, 4, 5, 8, 3) or bbs.shape[0] == 8
+    # some points are inside the arm, most outside
+    assert (all_val < 0).any() and (all_val > 0.1).any()
+
+
+def test_robot_sdf_wrench_urdf_single_mesh_link():
+    """The reference's own URDF fixture (tests/offset_wrench.urdf): 6-DOF chain, one mesh link."""
+    chain = pv.build_chain_from_urdf(open(H.mesh_path("offset_wrench.urdf")).read())
+    s = pv.RobotSDF(chain, path_prefix=H.MESHES,
+                    link_sdf_cls=pv.cache_link_sdf_factory(resolution=0.005, padding=0.05, device="cuda",
+                                                           cache_path=None))
+    assert len(s.sdf.sdfs) == 1 and len(s.joint_names) == 6
+    q = torch.tensor([0.1, -0.05, 0.2, 0.3, -0.2, 0.5])
+    s.set_joint_configuration(q)
+    # a point given in the wrench's own frame, mapped to the world by FK, must see the leaf's own value
+    leaf = s.sdf.sdfs[0]
+    local = H.uniform_points(500, leaf.surface_bounding_box()[:, 0], leaf.surface_bounding_box()[:, 1], seed=1)
+    fk = chain.forward_kinematics(q)["offset_wrench"].get_matrix()[0]
+    world = local @ fk[:3, :3].T + fk[:3, 3]
+    v_world, _ = s(world.cuda())
+    v_local, _ = leaf(local.cuda())
+    # fp32 round trip through FK^-1 moves points by ~1e-7: allow the few that cross a voxel boundary
+    assert (torch.isclose(v_world, v_local, atol=1e-6).float().mean() > 0.97)
