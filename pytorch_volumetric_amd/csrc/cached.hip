@@ -7,29 +7,59 @@
 
 namespace pvamd {
 
-// ---- vector path: one thread = 4 consecutive points = 3 x 16 B loads, 4 x 16 B stores ----
+// ---- wave-tile path: one wave = 256 consecutive points per pass ----
+// Every global instruction moves a contiguous 1 KB (64 lanes x 16 B): 3 loads bring the tile's 768 floats of xyz into
+// a wave-private LDS slice, each lane then owns points lane, lane+64, lane+128, lane+192 of the tile (stride-3 dword
+// LDS reads: conflict-free), the 4 results go back through the same slice and leave as 1 + 3 contiguous 1 KB stores.
+// No block barrier: a wave's LDS traffic is ordered.  Measured against the previous "4 points per thread, 48-byte
+// strided float4" form: 0.63 ms -> 0.38 ms for 64M points (tools/kbench.hip, profiles/r01_kbench.txt).
+constexpr int kWavesPerBlock = 4;
+constexpr int kTilePoints = 256;
+
 template <bool F64, bool WRITE_OOB>
-__global__ __launch_bounds__(256) void cached_query_vec4(const pvamd_grid_t g, const f32x4* __restrict__ pts4,
-                                                          int64_t ngroups, f32x4* __restrict__ val4,
-                                                          f32x4* __restrict__ grad4, uint32_t* __restrict__ oob4) {
-    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < ngroups; i += stride) {
-        const f32x4 a = __builtin_nontemporal_load(pts4 + 3 * i);
-        const f32x4 b = __builtin_nontemporal_load(pts4 + 3 * i + 1);
-        const f32x4 c = __builtin_nontemporal_load(pts4 + 3 * i + 2);
-        bool v0, v1, v2, v3;
-        const float4 r0 = cached_lookup<F64>(g, a.x, a.y, a.z, v0);
-        const float4 r1 = cached_lookup<F64>(g, a.w, b.x, b.y, v1);
-        const float4 r2 = cached_lookup<F64>(g, b.z, b.w, c.x, v2);
-        const float4 r3 = cached_lookup<F64>(g, c.y, c.z, c.w, v3);
-        __builtin_nontemporal_store(f32x4{r0.x, r1.x, r2.x, r3.x}, val4 + i);
-        __builtin_nontemporal_store(f32x4{r0.y, r0.z, r0.w, r1.y}, grad4 + 3 * i);
-        __builtin_nontemporal_store(f32x4{r1.z, r1.w, r2.y, r2.z}, grad4 + 3 * i + 1);
-        __builtin_nontemporal_store(f32x4{r2.w, r3.y, r3.z, r3.w}, grad4 + 3 * i + 2);
-        if constexpr (WRITE_OOB) {
-            const uint32_t m = (v0 ? 0u : 1u) | (v1 ? 0u : 1u << 8) | (v2 ? 0u : 1u << 16) | (v3 ? 0u : 1u << 24);
-            __builtin_nontemporal_store(m, oob4 + i);
+__global__ __launch_bounds__(kWavesPerBlock * 64) void cached_query_wave(const pvamd_grid_t g,
+                                                                         const f32x4* __restrict__ pts4,
+                                                                         int64_t ntiles, f32x4* __restrict__ val4,
+                                                                         f32x4* __restrict__ grad4,
+                                                                         uint8_t* __restrict__ oob) {
+    __shared__ f32x4 lds[kWavesPerBlock][192 + 64];  // per wave: 768 floats xyz/grad + 256 floats val = 4 KB
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    f32x4* sp = lds[wave];
+    float* spf = reinterpret_cast<float*>(sp);
+    float* svf = spf + 768;
+    const int64_t wstride = (int64_t)gridDim.x * kWavesPerBlock;
+    for (int64_t tile = (int64_t)blockIdx.x * kWavesPerBlock + wave; tile < ntiles; tile += wstride) {
+        const f32x4* src = pts4 + tile * 192;
+        const f32x4 a = __builtin_nontemporal_load(src + lane);
+        const f32x4 b = __builtin_nontemporal_load(src + lane + 64);
+        const f32x4 c = __builtin_nontemporal_load(src + lane + 128);
+        sp[lane] = a;
+        sp[lane + 64] = b;
+        sp[lane + 128] = c;
+        float px[4], py[4], pz[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int p = lane + 64 * k;
+            px[k] = spf[3 * p];
+            py[k] = spf[3 * p + 1];
+            pz[k] = spf[3 * p + 2];
         }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int p = lane + 64 * k;
+            bool valid;
+            const float4 r = cached_lookup<F64>(g, px[k], py[k], pz[k], valid);
+            svf[p] = r.x;
+            spf[3 * p] = r.y;
+            spf[3 * p + 1] = r.z;
+            spf[3 * p + 2] = r.w;
+            if constexpr (WRITE_OOB) oob[tile * kTilePoints + p] = valid ? 0 : 1;
+        }
+        __builtin_nontemporal_store(sp[192 + lane], val4 + tile * 64 + lane);
+        f32x4* dst = grad4 + tile * 192;
+        __builtin_nontemporal_store(sp[lane], dst + lane);
+        __builtin_nontemporal_store(sp[lane + 64], dst + lane + 64);
+        __builtin_nontemporal_store(sp[lane + 128], dst + lane + 128);
     }
 }
 
@@ -113,24 +143,23 @@ extern "C" int pvamd_cached_query(const pvamd_grid_t* grid, const float* points,
     if (!aligned_to(points, 4) || !aligned_to(out_val, 4) || !aligned_to(out_grad, 4)) return PVAMD_E_ALIGN;
     hipStream_t s = (hipStream_t)stream;
     const bool f64 = grid->index_f64 != 0;
-    const bool vec_ok = aligned_to(points, 16) && aligned_to(out_val, 16) && aligned_to(out_grad, 16) &&
-                        (!out_oob || aligned_to(out_oob, 4));
-    const int64_t ngroups = vec_ok ? P / 4 : 0;
-    if (ngroups > 0) {
-        const dim3 grid_dim(stream_grid(ngroups, 256)), block(256);
+    const bool vec_ok = aligned_to(points, 16) && aligned_to(out_val, 16) && aligned_to(out_grad, 16);
+    const int64_t ntiles = vec_ok ? P / kTilePoints : 0;
+    if (ntiles > 0) {
+        const int64_t need = (ntiles + kWavesPerBlock - 1) / kWavesPerBlock;
+        const dim3 grid_dim((unsigned)(need < 4096 ? need : 4096)), block(kWavesPerBlock * 64);
         const f32x4* p4 = reinterpret_cast<const f32x4*>(points);
         f32x4* v4 = reinterpret_cast<f32x4*>(out_val);
         f32x4* g4 = reinterpret_cast<f32x4*>(out_grad);
-        uint32_t* o4 = reinterpret_cast<uint32_t*>(out_oob);
         if (f64) {
-            if (out_oob) hipLaunchKernelGGL((cached_query_vec4<true, true>), grid_dim, block, 0, s, *grid, p4, ngroups, v4, g4, o4);
-            else hipLaunchKernelGGL((cached_query_vec4<true, false>), grid_dim, block, 0, s, *grid, p4, ngroups, v4, g4, o4);
+            if (out_oob) hipLaunchKernelGGL((cached_query_wave<true, true>), grid_dim, block, 0, s, *grid, p4, ntiles, v4, g4, out_oob);
+            else hipLaunchKernelGGL((cached_query_wave<true, false>), grid_dim, block, 0, s, *grid, p4, ntiles, v4, g4, out_oob);
         } else {
-            if (out_oob) hipLaunchKernelGGL((cached_query_vec4<false, true>), grid_dim, block, 0, s, *grid, p4, ngroups, v4, g4, o4);
-            else hipLaunchKernelGGL((cached_query_vec4<false, false>), grid_dim, block, 0, s, *grid, p4, ngroups, v4, g4, o4);
+            if (out_oob) hipLaunchKernelGGL((cached_query_wave<false, true>), grid_dim, block, 0, s, *grid, p4, ntiles, v4, g4, out_oob);
+            else hipLaunchKernelGGL((cached_query_wave<false, false>), grid_dim, block, 0, s, *grid, p4, ntiles, v4, g4, out_oob);
         }
     }
-    const int64_t first = ngroups * 4;
+    const int64_t first = ntiles * kTilePoints;
     if (first < P) {
         const dim3 grid_dim(stream_grid(P - first, 256)), block(256);
         if (f64) hipLaunchKernelGGL((cached_query_scalar<true>), grid_dim, block, 0, s, *grid, points, first, P, out_val, out_grad, out_oob);

@@ -44,53 +44,78 @@ PVAMD_DEV void rotate_back(const float* __restrict__ M, const Best& b, float& ox
     oz = fmaf(M[10], b.gz, fmaf(M[6], b.gy, mul_rn(M[2], b.gx)));
 }
 
+// One wave = 256 consecutive points of one configuration per pass; all global traffic in contiguous 1 KB pieces
+// through a wave-private LDS slice (same scheme as cached_query_wave, see cached.hip).
+constexpr int kWavesPerBlock = 4;
+constexpr int kTilePoints = 256;
+
 template <bool ANY_F64>
-__global__ __launch_bounds__(256) void composed_query_vec4(const pvamd_grid_t* __restrict__ grids, int S,
-                                                            const float* __restrict__ tf, int A,
-                                                            const f32x4* __restrict__ pts4, int64_t ngroups,
-                                                            f32x4* __restrict__ val4, f32x4* __restrict__ grad4,
-                                                            int4* __restrict__ leaf4) {
+__global__ __launch_bounds__(kWavesPerBlock * 64) void composed_query_wave(const pvamd_grid_t* __restrict__ grids, int S,
+                                                                           const float* __restrict__ tf, int A,
+                                                                           const f32x4* __restrict__ pts4,
+                                                                           int64_t ntiles, int64_t P,
+                                                                           float* __restrict__ val,
+                                                                           float* __restrict__ grad,
+                                                                           int* __restrict__ leaf) {
+    __shared__ f32x4 lds[kWavesPerBlock][192 + 64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    f32x4* sp = lds[wave];
+    float* spf = reinterpret_cast<float*>(sp);
+    float* svf = spf + 768;
     const int a = blockIdx.y;
-    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < ngroups; i += stride) {
-        const f32x4 pa = pts4[3 * i], pb = pts4[3 * i + 1], pc = pts4[3 * i + 2];  // re-read per a: L2-resident
-        const float px[4] = {pa.x, pa.w, pb.z, pc.y};
-        const float py[4] = {pa.y, pb.x, pb.w, pc.z};
-        const float pz[4] = {pa.z, pb.y, pc.x, pc.w};
+    const int64_t wstride = (int64_t)gridDim.x * kWavesPerBlock;
+    for (int64_t tile = (int64_t)blockIdx.x * kWavesPerBlock + wave; tile < ntiles; tile += wstride) {
+        const f32x4* src = pts4 + tile * 192;  // re-read for every configuration: L2-resident
+        sp[lane] = src[lane];
+        sp[lane + 64] = src[lane + 64];
+        sp[lane + 128] = src[lane + 128];
+        float px[4], py[4], pz[4];
         Best best[4];
 #pragma unroll
-        for (int k = 0; k < 4; ++k) best[k] = Best{0.f, 0.f, 0.f, 0.f, -1};
+        for (int k = 0; k < 4; ++k) {
+            const int p = lane + 64 * k;
+            px[k] = spf[3 * p];
+            py[k] = spf[3 * p + 1];
+            pz[k] = spf[3 * p + 2];
+            best[k] = Best{0.f, 0.f, 0.f, 0.f, -1};
+        }
         for (int s = 0; s < S; ++s) {
-            const float* M = tf + 16 * ((int64_t)s * A + a);
+            const float* M = tf + 16 * ((int64_t)s * A + a);  // wave-uniform: scalar loads
             const pvamd_grid_t& g = grids[s];
 #pragma unroll
             for (int k = 0; k < 4; ++k) visit_leaf<ANY_F64>(g, M, s, px[k], py[k], pz[k], best[k]);
         }
-        float gx[4], gy[4], gz[4];
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-            // per-lane winner: the matrix row reads below are vector (not scalar) loads, but hit L1/L2
+            const int p = lane + 64 * k;
+            // per-lane winner: these matrix reads are vector loads, but the S*A stack is tiny and cache-resident
             const float* M = tf + 16 * ((int64_t)best[k].s * A + a);
-            rotate_back(M, best[k], gx[k], gy[k], gz[k]);
+            float gx, gy, gz;
+            rotate_back(M, best[k], gx, gy, gz);
+            svf[p] = best[k].v;
+            spf[3 * p] = gx;
+            spf[3 * p + 1] = gy;
+            spf[3 * p + 2] = gz;
+            if (leaf) leaf[(int64_t)a * P + tile * kTilePoints + p] = best[k].s;
         }
-        const int64_t o = (int64_t)a * ngroups + i;  // P == 4*ngroups on this path
-        __builtin_nontemporal_store(f32x4{best[0].v, best[1].v, best[2].v, best[3].v}, val4 + o);
-        __builtin_nontemporal_store(f32x4{gx[0], gy[0], gz[0], gx[1]}, grad4 + 3 * o);
-        __builtin_nontemporal_store(f32x4{gy[1], gz[1], gx[2], gy[2]}, grad4 + 3 * o + 1);
-        __builtin_nontemporal_store(f32x4{gz[2], gx[3], gy[3], gz[3]}, grad4 + 3 * o + 2);
-        if (leaf4) leaf4[o] = make_int4(best[0].s, best[1].s, best[2].s, best[3].s);
+        const int64_t o = (int64_t)a * P + tile * kTilePoints;  // multiple of 4: rows start 16-byte aligned
+        __builtin_nontemporal_store(sp[192 + lane], reinterpret_cast<f32x4*>(val + o) + lane);
+        f32x4* dst = reinterpret_cast<f32x4*>(grad + 3 * o);
+        __builtin_nontemporal_store(sp[lane], dst + lane);
+        __builtin_nontemporal_store(sp[lane + 64], dst + lane + 64);
+        __builtin_nontemporal_store(sp[lane + 128], dst + lane + 128);
     }
 }
 
 template <bool ANY_F64>
 __global__ __launch_bounds__(256) void composed_query_scalar(const pvamd_grid_t* __restrict__ grids, int S,
                                                               const float* __restrict__ tf, int A,
-                                                              const float* __restrict__ pts, int64_t P,
-                                                              float* __restrict__ val, float* __restrict__ grad,
-                                                              int* __restrict__ leaf) {
+                                                              const float* __restrict__ pts, int64_t first,
+                                                              int64_t P, float* __restrict__ val,
+                                                              float* __restrict__ grad, int* __restrict__ leaf) {
     const int a = blockIdx.y;
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < P; i += stride) {
+    for (int64_t i = first + (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < P; i += stride) {
         const float px = pts[3 * i], py = pts[3 * i + 1], pz = pts[3 * i + 2];
         Best best{0.f, 0.f, 0.f, 0.f, -1};
         for (int s = 0; s < S; ++s) {
@@ -119,25 +144,23 @@ extern "C" int pvamd_composed_query(const pvamd_grid_t* grids, int32_t S, const 
     if (!grids || !tf || !out_val || !out_grad || !points) return PVAMD_E_NULL;
     if (!aligned_to(grids, 8) || !aligned_to(tf, 4) || !aligned_to(points, 4)) return PVAMD_E_ALIGN;
     hipStream_t s = (hipStream_t)stream;
-    const bool vec_ok = (P % 4 == 0) && aligned_to(points, 16) && aligned_to(out_val, 16) && aligned_to(out_grad, 16) &&
-                        (!out_leaf || aligned_to(out_leaf, 16));
+    const bool vec_ok = (P % 4 == 0) && aligned_to(points, 16) && aligned_to(out_val, 16) && aligned_to(out_grad, 16);
     // The leaf descriptors live in device memory; whether any of them asks for float64 index arithmetic is not
     // known host-side, so the kernels are built for the general case and test the (wave-uniform) flag per leaf.
-    if (vec_ok) {
-        const int64_t ngroups = P / 4;
-        // 2-D grid: x covers the points (capped; grid-stride), y = configuration
-        const int64_t need = (ngroups + 255) / 256;
-        const int64_t cap = ((int64_t)kNumCU * kMaxBlocksPerCU + A - 1) / A;
+    const int64_t ntiles = vec_ok ? P / kTilePoints : 0;
+    const int64_t cap = ((int64_t)4096 + A - 1) / A;  // ~4096 blocks in total, split over the A configurations
+    if (ntiles > 0) {
+        const int64_t need = (ntiles + kWavesPerBlock - 1) / kWavesPerBlock;
         const unsigned gx = (unsigned)(need < cap ? need : (cap < 1 ? 1 : cap));
-        hipLaunchKernelGGL((composed_query_vec4<true>), dim3(gx, A), dim3(256), 0, s, grids, S, tf, A,
-                           reinterpret_cast<const f32x4*>(points), ngroups, reinterpret_cast<f32x4*>(out_val),
-                           reinterpret_cast<f32x4*>(out_grad), reinterpret_cast<int4*>(out_leaf));
-    } else {
-        const int64_t need = (P + 255) / 256;
-        const int64_t cap = ((int64_t)kNumCU * kMaxBlocksPerCU + A - 1) / A;
+        hipLaunchKernelGGL((composed_query_wave<true>), dim3(gx, A), dim3(kWavesPerBlock * 64), 0, s, grids, S, tf, A,
+                           reinterpret_cast<const f32x4*>(points), ntiles, P, out_val, out_grad, out_leaf);
+    }
+    const int64_t first = ntiles * kTilePoints;
+    if (first < P) {
+        const int64_t need = (P - first + 255) / 256;
         const unsigned gx = (unsigned)(need < cap ? need : (cap < 1 ? 1 : cap));
-        hipLaunchKernelGGL((composed_query_scalar<true>), dim3(gx, A), dim3(256), 0, s, grids, S, tf, A, points, P,
-                           out_val, out_grad, out_leaf);
+        hipLaunchKernelGGL((composed_query_scalar<true>), dim3(gx, A), dim3(256), 0, s, grids, S, tf, A, points, first,
+                           P, out_val, out_grad, out_leaf);
     }
     return (int)hipGetLastError();
 }
