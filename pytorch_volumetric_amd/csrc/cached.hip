@@ -22,20 +22,34 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void cached_query_wave(const p
                                                                          int64_t ntiles, f32x4* __restrict__ val4,
                                                                          f32x4* __restrict__ grad4,
                                                                          uint8_t* __restrict__ oob) {
-    __shared__ f32x4 lds[kWavesPerBlock][192 + 64];  // per wave: 768 floats xyz/grad + 256 floats val = 4 KB
+    __shared__ __attribute__((aligned(16))) float lds[kWavesPerBlock][1024];  // per wave: 768 floats xyz/grad + 256 floats val = 4 KB
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    f32x4* sp = lds[wave];
-    float* spf = reinterpret_cast<float*>(sp);
+    float* spf = lds[wave];
+    f32x4_alias* sp = reinterpret_cast<f32x4_alias*>(spf);
     float* svf = spf + 768;
     const int64_t wstride = (int64_t)gridDim.x * kWavesPerBlock;
-    for (int64_t tile = (int64_t)blockIdx.x * kWavesPerBlock + wave; tile < ntiles; tile += wstride) {
+    int64_t tile = (int64_t)blockIdx.x * kWavesPerBlock + wave;
+    f32x4 a, b, c;
+    if (tile < ntiles) {
         const f32x4* src = pts4 + tile * 192;
-        const f32x4 a = __builtin_nontemporal_load(src + lane);
-        const f32x4 b = __builtin_nontemporal_load(src + lane + 64);
-        const f32x4 c = __builtin_nontemporal_load(src + lane + 128);
+        a = __builtin_nontemporal_load(src + lane);
+        b = __builtin_nontemporal_load(src + lane + 64);
+        c = __builtin_nontemporal_load(src + lane + 128);
+    }
+    for (; tile < ntiles; tile += wstride) {
         sp[lane] = a;
         sp[lane + 64] = b;
         sp[lane + 128] = c;
+        // software prefetch: the next tile's HBM loads are in flight while this tile is looked up (the wave fences
+        // below stop the compiler from doing this itself); 0.47 -> 0.42 ms per 64M points (profiles/r01_kbench.txt)
+        const int64_t next = tile + wstride;
+        if (next < ntiles) {
+            const f32x4* src = pts4 + next * 192;
+            a = __builtin_nontemporal_load(src + lane);
+            b = __builtin_nontemporal_load(src + lane + 64);
+            c = __builtin_nontemporal_load(src + lane + 128);
+        }
+        PVAMD_WAVE_SYNC();
         float px[4], py[4], pz[4];
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
@@ -44,6 +58,7 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void cached_query_wave(const p
             py[k] = spf[3 * p + 1];
             pz[k] = spf[3 * p + 2];
         }
+        PVAMD_WAVE_SYNC();
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             const int p = lane + 64 * k;
@@ -55,11 +70,13 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void cached_query_wave(const p
             spf[3 * p + 2] = r.w;
             if constexpr (WRITE_OOB) oob[tile * kTilePoints + p] = valid ? 0 : 1;
         }
+        PVAMD_WAVE_SYNC();
         __builtin_nontemporal_store(sp[192 + lane], val4 + tile * 64 + lane);
         f32x4* dst = grad4 + tile * 192;
         __builtin_nontemporal_store(sp[lane], dst + lane);
         __builtin_nontemporal_store(sp[lane + 64], dst + lane + 64);
         __builtin_nontemporal_store(sp[lane + 128], dst + lane + 128);
+        PVAMD_WAVE_SYNC();
     }
 }
 
@@ -147,7 +164,7 @@ extern "C" int pvamd_cached_query(const pvamd_grid_t* grid, const float* points,
     const int64_t ntiles = vec_ok ? P / kTilePoints : 0;
     if (ntiles > 0) {
         const int64_t need = (ntiles + kWavesPerBlock - 1) / kWavesPerBlock;
-        const dim3 grid_dim((unsigned)(need < 4096 ? need : 4096)), block(kWavesPerBlock * 64);
+        const dim3 grid_dim((unsigned)(need < 1024 ? need : 1024)), block(kWavesPerBlock * 64);  // 4 waves/SIMD
         const f32x4* p4 = reinterpret_cast<const f32x4*>(points);
         f32x4* v4 = reinterpret_cast<f32x4*>(out_val);
         f32x4* g4 = reinterpret_cast<f32x4*>(out_grad);

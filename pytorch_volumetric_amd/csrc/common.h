@@ -9,6 +9,19 @@ namespace pvamd {
 // native clang vectors: the non-temporal builtins and 16-B global_load/store_dwordx4 want these, not HIP's structs
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
+// same 16-byte vector, but allowed to alias plain float storage (LDS slices accessed both as floats and as float4s)
+typedef f32x4 __attribute__((may_alias)) f32x4_alias;
+
+// Wave-synchronous LDS exchange: lanes of ONE wave hand data to each other through LDS without a block barrier.  The
+// hardware executes a wave's DS instructions in order, but the compiler reasons per thread and will move a lane's
+// LDS store past loads that (for that lane) cannot alias -- seen in the ISA of the first version of cached_query_wave.
+// A wavefront-scope release/acquire fence pair around a wave_barrier pins the order; it emits no s_barrier.
+#define PVAMD_WAVE_SYNC()                                         \
+    do {                                                          \
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");    \
+        __builtin_amdgcn_wave_barrier();                          \
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");    \
+    } while (0)
 
 constexpr int kNumCU = 256;         // MI355X: 8 XCDs x 32 CUs
 constexpr int kMaxBlocksPerCU = 8;  // memory-bound kernels: cap the grid at 256 CU x 8 and grid-stride the rest

@@ -57,10 +57,10 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void composed_query_wave(const
                                                                            float* __restrict__ val,
                                                                            float* __restrict__ grad,
                                                                            int* __restrict__ leaf) {
-    __shared__ f32x4 lds[kWavesPerBlock][192 + 64];
+    __shared__ __attribute__((aligned(16))) float lds[kWavesPerBlock][1024];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    f32x4* sp = lds[wave];
-    float* spf = reinterpret_cast<float*>(sp);
+    float* spf = lds[wave];
+    f32x4_alias* sp = reinterpret_cast<f32x4_alias*>(spf);
     float* svf = spf + 768;
     const int a = blockIdx.y;
     const int64_t wstride = (int64_t)gridDim.x * kWavesPerBlock;
@@ -69,6 +69,7 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void composed_query_wave(const
         sp[lane] = src[lane];
         sp[lane + 64] = src[lane + 64];
         sp[lane + 128] = src[lane + 128];
+        PVAMD_WAVE_SYNC();
         float px[4], py[4], pz[4];
         Best best[4];
 #pragma unroll
@@ -79,6 +80,7 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void composed_query_wave(const
             pz[k] = spf[3 * p + 2];
             best[k] = Best{0.f, 0.f, 0.f, 0.f, -1};
         }
+        PVAMD_WAVE_SYNC();
         for (int s = 0; s < S; ++s) {
             const float* M = tf + 16 * ((int64_t)s * A + a);  // wave-uniform: scalar loads
             const pvamd_grid_t& g = grids[s];
@@ -98,12 +100,14 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void composed_query_wave(const
             spf[3 * p + 2] = gz;
             if (leaf) leaf[(int64_t)a * P + tile * kTilePoints + p] = best[k].s;
         }
+        PVAMD_WAVE_SYNC();
         const int64_t o = (int64_t)a * P + tile * kTilePoints;  // multiple of 4: rows start 16-byte aligned
         __builtin_nontemporal_store(sp[192 + lane], reinterpret_cast<f32x4*>(val + o) + lane);
         f32x4* dst = reinterpret_cast<f32x4*>(grad + 3 * o);
         __builtin_nontemporal_store(sp[lane], dst + lane);
         __builtin_nontemporal_store(sp[lane + 64], dst + lane + 64);
         __builtin_nontemporal_store(sp[lane + 128], dst + lane + 128);
+        PVAMD_WAVE_SYNC();
     }
 }
 

@@ -8,6 +8,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstring>
+#include <dlfcn.h>
 #include "../pytorch_volumetric_amd/csrc/common.h"
 #include "../pytorch_volumetric_amd/csrc/grid_lookup.h"
 
@@ -110,19 +111,21 @@ __global__ __launch_bounds__(256) void q_lds(const pvamd_grid_t g, const f32x4* 
 // 1 KB stores.  GMODE: 0 plain gather, 1 nontemporal gather ----
 template <bool F64, int GMODE, int WAVES>
 __global__ __launch_bounds__(WAVES * 64) void q_wave(const pvamd_grid_t g, const f32x4* __restrict__ pts4, int64_t ntiles, f32x4* __restrict__ val4, f32x4* __restrict__ grad4) {
-    __shared__ f32x4 lds[WAVES][192 + 64];  // per wave: 768 floats of xyz / grad + 256 floats of val
+    __shared__ __attribute__((aligned(16))) float lds[WAVES][1024];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    f32x4* sp = lds[wave];
-    float* spf = reinterpret_cast<float*>(sp);
+    float* spf = lds[wave];
+    f32x4_alias* sp = reinterpret_cast<f32x4_alias*>(spf);
     float* svf = spf + 768;
     const int64_t wstride = (int64_t)gridDim.x * WAVES;
     for (int64_t tile = (int64_t)blockIdx.x * WAVES + wave; tile < ntiles; tile += wstride) {
         const f32x4* src = pts4 + tile * 192;
         const f32x4 a = __builtin_nontemporal_load(src + lane), b = __builtin_nontemporal_load(src + lane + 64), c = __builtin_nontemporal_load(src + lane + 128);
         sp[lane] = a; sp[lane + 64] = b; sp[lane + 128] = c;
+        PVAMD_WAVE_SYNC();
         float px[4], py[4], pz[4];
 #pragma unroll
         for (int k = 0; k < 4; ++k) { const int p = lane + 64 * k; px[k] = spf[3 * p]; py[k] = spf[3 * p + 1]; pz[k] = spf[3 * p + 2]; }
+        PVAMD_WAVE_SYNC();
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             const int p = lane + 64 * k;
@@ -135,11 +138,80 @@ __global__ __launch_bounds__(WAVES * 64) void q_wave(const pvamd_grid_t g, const
             } else r = bounding_box_sdf(g, px[k], py[k], pz[k]);
             svf[p] = r.x; spf[3 * p] = r.y; spf[3 * p + 1] = r.z; spf[3 * p + 2] = r.w;
         }
+        PVAMD_WAVE_SYNC();
         __builtin_nontemporal_store(sp[192 + lane], val4 + tile * 64 + lane);
         f32x4* dst = grad4 + tile * 192;
         __builtin_nontemporal_store(sp[lane], dst + lane);
         __builtin_nontemporal_store(sp[lane + 64], dst + lane + 64);
         __builtin_nontemporal_store(sp[lane + 128], dst + lane + 128);
+        PVAMD_WAVE_SYNC();
+    }
+}
+
+// ---- dwordx3 per point: lane-consecutive points, every VMEM instruction contiguous (768 B loads/stores, 256 B val
+// stores), no LDS.  UNR points per lane in flight. ----
+typedef float f32x3 __attribute__((ext_vector_type(3)));
+typedef f32x3 __attribute__((aligned(4))) f32x3_u;  // 12 bytes of payload at 4-byte alignment
+template <bool F64, int UNR>
+__global__ __launch_bounds__(256) void q_x3(const pvamd_grid_t g, const float* __restrict__ pts, int64_t P, float* __restrict__ val, float* __restrict__ grad) {
+    const int64_t chunk = (int64_t)blockDim.x * UNR;
+    for (int64_t base = (int64_t)blockIdx.x * chunk; base < P; base += (int64_t)gridDim.x * chunk) {
+        float px[UNR], py[UNR], pz[UNR];
+#pragma unroll
+        for (int k = 0; k < UNR; ++k) {
+            const int64_t i = base + threadIdx.x + (int64_t)k * blockDim.x;
+            const f32x3 q = __builtin_nontemporal_load(reinterpret_cast<const f32x3_u*>(pts + 3 * (i < P ? i : P - 1)));
+            px[k] = q.x; py[k] = q.y; pz[k] = q.z;
+        }
+#pragma unroll
+        for (int k = 0; k < UNR; ++k) {
+            const int64_t i = base + threadIdx.x + (int64_t)k * blockDim.x;
+            bool valid;
+            const float4 r = cached_lookup<F64>(g, px[k], py[k], pz[k], valid);
+            if (i < P) {
+                __builtin_nontemporal_store(r.x, val + i);
+                const f32x3 o = {r.y, r.z, r.w};
+                __builtin_nontemporal_store(o, reinterpret_cast<f32x3_u*>(grad + 3 * i));
+            }
+        }
+    }
+}
+
+// ---- q_wave with the next tile's global loads issued before the current tile is processed ----
+template <bool F64, int WAVES>
+__global__ __launch_bounds__(WAVES * 64) void q_wave_pf(const pvamd_grid_t g, const f32x4* __restrict__ pts4, int64_t ntiles, f32x4* __restrict__ val4, f32x4* __restrict__ grad4) {
+    __shared__ __attribute__((aligned(16))) float lds[WAVES][1024];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    float* spf = lds[wave];
+    f32x4_alias* sp = reinterpret_cast<f32x4_alias*>(spf);
+    float* svf = spf + 768;
+    const int64_t wstride = (int64_t)gridDim.x * WAVES;
+    int64_t tile = (int64_t)blockIdx.x * WAVES + wave;
+    f32x4 a, b, c;
+    if (tile < ntiles) { const f32x4* src = pts4 + tile * 192; a = __builtin_nontemporal_load(src + lane); b = __builtin_nontemporal_load(src + lane + 64); c = __builtin_nontemporal_load(src + lane + 128); }
+    for (; tile < ntiles; tile += wstride) {
+        sp[lane] = a; sp[lane + 64] = b; sp[lane + 128] = c;
+        const int64_t nt = tile + wstride;
+        if (nt < ntiles) { const f32x4* src = pts4 + nt * 192; a = __builtin_nontemporal_load(src + lane); b = __builtin_nontemporal_load(src + lane + 64); c = __builtin_nontemporal_load(src + lane + 128); }
+        PVAMD_WAVE_SYNC();
+        float px[4], py[4], pz[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { const int p = lane + 64 * k; px[k] = spf[3 * p]; py[k] = spf[3 * p + 1]; pz[k] = spf[3 * p + 2]; }
+        PVAMD_WAVE_SYNC();
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int p = lane + 64 * k;
+            bool valid;
+            const float4 r = cached_lookup<F64>(g, px[k], py[k], pz[k], valid);
+            svf[p] = r.x; spf[3 * p] = r.y; spf[3 * p + 1] = r.z; spf[3 * p + 2] = r.w;
+        }
+        PVAMD_WAVE_SYNC();
+        __builtin_nontemporal_store(sp[192 + lane], val4 + tile * 64 + lane);
+        f32x4* dst = grad4 + tile * 192;
+        __builtin_nontemporal_store(sp[lane], dst + lane);
+        __builtin_nontemporal_store(sp[lane + 64], dst + lane + 64);
+        __builtin_nontemporal_store(sp[lane + 128], dst + lane + 128);
+        PVAMD_WAVE_SYNC();
     }
 }
 
@@ -172,7 +244,11 @@ int main(int argc, char** argv) {
     const f32x4* p4 = (const f32x4*)dp; f32x4* v4 = (f32x4*)dval; f32x4* g4 = (f32x4*)dgrad;
     struct V { const char* name; int id; };
     std::vector<V> vs = {{"copy_linear(28B/pt)", 0}, {"copy_strided", 1}, {"q_strided f64 gather nt (product)", 2}, {"q_strided f32 gather nt", 3},
-                         {"q_strided f64 NOgather nt", 4}, {"q_strided f32 NOgather nt", 5}, {"q_strided f64 gather plain-ld/st", 6}, {"q_lds f64", 7}, {"q_lds f32", 8}, {"q_wave f64 plain W4", 9}, {"q_wave f64 ntgather W4", 10}, {"q_wave f32 plain W4", 11}, {"q_wave f64 plain W8", 12}, {"q_wave f64 plain W16", 13}, {"q_wave f64 plain W4 grid4096", 14}};
+                         {"q_strided f64 NOgather nt", 4}, {"q_strided f32 NOgather nt", 5}, {"q_strided f64 gather plain-ld/st", 6}, {"q_lds f64", 7}, {"q_lds f32", 8}, {"q_wave f64 plain W4", 9}, {"q_wave f64 ntgather W4", 10}, {"q_wave f32 plain W4", 11}, {"q_wave f64 plain W8", 12}, {"q_wave f64 plain W16", 13}, {"q_wave f64 plain W4 grid4096", 14}, {"q_x3 f64 unr4", 15}, {"q_x3 f64 unr2", 16}, {"q_x3 f64 unr1", 17}, {"q_x3 f64 unr8", 18}, {"q_wave_pf f64 W4 g2048", 19}, {"q_wave_pf f64 W4 g1024", 20}, {"q_x3 f32 unr4", 21}, {"PRODUCT libpvamd.so pvamd_cached_query", 22}};
+    typedef int (*cq_t)(const pvamd_grid_t*, const float*, int64_t, float*, float*, uint8_t*, void*);
+    void* so = dlopen("pytorch_volumetric_amd/csrc/libpvamd.so", RTLD_NOW);
+    cq_t product = so ? (cq_t)dlsym(so, "pvamd_cached_query") : nullptr;
+    if (!product) printf("libpvamd.so not found (run from the repo root): product row is a no-op\n");
     std::vector<std::vector<float>> times(vs.size());
     auto launch = [&](int id) {
         switch (id) {
@@ -190,6 +266,14 @@ int main(int argc, char** argv) {
             case 11: hipLaunchKernelGGL((q_wave<false, 0, 4>), dim3((unsigned)std::min<int64_t>((nwt + 3) / 4, 2048)), dim3(256), 0, 0, g, p4, nwt, v4, g4); break;
             case 12: hipLaunchKernelGGL((q_wave<true, 0, 8>), dim3((unsigned)std::min<int64_t>((nwt + 7) / 8, 1024)), dim3(512), 0, 0, g, p4, nwt, v4, g4); break;
             case 13: hipLaunchKernelGGL((q_wave<true, 0, 16>), dim3((unsigned)std::min<int64_t>((nwt + 15) / 16, 512)), dim3(1024), 0, 0, g, p4, nwt, v4, g4); break;
+            case 15: hipLaunchKernelGGL((q_x3<true, 4>), dim3((unsigned)std::min<int64_t>((P + 1023) / 1024, 4096)), dim3(256), 0, 0, g, dp, P, dval, dgrad); break;
+            case 16: hipLaunchKernelGGL((q_x3<true, 2>), dim3((unsigned)std::min<int64_t>((P + 511) / 512, 4096)), dim3(256), 0, 0, g, dp, P, dval, dgrad); break;
+            case 17: hipLaunchKernelGGL((q_x3<true, 1>), dim3((unsigned)std::min<int64_t>((P + 255) / 256, 8192)), dim3(256), 0, 0, g, dp, P, dval, dgrad); break;
+            case 18: hipLaunchKernelGGL((q_x3<true, 8>), dim3((unsigned)std::min<int64_t>((P + 2047) / 2048, 4096)), dim3(256), 0, 0, g, dp, P, dval, dgrad); break;
+            case 19: hipLaunchKernelGGL((q_wave_pf<true, 4>), dim3((unsigned)std::min<int64_t>((nwt + 3) / 4, 2048)), dim3(256), 0, 0, g, p4, nwt, v4, g4); break;
+            case 20: hipLaunchKernelGGL((q_wave_pf<true, 4>), dim3((unsigned)std::min<int64_t>((nwt + 3) / 4, 1024)), dim3(256), 0, 0, g, p4, nwt, v4, g4); break;
+            case 21: hipLaunchKernelGGL((q_x3<false, 4>), dim3((unsigned)std::min<int64_t>((P + 1023) / 1024, 4096)), dim3(256), 0, 0, g, dp, P, dval, dgrad); break;
+            case 22: if (product) product(&g, dp, P, dval, dgrad, nullptr, nullptr); break;
             case 14: hipLaunchKernelGGL((q_wave<true, 0, 4>), dim3((unsigned)std::min<int64_t>((nwt + 3) / 4, 4096)), dim3(256), 0, 0, g, p4, nwt, v4, g4); break;
         }
     };
