@@ -464,23 +464,23 @@ class ComposedSDF(ObjectFrameSDF):
     def set_transforms(self, tsf, batch_dim=None):
         """sdf.py:370-383.  An un-given batch is inferred as (S_tsf // S,) -- the reference computes a float there
         (sdf.py:379) and cannot slice with it; only its explicit batch_dim path works."""
-        self.tsf_batch = batch_dim
-        self._tf_dev = None
         if tsf is None:
-            self.obj_frame_to_link_frame = None
-            self.link_frame_to_obj_frame = []
+            self.obj_frame_to_link_frame, self.link_frame_to_obj_frame = None, []
+            self.tsf_batch, self._tf_dev = batch_dim, None
             return
         m = tf.as_matrix(tsf)
-        self.obj_frame_to_link_frame = tsf if hasattr(tsf, "get_matrix") else tf.Transform3d(matrix=m)
         S, S_tsf = len(self.sdfs), m.shape[0]
-        if self.tsf_batch is None and S_tsf != S:
+        if batch_dim is None:
             if S_tsf % S != 0:
                 raise ValueError(f"{S_tsf} transforms cannot be split over {S} SDFs")
-            self.tsf_batch = (S_tsf // S,)
-        elif self.tsf_batch is not None:
-            self.tsf_batch = tuple(int(b) for b in self.tsf_batch)
-            if math.prod(self.tsf_batch) * S != S_tsf:
-                raise ValueError(f"{S_tsf} transforms != {S} SDFs x batch {self.tsf_batch}")
+            batch_dim = None if S_tsf == S else (S_tsf // S,)
+        else:
+            batch_dim = tuple(int(b) for b in batch_dim)
+            if math.prod(batch_dim) * S != S_tsf:
+                raise ValueError(f"{S_tsf} transforms != {S} SDFs x batch {batch_dim}")
+        # validated: now commit
+        self.tsf_batch, self._tf_dev = batch_dim, None
+        self.obj_frame_to_link_frame = tsf if hasattr(tsf, "get_matrix") else tf.Transform3d(matrix=m)
         inv = tf.rigid_inverse(m)
         self.link_frame_to_obj_frame = [tf.Transform3d(matrix=inv[self.ith_transform_slice(i)]) for i in range(S)]
 

@@ -1,0 +1,84 @@
+"""CPU: the C-ABI library loads and exports exactly what include/pvamd.h declares (no compute calls)."""
+import ctypes
+import os
+import re
+import subprocess
+
+import pytest
+
+import pytorch_volumetric_amd as pv
+from pytorch_volumetric_amd import _lib
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HEADER = os.path.join(ROOT, "include", "pvamd.h")
+
+
+def declared_functions():
+    text = open(HEADER).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(pvamd_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_library_is_built_in_tree_and_loads():
+    assert os.path.exists(_lib.LIB_PATH), "run __graft_entry__.build() first"
+    lib = _lib.load()
+    assert lib.pvamd_abi_version() == _lib.ABI_VERSION
+    assert b"gfx950" in lib.pvamd_build_info()
+
+
+def test_every_declared_symbol_is_exported_and_bound():
+    names = declared_functions()
+    assert len(names) >= 12
+    lib = ctypes.CDLL(_lib.LIB_PATH)
+    for n in names:
+        assert hasattr(lib, n), f"{n} declared in include/pvamd.h but not exported"
+    assert sorted(_lib.SIGNATURES) == names, "ctypes binding and header disagree"
+
+
+def test_struct_layouts_match_the_header():
+    """Compile a tiny C program against the header and compare sizeof/offsetof with the ctypes mirrors."""
+    src = r'''
+    #include <stdio.h>
+    #include <stddef.h>
+    #include "pvamd.h"
+    int main(void) {
+      printf("%zu %zu %zu %zu %zu %zu %zu\n", sizeof(pvamd_grid_t), offsetof(pvamd_grid_t, dres), offsetof(pvamd_grid_t, fmin),
+             offsetof(pvamd_grid_t, bb_min), offsetof(pvamd_grid_t, shape), offsetof(pvamd_grid_t, index_f64),
+             offsetof(pvamd_grid_t, oob_mode));
+      printf("%zu %zu %zu\n", sizeof(pvamd_mesh_t), offsetof(pvamd_mesh_t, F), offsetof(pvamd_mesh_t, ray_dir));
+      return 0; }'''
+    exe = "/tmp/_pvamd_layout"
+    subprocess.run(["gcc", "-x", "c", "-", "-I", os.path.join(ROOT, "include"), "-o", exe], input=src.encode(), check=True)
+    out = subprocess.run([exe], capture_output=True, check=True).stdout.decode().split()
+    G, M = _lib.GridDesc, _lib.MeshDesc
+    assert [int(x) for x in out[:7]] == [ctypes.sizeof(G), G.dres.offset, G.fmin.offset, G.bb_min.offset, G.shape.offset,
+                                         G.index_f64.offset, G.oob_mode.offset]
+    assert [int(x) for x in out[7:]] == [ctypes.sizeof(M), M.F.offset, M.ray_dir.offset]
+
+
+def test_no_gpu_means_a_loud_error_not_a_fallback():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    with pytest.raises(_lib.PvamdError):
+        _lib.require_gpu()
+    obj = pv.MeshObjectFactory(mesh=pv.mesh_io.box_mesh()) if hasattr(pv, "mesh_io") else None
+    from pytorch_volumetric_amd import mesh_io
+    obj = pv.MeshObjectFactory(mesh=mesh_io.box_mesh())
+    with pytest.raises(_lib.PvamdError):
+        pv.MeshSDF(obj)(torch.zeros(4, 3))
+
+
+def test_product_never_touches_the_oracle():
+    """oracle/ is test infrastructure: nothing under pytorch_volumetric_amd/ may import, load or link it."""
+    pkg = os.path.join(ROOT, "pytorch_volumetric_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", "Makefile")):
+                text = open(os.path.join(dirpath, f), errors="ignore").read()
+                assert "import oracle" not in text and "from oracle" not in text, f
+                assert "libpvamd_oracle" not in text, f
+                if f.endswith((".hip", ".h")) and f != "xform.hip":
+                    assert '#include "../../oracle' not in text and "oracle/" not in text.replace("oracle/pvamd_oracle.c", ""), f
+    deps = subprocess.run(["ldd", _lib.LIB_PATH], capture_output=True).stdout.decode()
+    assert "oracle" not in deps

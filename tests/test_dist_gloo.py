@@ -1,0 +1,104 @@
+"""CPU, world_size 2 over gloo: the multi-GPU sharding logic (partition, pad, all-gather, reorder, trim; chamfer
+all-reduce) with the oracle standing in for the per-rank kernels."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+import pytorch_volumetric_amd as pv
+from oracle import oracle
+from pytorch_volumetric_amd.dist import ShardedSDF, shard_range
+from tests import helpers as H
+
+
+def free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+class OracleLeaf:
+    """CPU stand-in for a CachedSDF leaf (the checker computes here; the product path would be the HIP kernel)."""
+
+    def __init__(self):
+        gt = H.drill_like_gt()
+        rng = H.padded_range(H.DRILL_BB, 0.1)
+        snapped = pv.get_divisible_range_by_resolution(0.02, rng)
+        _, pts = pv.get_coordinates_and_points_in_grid(0.02, snapped)
+        coords, _ = pv.get_coordinates_and_points_in_grid(0.02, snapped)
+        v, g = gt(pts)
+        self.grid = oracle.Grid(v.reshape([len(c) for c in coords]).numpy(), g.numpy(),
+                                np.array([s[0] for s in snapped]), np.array([s[1] for s in snapped]), H.DRILL_BB)
+
+    def __call__(self, pts):
+        lead = pts.shape[:-1]
+        v, g, _ = oracle.cached_query(self.grid, pts.reshape(-1, 3).numpy())
+        return torch.from_numpy(v).reshape(*lead), torch.from_numpy(g).reshape(*lead, 3)
+
+
+class OracleRobot:
+    """Config-batched composed query: returns (A, P) / (A, P, 3) like RobotSDF."""
+
+    def __init__(self, A):
+        self.leaf = OracleLeaf()
+        self.A = A
+        self.tf = H.random_rigid(3 * A, seed=11).numpy()
+
+    def __call__(self, pts):
+        v, g, _ = oracle.composed_query([self.leaf.grid] * 3, self.tf, self.A, pts.reshape(-1, 3).numpy())
+        return torch.from_numpy(v), torch.from_numpy(g)
+
+
+def worker(rank, world, port, P, results):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        pts = H.uniform_points(P, [-0.3] * 3, [0.4] * 3, seed=5).reshape(-1, 3)
+        leaf = OracleLeaf()
+        full_v, full_g = leaf(pts)
+        sv, sg = ShardedSDF(leaf)(pts)
+        ok = torch.equal(sv, full_v) and torch.equal(sg.nan_to_num(7.), full_g.nan_to_num(7.))
+        # batched point dims come back in their original shape
+        if P % 7 == 0:
+            bv, bg = ShardedSDF(leaf)(pts.reshape(7, P // 7, 3))
+            ok = ok and bv.shape == (7, P // 7) and torch.equal(bv.reshape(-1), full_v)
+        # configuration batch: (A, P) outputs gathered along the point axis
+        robot = OracleRobot(A=4)
+        rv, rg = robot(pts)
+        srv, srg = ShardedSDF(robot)(pts)
+        ok = ok and srv.shape == (4, P) and torch.equal(srv, rv) and torch.equal(srg.nan_to_num(7.), rg.nan_to_num(7.))
+        # gather=False: the local slice only
+        lv, lg, (a, b) = ShardedSDF(leaf, gather=False)(pts)
+        ok = ok and (a, b) == shard_range(P, world, rank)[:2] and torch.equal(lv, full_v[a:b])
+        # chamfer partial sums: all-reduce of B float64 + the global point count
+        sums = torch.tensor([float(rank + 1), 2.0], dtype=torch.float64)
+        dist.all_reduce(sums)
+        ok = ok and sums.tolist() == [3.0, 4.0]
+        results[rank] = bool(ok)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("P", [1001, 14, 1])
+def test_sharded_query_equals_unsharded_world2(P):
+    world = 2
+    port = free_port()
+    mgr = mp.Manager()
+    results = mgr.dict()
+    mp.spawn(worker, args=(world, port, P, results), nprocs=world, join=True)
+    assert dict(results) == {0: True, 1: True}
+
+
+def test_shard_range_covers_everything_exactly_once():
+    for P in (0, 1, 7, 8, 1000, 1001):
+        for W in (1, 2, 3, 8):
+            spans = [shard_range(P, W, r) for r in range(W)]
+            covered = sum(b - a for a, b, _ in spans)
+            assert covered == P
+            assert all(spans[i][1] == spans[i + 1][0] or spans[i + 1][0] == P for i in range(W - 1))
+            assert all(b - a <= c for a, b, c in spans)

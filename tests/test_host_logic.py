@@ -1,0 +1,190 @@
+"""CPU: host-side logic that needs no GPU -- grid helpers vs vectors from the reference's own code, dtype rules of the
+value-range view, transforms, kinematics, mesh loading, transform bookkeeping of ComposedSDF, pose-set reductions."""
+import math
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import pytorch_volumetric_amd as pv
+from pytorch_volumetric_amd import kinematics, mesh_io
+from pytorch_volumetric_amd import transforms as tf
+from pytorch_volumetric_amd.voxel import RangeView
+from tests import helpers as H
+
+G = np.load(os.path.join(H.GOLDEN, "reference_lifted.npz"))
+
+
+@pytest.mark.parametrize("case", ["drill_c2", "drill_fine", "readme_slice", "pyfloat"])
+def test_grid_helpers_match_the_reference_bitwise(case):
+    res = float(G[f"grid/{case}/resolution"])
+    rng = G[f"grid/{case}/range_in"]
+    rng = rng if case != "pyfloat" else [(float(a), float(b)) for a, b in rng]
+    snapped = pv.get_divisible_range_by_resolution(res, rng)
+    assert np.array_equal(np.array(snapped, dtype=np.float64), G[f"grid/{case}/range_snapped"])
+    coords, pts = pv.get_coordinates_and_points_in_grid(res, snapped)
+    assert [len(c) for c in coords] == list(G[f"grid/{case}/shape"])
+    for d, c in enumerate(coords):
+        assert np.array_equal(c.numpy(), G[f"grid/{case}/coords{d}"])
+    assert np.array_equal(pts[:64].numpy(), G[f"grid/{case}/points_head"])
+    assert np.array_equal(pts[-64:].numpy(), G[f"grid/{case}/points_tail"])
+
+
+def test_named_grid_sizes():
+    assert list(G["grid/drill_c2/shape"]) == [37, 33, 40]            # BASELINE C2: 48,840 voxels
+    assert list(G["grid/drill_fine/shape"]) == [92, 73, 105]         # tests/test_sdf.py:46
+    assert int(np.prod(G["grid/readme_slice/shape"])) == 15251       # README.md:195 M=15251
+
+
+def test_sphere_sdf_aabb_corners_is_inside_and_diversity_match_the_reference():
+    s = pv.SphereSDF(float(G["sphere/radius"]))
+    v, g = s(torch.from_numpy(G["sphere/points"]))
+    assert np.array_equal(v.numpy(), G["sphere/val"]) and np.array_equal(g.numpy(), G["sphere/grad"])
+    assert np.array_equal(s.surface_bounding_box(padding=0.1, padding_ratio=0.2).numpy(), G["sphere/bbox_pad"])
+    assert np.array_equal(s.outside_surface(torch.from_numpy(G["sphere/points"]), 0.05).numpy(), G["sphere/outside"])
+    assert np.array_equal(pv.aabb_to_ordered_end_points(G["aabb/in"]), G["aabb/corners"])
+    assert np.array_equal(pv.aabb_to_ordered_end_points(G["aabb/in"], arrange_in_sequential_order=True),
+                          G["aabb/sequential"])
+    t = pv.aabb_to_ordered_end_points(torch.from_numpy(G["aabb/in"]))
+    assert torch.is_tensor(t) and np.array_equal(t.numpy(), G["aabb/corners"])
+    assert np.array_equal(pv.is_inside(torch.from_numpy(G["inside/points"]), torch.from_numpy(G["inside/range"])).numpy(),
+                          G["inside/result"])
+    r = pv.PlausibleDiversity.do_evaluate_plausible_diversity_on_pairwise_chamfer_dist(torch.from_numpy(G["pd/errors"]))
+    assert np.array_equal(r.plausibility.numpy(), G["pd/plausibility"])
+    assert np.array_equal(r.coverage.numpy(), G["pd/coverage"])
+    assert np.array_equal(r.most_plausible_per_estimated.indices.numpy(), G["pd/argmin_rows"])
+    assert np.array_equal(r.most_covered_per_plausible.indices.numpy(), G["pd/argmin_cols"])
+
+
+def test_range_view_follows_torch_promotion():
+    numpy_range = np.array([[-0.6, 0.6], [-0.5, 0.5], [-0.45, 0.55]])
+    v64 = RangeView([(a, b) for a, b in numpy_range], (25, 21, 21))
+    assert v64.index_f64 and v64.min.dtype == torch.float64
+    v32 = RangeView([(-0.6, 0.6), (-0.5, 0.5), (-0.45, 0.55)], (25, 21, 21))
+    assert not v32.index_f64 and v32.resolution.dtype == torch.float32
+    # float32 resolution is computed in float32 from float32 bounds, like (max - min) / (shape - 1) in torch
+    expect = (torch.tensor([0.6, 0.5, 0.55]) - torch.tensor([-0.6, -0.5, -0.45])) / (torch.tensor([25, 21, 21]) - 1)
+    assert torch.equal(v32.fres, expect)
+    v_np32 = RangeView([(np.float32(-1), np.float32(1))] * 3, (3, 3, 3))
+    assert not v_np32.index_f64
+
+
+def test_transform3d_members():
+    g = torch.Generator().manual_seed(0)
+    m = H.random_rigid(5, seed=0)
+    t = pv.Transform3d(matrix=m)
+    assert len(t) == 5 and len(t[1:3]) == 2 and t.get_matrix().shape == (5, 4, 4)
+    assert torch.allclose(t.compose(t.inverse()).get_matrix(), torch.eye(4).expand(5, 4, 4), atol=1e-6)
+    p = torch.rand(7, 3, generator=g)
+    out = t.transform_points(p)
+    assert out.shape == (5, 7, 3)
+    assert torch.allclose(out[2], p @ m[2, :3, :3].T + m[2, :3, 3], atol=1e-6)
+    assert pv.Transform3d(matrix=m[0]).transform_points(p).shape == (7, 3)  # single transform keeps (N,3)
+    n = t.transform_normals(p)
+    assert torch.allclose(n[3], p @ m[3, :3, :3].T, atol=1e-6)
+    st = pv.Translate(0.1, 0, 0).stack(pv.Translate(-0.2, 0, 0.2))
+    assert len(st) == 2 and torch.allclose(st.get_matrix()[1, :3, 3], torch.tensor([-0.2, 0.0, 0.2]))
+    q = torch.tensor([math.cos(0.3), 0.0, 0.0, math.sin(0.3)])  # wxyz, rotation about z by 0.6
+    r = tf.quaternion_to_matrix(q)
+    assert torch.allclose(r, tf.axis_angle_to_matrix([0.0, 0.0, 1.0], torch.tensor(0.6)), atol=1e-6)
+    assert torch.allclose(tf.rpy_to_matrix((0, 0, 0.6)).float(), r, atol=1e-6)
+
+
+def test_kinematics_planar_two_link_known_answer():
+    urdf = """<robot name="p"><link name="a"/><link name="b"/><link name="c"/>
+    <joint name="j1" type="revolute"><parent link="a"/><child link="b"/><origin xyz="0 0 0"/><axis xyz="0 0 1"/></joint>
+    <joint name="j2" type="revolute"><parent link="b"/><child link="c"/><origin xyz="1 0 0"/><axis xyz="0 0 1"/></joint>
+    </robot>"""
+    chain = kinematics.build_serial_chain_from_urdf(urdf, "c")
+    assert chain.get_joint_parameter_names() == ["j1", "j2"]
+    assert chain.get_frame_names(exclude_fixed=False) == ["a", "b", "c"]
+    q = torch.tensor([[0.3, 0.4], [math.pi / 2, 0.0]])
+    fk = chain.forward_kinematics(q)
+    c = fk["c"].get_matrix()
+    assert torch.allclose(c[0, :3, 3], torch.tensor([math.cos(0.3), math.sin(0.3), 0.0]), atol=1e-6)
+    assert torch.allclose(c[0, :2, :2], torch.tensor([[math.cos(0.7), -math.sin(0.7)], [math.sin(0.7), math.cos(0.7)]]),
+                          atol=1e-6)
+    assert torch.allclose(c[1, :3, 3], torch.tensor([0.0, 1.0, 0.0]), atol=1e-6)
+
+
+def test_wrench_urdf_fixture_parses():
+    chain = kinematics.build_chain_from_urdf(open(H.mesh_path("offset_wrench.urdf")).read())
+    assert len(chain.get_joint_parameter_names()) == 6
+    vis = chain.find_frame("offset_wrench").link.visuals
+    assert len(vis) == 1 and vis[0].geom_type == "mesh" and vis[0].geom_param[0] == "offset_wrench_nogrip.obj"
+    fk = chain.forward_kinematics(torch.tensor([0.1, 0.2, 0.3, 0.0, 0.0, 0.0]))
+    assert torch.allclose(fk["offset_wrench"].get_matrix()[0, :3, 3], torch.tensor([0.1, 0.2, 0.3]), atol=1e-6)
+
+
+def test_mesh_fixtures_are_the_meshes_the_survey_measured():
+    """vertex & face counts, closedness, outward orientation."""
+    for name, V, F, closed in (("probe.obj", 171, 338, True), ("offset_wrench_nogrip.obj", 636, 1263, False),
+                               ("box_template.obj", 8, 12, True), ("ycb_power_drill.npz", 7866, 15728, True)):
+        m = mesh_io.load_mesh(H.mesh_path(name))
+        assert m.vertices.shape == (V, 3) and m.faces.shape == (F, 3)
+        e = np.sort(np.concatenate([m.faces[:, [0, 1]], m.faces[:, [1, 2]], m.faces[:, [2, 0]]]), axis=1)
+        _, counts = np.unique(e, axis=0, return_counts=True)
+        assert (counts == 2).all() == closed
+        t = m.triangle_soup()
+        assert np.einsum("ij,ij->i", t[:, 0], np.cross(t[:, 1], t[:, 2])).sum() > 0
+    lo, hi = mesh_io.load_mesh(H.mesh_path("ycb_power_drill.npz")).aabb()
+    assert np.allclose(lo, H.DRILL_BB[:, 0]) and np.allclose(hi, H.DRILL_BB[:, 1])
+
+
+def test_obj_stl_round_trip_and_polygon_triangulation(tmp_path):
+    m = mesh_io.uv_sphere_mesh(0.3, 8, 4)
+    p = str(tmp_path / "s.obj")
+    mesh_io.save_obj(p, m)
+    m2 = mesh_io.load_mesh(p)
+    assert np.allclose(m2.vertices, m.vertices, atol=1e-8) and np.array_equal(m2.faces, m.faces)
+    quad = "v 0 0 0\nv 1 0 0\nv 1 1 0\nv 0 1 0\nf 1/1/1 2/2/2 3/3/3 4/4/4\nf -4 -3 -2\n"
+    qp = tmp_path / "q.obj"
+    qp.write_text(quad)
+    mq = mesh_io.load_mesh(str(qp))
+    assert mq.faces.tolist() == [[0, 1, 2], [0, 2, 3], [0, 1, 2]]
+    with pytest.raises(RuntimeError):
+        pv.MeshObjectFactory("does_not_exist.obj")  # sdf.py:102
+
+
+def test_factory_frame_ops_and_pickle_round_trip():
+    import pickle
+    obj = pv.MeshObjectFactory(H.mesh_path("box_template.obj"), scale=0.5, vis_frame_pos=(1.0, 0.0, 0.0),
+                               vis_frame_rot=(0.0, 0.0, math.sin(math.pi / 4), math.cos(math.pi / 4)))
+    assert np.allclose(obj.bounding_box(), [[0.0, 1.0], [-0.5, 0.5], [-0.5, 0.5]], atol=1e-12)
+    assert np.allclose(obj.bounding_box(padding=0.1, padding_ratio=0.5), [[-0.6, 1.6], [-1.1, 1.1], [-1.1, 1.1]])
+    obj2 = pickle.loads(pickle.dumps(obj))
+    assert np.array_equal(obj2.bounding_box(), obj.bounding_box()) and obj2.num_faces == 12
+    assert np.allclose(np.linalg.norm(obj._face_normals, axis=1), 1.0)
+    assert pv.MeshSDF(obj).surface_bounding_box(padding=0.1).shape == (3, 2)
+
+
+def test_composed_transform_bookkeeping_without_gpu():
+    leaves = [pv.SphereSDF(0.1), pv.SphereSDF(0.2)]
+    m = H.random_rigid(6, seed=3)
+    comp = pv.ComposedSDF(leaves, pv.Transform3d(matrix=m[:2]))
+    assert comp.tsf_batch is None and comp.ith_transform_slice(1) == slice(1, 2)
+    comp.set_transforms(pv.Transform3d(matrix=m))  # inferred integer batch (the reference computes a float here)
+    assert comp.tsf_batch == (3,) and comp.ith_transform_slice(1) == slice(3, 6)
+    comp.set_transforms(m, batch_dim=(3,))  # raw tensor accepted
+    assert torch.allclose(comp.link_frame_to_obj_frame[1].get_matrix() @ m[3:6], torch.eye(4).expand(3, 4, 4), atol=1e-6)
+    with pytest.raises(ValueError):
+        comp.set_transforms(m[:5])
+    bb = comp.surface_bounding_box()
+    assert bb.shape == (3, 3, 2)
+    with pytest.raises(ValueError):
+        pv.batch_chamfer_dist(torch.eye(4)[None], torch.zeros(3, 3)) if torch.cuda.is_available() else (_ for _ in ()).throw(ValueError())
+
+
+def test_sample_mesh_points_is_seeded_and_on_the_surface(tmp_path):
+    obj = pv.MeshObjectFactory(H.mesh_path("box_template.obj"))
+    db = str(tmp_path / "pts.pkl")
+    p1, n1, cache = pv.sample_mesh_points(obj, num_points=300, seed=4, name="box", dbpath=db)
+    p2, n2, _ = pv.sample_mesh_points(obj, num_points=300, seed=4, name="box", dbpath=None)
+    assert torch.equal(p1, p2) and p1.shape == (300, 3) and n1.shape == (300, 3)
+    assert torch.allclose(p1.abs().max(dim=1).values, torch.ones(300), atol=1e-6)  # on the cube surface
+    assert torch.allclose((p1 * n1).sum(-1), torch.ones(300), atol=1e-6)
+    p3, _, _ = pv.sample_mesh_points(None, num_points=300, seed=4, name="box", dbpath=db)  # served from the cache file
+    assert torch.equal(p3, p1)
+    with pytest.raises(RuntimeError):
+        pv.sample_mesh_points(None, num_points=7, seed=4, name="box", dbpath=db)

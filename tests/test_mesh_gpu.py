@@ -65,9 +65,9 @@ def test_cube_closed_form():
     # gradient: unit length, equals the closed-form normal away from edges/medial axis
     far = (ref.abs() > 1e-2)
     assert torch.allclose(grad.cpu()[far].norm(dim=-1), torch.ones(int(far.sum())), atol=1e-5)
-    face_region = ((q > 0).sum(dim=-1) == 1) & far
+    face_region = ((q > 0).sum(dim=-1) == 1) & far & (q.sort(dim=-1).values[:, 1] < -1e-2)  # away from fp32 edge ties
     expect = torch.sign(pts) * (q > 0).float()
-    assert torch.allclose(grad.cpu()[face_region], expect[face_region], atol=1e-5)
+    assert ((grad.cpu()[face_region] - expect[face_region]).abs().amax(dim=-1).double() < 3e-6 / ref[face_region].abs()).all()
 
 
 @pytest.mark.parametrize("mesh", ["probe.obj", "offset_wrench_nogrip.obj"])
