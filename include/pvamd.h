@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define PVAMD_ABI_VERSION 1
+#define PVAMD_ABI_VERSION 2
 
 #define PVAMD_E_NULL      (-1)  /* a required pointer is NULL            */
 #define PVAMD_E_SHAPE     (-2)  /* a size/shape argument is out of range */
@@ -61,7 +61,12 @@ typedef struct pvamd_grid {
     int32_t      shape[3];   /* nx, ny, nz (each >= 2)                                             */
     int32_t      index_f64;  /* see above                                                          */
     int32_t      oob_mode;   /* PVAMD_OOB_*                                                        */
-    int32_t      reserved;
+    int32_t      finalized;  /* set by pvamd_grid_finalize(); kernels refuse descriptors without it */
+    /* ---- derived by pvamd_grid_finalize() from the fields above; callers do not fill these ---- */
+    float        vlo[3];     /* smallest float32 p with min <= p in the index dtype (exact range test in fp32)  */
+    float        vhi[3];     /* largest  float32 p with p <= max                                             */
+    float        inv32[3];   /* float32(1/res): the multiply-first index estimate, checked against a rounding */
+    float        err32[3];   /* bound and redone with the exact IEEE division when it is within it            */
 } pvamd_grid_t;
 
 /*
@@ -84,6 +89,10 @@ int         pvamd_abi_version(void);
 const char* pvamd_build_info(void);      /* static string: arch, compiler, build flags */
 /* number of devices visible / name of device 0 -- lets a host language check the GPU without a HIP binding */
 int         pvamd_device_count(void);
+
+/* Host-side, pure: fill the derived fields of a descriptor (vlo/vhi/inv32/err32, finalized) from its primary
+ * fields.  Must be called once after the primary fields are set and before the descriptor is used or uploaded.   */
+int pvamd_grid_finalize(pvamd_grid_t* grid);
 
 /* Build the packed voxel layout on device: out[i] = (val[i], grad[i][0..2]).  Replaces nothing in the
  * reference (layout choice); feeds every grid entry point.  val: device [n], grad: device [n][3], out: device [n][4]. */

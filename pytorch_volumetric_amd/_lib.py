@@ -11,7 +11,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libpvamd.so")
 
-ABI_VERSION = 1
+ABI_VERSION = 2
 OOB_LOOKUP_GT_SDF = 0
 OOB_BOUNDING_BOX = 1
 
@@ -33,7 +33,11 @@ class GridDesc(ctypes.Structure):
         ("shape", ctypes.c_int32 * 3),
         ("index_f64", ctypes.c_int32),
         ("oob_mode", ctypes.c_int32),
-        ("reserved", ctypes.c_int32),
+        ("finalized", ctypes.c_int32),
+        ("vlo", ctypes.c_float * 3),
+        ("vhi", ctypes.c_float * 3),
+        ("inv32", ctypes.c_float * 3),
+        ("err32", ctypes.c_float * 3),
     ]
 
 
@@ -54,6 +58,7 @@ SIGNATURES = {
     "pvamd_abi_version": (ctypes.c_int, []),
     "pvamd_build_info": (ctypes.c_char_p, []),
     "pvamd_device_count": (ctypes.c_int, []),
+    "pvamd_grid_finalize": (ctypes.c_int, [ctypes.POINTER(GridDesc)]),
     "pvamd_pack_grid": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p,
                                        ctypes.c_void_p]),
     "pvamd_cached_query": (ctypes.c_int, [ctypes.POINTER(GridDesc), ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p,

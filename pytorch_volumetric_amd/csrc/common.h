@@ -43,6 +43,7 @@ static inline int check_grid(const pvamd_grid_t& g, bool need_vox = true) {
     }
     if ((int64_t)g.shape[0] * g.shape[1] * g.shape[2] > (int64_t)INT32_MAX) return PVAMD_E_SHAPE;
     if (g.oob_mode != PVAMD_OOB_LOOKUP_GT_SDF && g.oob_mode != PVAMD_OOB_BOUNDING_BOX) return PVAMD_E_MODE;
+    if (!g.finalized) return PVAMD_E_MODE;  // pvamd_grid_finalize() was not called
     return 0;
 }
 

@@ -14,6 +14,7 @@ namespace pvamd {
 struct Best {
     float v, gx, gy, gz;  // gradient kept in the winning leaf's frame until the end
     int s;
+    bool unnormalised;    // (gx,gy,gz) is the bounding-box vector t; the gradient t/v is formed only for the winner
 };
 
 template <bool ANY_F64>
@@ -22,26 +23,41 @@ PVAMD_DEV void visit_leaf(const pvamd_grid_t& g, const float* __restrict__ M, in
     const float x = affine_row(M[0], M[1], M[2], M[3], px, py, pz);
     const float y = affine_row(M[4], M[5], M[6], M[7], px, py, pz);
     const float z = affine_row(M[8], M[9], M[10], M[11], px, py, pz);
-    bool valid;
-    float4 r;
-    if (ANY_F64 && g.index_f64) r = cached_lookup<true>(g, x, y, z, valid);
-    else r = cached_lookup<false>(g, x, y, z, valid);
+    float v, a, b, c;
+    const bool valid = in_range(g, x, y, z);
+    if (valid) {
+        const int flat = (ANY_F64 && g.index_f64) ? voxel_flat_in_range<true>(g, x, y, z)
+                                                  : voxel_flat_in_range<false>(g, x, y, z);
+        const float4 r = reinterpret_cast<const float4*>(g.vox)[flat];
+        v = r.x; a = r.y; b = r.z; c = r.w;
+    } else {
+        float t[3];
+        v = bounding_box_vector(g, x, y, z, t);  // out-of-range leaves cost no division unless they win
+        a = t[0]; b = t[1]; c = t[2];
+    }
     // torch.argmin semantics (sdf.py:421): first minimum wins, NaN counts as the minimum
-    const bool take = (best.s < 0) || (r.x < best.v) || (r.x != r.x && best.v == best.v);
+    const bool take = (best.s < 0) || (v < best.v) || (v != v && best.v == best.v);
     if (take) {
-        best.v = r.x;
-        best.gx = r.y;
-        best.gy = r.z;
-        best.gz = r.w;
+        best.v = v;
+        best.gx = a;
+        best.gy = b;
+        best.gz = c;
         best.s = s;
+        best.unnormalised = !valid;
     }
 }
 
 // g_obj = R^T g_leaf with R the obj->leaf rotation (sdf.py:409 transform_normals by the inverse transform)
 PVAMD_DEV void rotate_back(const float* __restrict__ M, const Best& b, float& ox, float& oy, float& oz) {
-    ox = fmaf(M[8], b.gz, fmaf(M[4], b.gy, mul_rn(M[0], b.gx)));
-    oy = fmaf(M[9], b.gz, fmaf(M[5], b.gy, mul_rn(M[1], b.gx)));
-    oz = fmaf(M[10], b.gz, fmaf(M[6], b.gy, mul_rn(M[2], b.gx)));
+    float gx = b.gx, gy = b.gy, gz = b.gz;
+    if (b.unnormalised) {  // sdf.py:570 grad = dtotal / dist
+        gx = div_rn(gx, b.v);
+        gy = div_rn(gy, b.v);
+        gz = div_rn(gz, b.v);
+    }
+    ox = fmaf(M[8], gz, fmaf(M[4], gy, mul_rn(M[0], gx)));
+    oy = fmaf(M[9], gz, fmaf(M[5], gy, mul_rn(M[1], gx)));
+    oz = fmaf(M[10], gz, fmaf(M[6], gy, mul_rn(M[2], gx)));
 }
 
 // One wave = 256 consecutive points of one configuration per pass; all global traffic in contiguous 1 KB pieces
@@ -78,7 +94,7 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void composed_query_wave(const
             px[k] = spf[3 * p];
             py[k] = spf[3 * p + 1];
             pz[k] = spf[3 * p + 2];
-            best[k] = Best{0.f, 0.f, 0.f, 0.f, -1};
+            best[k] = Best{0.f, 0.f, 0.f, 0.f, -1, false};
         }
         PVAMD_WAVE_SYNC();
         for (int s = 0; s < S; ++s) {
@@ -121,7 +137,7 @@ __global__ __launch_bounds__(256) void composed_query_scalar(const pvamd_grid_t*
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     for (int64_t i = first + (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < P; i += stride) {
         const float px = pts[3 * i], py = pts[3 * i + 1], pz = pts[3 * i + 2];
-        Best best{0.f, 0.f, 0.f, 0.f, -1};
+        Best best{0.f, 0.f, 0.f, 0.f, -1, false};
         for (int s = 0; s < S; ++s) {
             visit_leaf<ANY_F64>(grids[s], tf + 16 * ((int64_t)s * A + a), s, px, py, pz, best);
         }

@@ -53,12 +53,43 @@ PVAMD_DEV bool voxel_flat(const pvamd_grid_t& g, float x, float y, float z, int&
     return valid;
 }
 
+// ---- fast path used by the query kernels (bit-identical to the exact statements above) ----
+// Range test in fp32: for a float32 p, "min <= p <= max" in the index dtype is equivalent to vlo <= p <= vhi with the
+// bounds rounded inward to float32 by pvamd_grid_finalize().
+PVAMD_DEV bool in_range(const pvamd_grid_t& g, float x, float y, float z) {
+    return (g.vlo[0] <= x) & (x <= g.vhi[0]) & (g.vlo[1] <= y) & (y <= g.vhi[1]) & (g.vlo[2] <= z) & (z <= g.vhi[2]);
+}
+
+// Index of an in-range coordinate: multiply-first estimate in fp32; unless it lies within its rounding bound of a
+// half-integer (where the estimate and the reference's quotient could round differently) it IS the reference index.
+// Otherwise -- a few points per million -- the exact IEEE division of voxel_index_1d is redone.
+template <bool F64>
+PVAMD_DEV int voxel_index_fast(const pvamd_grid_t& g, int d, float p) {
+    const float t = mul_rn(sub_rn(p, g.fmin[d]), g.inv32[d]);
+    const float kc = __builtin_rintf(t);
+    const float half_dist = sub_rn(0.5f, fabsf(sub_rn(t, kc)));
+    const float bound = fmaf(g.err32[d], add_rn(fabsf(p), 1.f), mul_rn(2.5e-7f, fabsf(t)));
+    if (half_dist > bound) return (int)kc;  // NaN-safe: any NaN fails the comparison and takes the exact path
+    long long k;
+    voxel_index_1d<F64>(g, d, p, k);
+    return (int)k;
+}
+
+template <bool F64>
+PVAMD_DEV int voxel_flat_in_range(const pvamd_grid_t& g, float x, float y, float z) {
+    int kx = voxel_index_fast<F64>(g, 0, x), ky = voxel_index_fast<F64>(g, 1, y), kz = voxel_index_fast<F64>(g, 2, z);
+    kx = min(max(kx, 0), g.shape[0] - 1);  // no-ops for a well-formed descriptor; keep the gather in bounds regardless
+    ky = min(max(ky, 0), g.shape[1] - 1);
+    kz = min(max(kz, 0), g.shape[2] - 1);
+    return (kx * g.shape[1] + ky) * g.shape[2] + kz;
+}
+
 // BOUNDING_BOX fallback (sdf.py:559-571): per component dmin = max(bbmin - p, 0), dmax = max(p - bbmax, 0),
 // t = dmin + dmax, negated where dmin > 0; val = |t|, grad = t / |t|  (0/0 = NaN when the point is inside
-// the box, exactly as the reference).
-PVAMD_DEV float4 bounding_box_sdf(const pvamd_grid_t& g, float x, float y, float z) {
+// the box, exactly as the reference).  Returns |t| and leaves the UNNORMALISED vector in t[] so that callers that
+// only need the gradient of a winning leaf can defer the three divisions.
+PVAMD_DEV float bounding_box_vector(const pvamd_grid_t& g, float x, float y, float z, float t[3]) {
     const float p[3] = {x, y, z};
-    float t[3];
 #pragma unroll
     for (int d = 0; d < 3; ++d) {
         float lo = sub_rn(g.bb_min[d], p[d]);
@@ -69,18 +100,21 @@ PVAMD_DEV float4 bounding_box_sdf(const pvamd_grid_t& g, float x, float y, float
         const float s = add_rn(lo, hi);
         t[d] = lo_active ? -s : s;
     }
-    const float n2 = fmaf(t[2], t[2], fmaf(t[1], t[1], mul_rn(t[0], t[0])));
-    const float n = sqrt_rn(n2);
+    return sqrt_rn(fmaf(t[2], t[2], fmaf(t[1], t[1], mul_rn(t[0], t[0]))));
+}
+
+PVAMD_DEV float4 bounding_box_sdf(const pvamd_grid_t& g, float x, float y, float z) {
+    float t[3];
+    const float n = bounding_box_vector(g, x, y, z, t);
     return make_float4(n, div_rn(t[0], n), div_rn(t[1], n), div_rn(t[2], n));
 }
 
 // (val, gx, gy, gz) for one point in the leaf frame; `valid` reports the range test.
 template <bool F64>
 PVAMD_DEV float4 cached_lookup(const pvamd_grid_t& g, float x, float y, float z, bool& valid) {
-    int flat;
-    valid = voxel_flat<F64>(g, x, y, z, flat);
+    valid = in_range(g, x, y, z);
     if (valid) {
-        return reinterpret_cast<const float4*>(g.vox)[flat];
+        return reinterpret_cast<const float4*>(g.vox)[voxel_flat_in_range<F64>(g, x, y, z)];
     }
     if (g.oob_mode == PVAMD_OOB_BOUNDING_BOX) {
         return bounding_box_sdf(g, x, y, z);

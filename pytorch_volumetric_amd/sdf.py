@@ -372,6 +372,7 @@ class CachedSDF(ObjectFrameSDF):
             desc.bb_min[d], desc.bb_max[d] = bb[d, 0].item(), bb[d, 1].item()
         mode = self.out_of_bounds_strategy if oob_mode is None else oob_mode
         desc.oob_mode = _lib.OOB_BOUNDING_BOX if mode == OutOfBoundsStrategy.BOUNDING_BOX else _lib.OOB_LOOKUP_GT_SDF
+        _lib.check(_lib.load().pvamd_grid_finalize(ctypes.byref(desc)), "pvamd_grid_finalize")
         return desc
 
     def __call__(self, points_in_object_frame):

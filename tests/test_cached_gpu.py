@@ -198,3 +198,35 @@ def test_full_size_c2_properties():
     oval, ograd, _ = oracle.cached_query(og, pts[:100_000].cpu().numpy())
     assert np.array_equal(v1[:100_000].cpu().numpy(), oval, equal_nan=True)
     assert np.array_equal(g1[:100_000].cpu().numpy(), ograd, equal_nan=True)
+
+
+@pytest.mark.parametrize("f64", [True, False])
+def test_index_fast_path_agrees_with_exact_division_at_rounding_boundaries(f64):
+    """The query kernels estimate the index with a multiply and fall back to the reference's exact division only near
+    half-voxel planes.  Hammer those planes: values must still match the oracle (which always divides) bit for bit."""
+    c = make_cached(f64=f64)
+    og = H.oracle_grid_from_cached(c)
+    v = c._view
+    mn = (v.dmin if f64 else v.fmin).double().numpy()
+    res = (v.dres if f64 else v.fres).double().numpy()
+    rng = np.random.default_rng(0)
+    n = 400_000
+    k = rng.integers(0, np.array(v.shape) - 1, size=(n, 3))
+    # exactly on, and within a few float32 ulps of, the half-voxel planes (in all three coordinates at once)
+    ulps = rng.integers(-6, 7, size=(n, 3))
+    base = (mn[None, :] + (k + 0.5) * res[None, :]).astype(np.float32)
+    pts = base.copy()
+    for _ in range(6):
+        up = np.nextafter(pts, np.float32(np.inf))
+        dn = np.nextafter(pts, np.float32(-np.inf))
+        pts = np.where(ulps > 0, up, np.where(ulps < 0, dn, pts))
+        ulps = ulps - np.sign(ulps)
+    val, grad = c(torch.from_numpy(pts).cuda())
+    oval, ograd, ooob = oracle.cached_query(og, pts)
+    assert not ooob.any()
+    assert np.array_equal(val.cpu().numpy(), oval) and np.array_equal(grad.cpu().numpy(), ograd)
+    key = c.voxels.ensure_index_key(torch.from_numpy(pts).cuda()).cpu().numpy()
+    okey, _, _ = oracle.voxel_index(og, pts)
+    assert np.array_equal(key, okey)
+    # the sample really straddles the rounding boundary: both neighbours occur
+    assert ((okey == k).any() and (okey == k + 1).any())

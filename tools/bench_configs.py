@@ -1,0 +1,160 @@
+#!/usr/bin/env python
+"""Secondary benchmark: every BASELINE.json config (C1..C5) once, on one GPU, with its own roofline denominator and a
+bounded CPU-oracle timing beside it.  bench.py stays the contract benchmark (C2); this script feeds BASELINE.md section 4.
+Usage (GPU box, repo root):  python tools/bench_configs.py [--quick] > gpurun_out/configs.json
+"""
+import argparse
+import json
+import os
+import sys
+import tempfile
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+import numpy as np
+import torch
+
+import pytorch_volumetric_amd as pv
+from oracle import oracle
+from pytorch_volumetric_amd import mesh_io
+from tests import helpers as H
+
+HBM_PEAK = 8000.0      # GB/s
+FP32_PEAK = 157.3      # TFLOP/s vector
+FLOP_PER_PAIR_CLOSEST = 80.0   # Ericson closest point
+FLOP_PER_PAIR_QUERY = 120.0    # + ray-parity test
+
+
+def gpu_time(fn, warm=3, reps=10):
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    ts = []
+    for _ in range(reps):
+        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        s.record()
+        fn()
+        e.record()
+        torch.cuda.synchronize()
+        ts.append(s.elapsed_time(e) * 1e-3)
+    return float(np.median(ts)), float(np.min(ts))
+
+
+def cpu_time(fn, budget=3.0):
+    fn()
+    n, t0 = 0, time.perf_counter()
+    while True:
+        fn()
+        n += 1
+        dt = time.perf_counter() - t0
+        if dt > budget:
+            return dt / n
+
+
+def synthetic_arm(tmp, n_links=8):
+    for i in range(n_links):
+        m = mesh_io.uv_sphere_mesh(1.0, 24, 12, scale=(0.06, 0.06, 0.11), center=(0, 0, 0.09))
+        mesh_io.save_obj(os.path.join(tmp, f"link_{i}.obj"), m)
+    axes = ["0 0 1", "0 1 0", "0 0 1", "0 -1 0", "0 0 1", "0 1 0", "0 0 1"]
+    parts = ['<robot name="arm7">']
+    for i in range(n_links):
+        parts.append(f'<link name="link_{i}"><visual><origin xyz="0 0 0" rpy="0 0 0"/><geometry>'
+                     f'<mesh filename="link_{i}.obj"/></geometry></visual></link>')
+    for i in range(n_links - 1):
+        parts.append(f'<joint name="j{i}" type="revolute"><parent link="link_{i}"/><child link="link_{i + 1}"/>'
+                     f'<origin xyz="0 0 0.18" rpy="0 0 0"/><axis xyz="{axes[i]}"/></joint>')
+    parts.append('</robot>')
+    return pv.build_serial_chain_from_urdf("\n".join(parts), f"link_{n_links - 1}")
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--quick", action="store_true")
+    args = ap.parse_args()
+    torch.cuda.set_device(0)
+    out = {"host_cpus": os.cpu_count(), "oracle_threads": oracle.num_threads(), "device": torch.cuda.get_device_name(0)}
+
+    # ---------------- C1: MeshSDF, drill (15,728 tris), 10k grid points ----------------
+    obj = pv.MeshObjectFactory(H.mesh_path("ycb_power_drill.npz"))
+    _, grid_pts = pv.get_coordinates_and_points_in_grid(0.002, obj.bounding_box(0.01))
+    g = torch.Generator().manual_seed(0)
+    pts = grid_pts[torch.randperm(len(grid_pts), generator=g)[:10_000]].cuda()
+    sdf = pv.MeshSDF(obj)
+    t, tmin = gpu_time(lambda: sdf(pts))
+    om = H.oracle_mesh_from_factory(obj)
+    host_pts = pts.cpu().numpy()
+    tc = cpu_time(lambda: oracle.mesh_query(om, host_pts[:2000], seed=0))
+    pairs = 10_000 * obj.num_faces
+    out["C1_meshsdf_drill_10k"] = {
+        "points": 10_000, "triangles": obj.num_faces, "gpu_s": t, "gpu_points_per_s": 10_000 / t,
+        "gpu_pairs_per_s": pairs / t, "fp32_tflops_at_120flop": pairs * FLOP_PER_PAIR_QUERY / t / 1e12,
+        "frac_fp32_peak": pairs * FLOP_PER_PAIR_QUERY / t / 1e12 / FP32_PEAK,
+        "cpu_points_per_s": 2000 / tc, "cpu_note": f"brute-force oracle, {oracle.num_threads()} threads, 2000-point sample "
+                                                   "(NOT Embree: not the reference's CPU engine)"}
+
+    # cache build (8(f) rank 1): all voxel centres of the C2 grid through the mesh kernel
+    t0 = time.perf_counter()
+    cached = pv.CachedSDF("drill", 0.01, obj.bounding_box(padding=0.1), sdf, device="cuda", cache_path=None)
+    torch.cuda.synchronize()
+    out["cache_build_drill_0.01"] = {"voxels": int(np.prod(cached._view.shape)), "wall_s": time.perf_counter() - t0}
+
+    # ---------------- C3: ComposedSDF of 8 transformed drills, 4M points ----------------
+    S, P3 = 8, 1 << 22
+    tfm = H.random_rigid(S, seed=0)
+    comp = pv.ComposedSDF([cached] * S, pv.Transform3d(matrix=tfm))
+    pts3 = H.uniform_points(P3, [-0.5] * 3, [0.5] * 3, seed=0).cuda()
+    t, tmin = gpu_time(lambda: comp(pts3), reps=20)
+    og = H.oracle_grid_from_cached(cached)
+    hp = pts3[:400_000].cpu().numpy()
+    tc = cpu_time(lambda: oracle.composed_query([og] * S, tfm.numpy(), 1, hp))
+    out["C3_composed_8_drills_4M"] = {
+        "points": P3, "leaves": S, "gpu_s": t, "gpu_queries_per_s": P3 / t, "algorithmic_GBs": 28 * P3 / t / 1e9,
+        "frac_hbm_peak": 28 * P3 / t / 1e9 / HBM_PEAK, "includes": "python call + output allocation",
+        "cpu_queries_per_s": 400_000 / tc}
+
+    # ---------------- C4: RobotSDF, 7-DOF / 8 links, A=200 configs x 262,144 points ----------------
+    with tempfile.TemporaryDirectory() as tmp:
+        chain = synthetic_arm(tmp)
+        robot = pv.RobotSDF(chain, path_prefix=tmp,
+                            link_sdf_cls=pv.cache_link_sdf_factory(resolution=0.02, padding=0.1, device="cuda",
+                                                                   cache_path=None))
+    A, P4 = (50, 1 << 16) if args.quick else (200, 1 << 18)
+    th0 = torch.tensor([0.0, -np.pi / 4, 0.0, np.pi / 2, 0.0, np.pi / 4, 0.0])
+    gq = torch.Generator().manual_seed(0)
+    th = torch.cat((th0.view(1, -1), th0 + torch.randn(A - 1, 7, generator=gq) * 0.1))
+    t_cfg, _ = gpu_time(lambda: robot.set_joint_configuration(th), reps=5)
+    pts4 = H.uniform_points(P4, [-0.7, -0.7, -0.2], [0.7, 0.7, 1.5], seed=1).cuda()
+    t, tmin = gpu_time(lambda: robot(pts4), reps=10)
+    pairs4 = A * P4
+    out["C4_robot_8links"] = {
+        "configs": A, "points": P4, "gpu_s": t, "gpu_pairs_per_s": pairs4 / t, "algorithmic_GBs": 16 * pairs4 / t / 1e9,
+        "frac_hbm_peak": 16 * pairs4 / t / 1e9 / HBM_PEAK, "set_joint_configuration_s": t_cfg,
+        "link_grid_voxels": [int(np.prod(s._view.shape)) for s in robot.sdf.sdfs],
+        "note": "synthetic KUKA-like arm (KUKA assets unavailable offline); link caches res 0.02 pad 0.1"}
+
+    # ---------------- C5: chamfer, source points -> 99,500-triangle sphere mesh ----------------
+    m = mesh_io.uv_sphere_mesh(0.1, 250, 200)
+    sphere = pv.MeshObjectFactory(mesh=m)
+    N5 = (1 << 16) if args.quick else (1 << 21)
+    src = H.uniform_points(N5, [-0.15] * 3, [0.15] * 3, seed=2).cuda()
+    W = torch.eye(4).unsqueeze(0).cuda()
+    t, tmin = gpu_time(lambda: pv.batch_chamfer_dist(W, src, sphere, scale=1000.0), warm=1, reps=3)
+    err = pv.batch_chamfer_dist(W, src, sphere, scale=1.0)
+    ref = ((src.norm(dim=-1) - 0.1) ** 2).mean()
+    pairs5 = N5 * m.faces.shape[0]
+    osphere = H.oracle_mesh_from_factory(sphere)
+    hs = src[:512].cpu().numpy()
+    tc = cpu_time(lambda: oracle.chamfer_mesh(osphere, np.eye(4, dtype=np.float32)[None], hs, 1000.0))
+    out["C5_chamfer_sphere_99500"] = {
+        "points": N5, "triangles": int(m.faces.shape[0]), "gpu_s": t, "gpu_pairs_per_s": pairs5 / t,
+        "fp32_tflops_at_80flop": pairs5 * FLOP_PER_PAIR_CLOSEST / t / 1e12,
+        "frac_fp32_peak": pairs5 * FLOP_PER_PAIR_CLOSEST / t / 1e12 / FP32_PEAK,
+        "chamfer_vs_analytic_abs_err": abs(err.item() - ref.item()),
+        "cpu_pairs_per_s": 512 * m.faces.shape[0] / tc}
+    print(json.dumps(out, indent=1))
+
+
+if __name__ == "__main__":
+    main()

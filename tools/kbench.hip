@@ -221,6 +221,7 @@ int main(int argc, char** argv) {
     const int64_t P = argc > 1 ? atoll(argv[1]) : (1ll << 26);
     const float margin = argc > 2 ? atof(argv[2]) : 0.05f;
     const int rounds = argc > 3 ? atoi(argv[3]) : 5;
+    const int burst = argc > 4 ? atoi(argv[4]) : 1;  // launches per timed event pair (back-to-back, like a graph replay)
     // drill-like grid 37x33x40
     pvamd_grid_t g; memset(&g, 0, sizeof(g));
     const double lo[3] = {-0.167981, -0.141332, -0.103716}, res = 0.01; const int shape[3] = {37, 33, 40};
@@ -284,8 +285,8 @@ int main(int argc, char** argv) {
     CK(hipDeviceSynchronize());
     for (int r = 0; r < rounds; ++r)
         for (size_t k = 0; k < vs.size(); ++k) {
-            CK(hipEventRecord(e0, 0)); launch_fixed(vs[k].id); CK(hipEventRecord(e1, 0)); CK(hipEventSynchronize(e1));
-            float ms; CK(hipEventElapsedTime(&ms, e0, e1)); times[k].push_back(ms);
+            CK(hipEventRecord(e0, 0)); for (int b = 0; b < burst; ++b) launch_fixed(vs[k].id); CK(hipEventRecord(e1, 0)); CK(hipEventSynchronize(e1));
+            float ms; CK(hipEventElapsedTime(&ms, e0, e1)); times[k].push_back(ms / burst);
         }
     printf("P=%lld margin=%.3f rounds=%d  (GB/s = 28 B/pt algorithmic)\n", (long long)P, margin, rounds);
     for (size_t k = 0; k < vs.size(); ++k) {
