@@ -70,16 +70,24 @@ typedef struct pvamd_grid {
 } pvamd_grid_t;
 
 /*
- * One triangle mesh = the read-only state of an ObjectFactory after precompute_sdf (sdf.py:97-120).
- * tri:    device [F][3][3] fp32 triangle soup (vertex a, b, c of face f; already scaled / rotated / translated)
- * normal: device [F][3] fp32 unit face normals (sdf.py:119-120)
+ * One triangle mesh = the read-only state of an ObjectFactory after precompute_sdf (sdf.py:97-120), prepared for the
+ * kernels by pvamd_mesh_prepare().
+ * normal:  device [F][3] fp32 unit face normals (sdf.py:119-120), indexed by ORIGINAL face id
+ * rec:     device [F][PVAMD_TRI_REC] per-triangle records written by pvamd_mesh_prepare, in the (spatially sorted)
+ *          order the caller chose; each record carries its original face id
+ * tiles:   device [ceil(F/PVAMD_TRI_TILE)][4] bounding sphere (cx, cy, cz, r) of each run of PVAMD_TRI_TILE records
+ * rec_of_face: device [F] int32, position of the record of original face id f (inverse of the chosen order)
  * ray_dir: the reference passes bounding_box(padding=1.0)[:,1] as the last three floats of each ray
  *          (sdf.py:147-152); open3d reads those as the ray DIRECTION (tnear=0, tfar=inf).  Kept as float64
  *          because the reference adds its jitter in float64 before rounding to float32 (sdf.py:149-150).
  */
+#define PVAMD_TRI_REC  28   /* floats per prepared triangle record */
+#define PVAMD_TRI_TILE 256  /* triangles per LDS tile / per tile sphere */
 typedef struct pvamd_mesh {
-    const float* tri;        /* device */
     const float* normal;     /* device */
+    const float* rec;        /* device */
+    const float* tiles;      /* device */
+    const int32_t* rec_of_face; /* device */
     int32_t      F;
     int32_t      reserved;
     double       ray_dir[3];
@@ -124,22 +132,41 @@ int pvamd_composed_query(const pvamd_grid_t* grids, int32_t S, const float* tf, 
                          const float* points, int64_t P,
                          float* out_val, float* out_grad, int32_t* out_leaf, void* stream);
 
+/* Prepare a mesh for the query kernels: per-triangle records (corners, edge vectors, geometric normal for the ray
+ * test, bounding sphere, original face id) and one bounding sphere per run of PVAMD_TRI_TILE records.  The spheres only
+ * ever SKIP work that provably cannot change a result (they are inflated by abs_margin and a relative 1e-5), so query
+ * results are bit-identical to the untiled brute force whatever order the triangles are given in; spatially sorted
+ * input (e.g. Morton order of centroids) is what makes the skipping effective.
+ * tri: device [F][3][3] fp32 soup in the order to process.  face_id: device [F] int32 original ids, or NULL for 0..F-1.
+ * abs_margin: absolute slack, >= 1e-6 * (largest |vertex coordinate| + bounding-box diagonal).
+ * rec_out: device [F][PVAMD_TRI_REC] (16-byte aligned).  tiles_out: device [ceil(F/PVAMD_TRI_TILE)][4].
+ * rec_of_face_out: device [F] int32.                                                                            */
+int pvamd_mesh_prepare(const float* tri, const int32_t* face_id, int32_t F, float abs_margin, float* rec_out,
+                       float* tiles_out, int32_t* rec_of_face_out, void* stream);
+
+/* 30-bit Z-order (Morton) key of every point inside the box [lo, hi]: the sort key for a spatially coherent
+ * processing order (`order` below).  points: device [P][3].  box: device [2][3] fp32 (lo xyz, hi xyz).
+ * keys_out: device [P] int32.                                                                                  */
+int pvamd_morton_keys(const float* points, int64_t P, const float* box, int32_t* keys_out, void* stream);
+
 /* ObjectFactory._do_object_frame_closest_point (sdf.py:122-172): closest surface point, signed distance by
  * ray-hit parity, gradient, face id, optional face normal.
- * mesh: host struct with device pointers.  jitter_seed: counter-based replacement for the reference's unseeded
+ * mesh: host struct with device pointers.  order: device [P] int32 permutation or NULL -- the k-th lane processes
+ * point order[k] (spatially sorted processing makes the tile culling effective; outputs stay in point order).  jitter_seed: counter-based replacement for the reference's unseeded
  * np.random.randn (sdf.py:149); index_base = global index of points[0], so that a query sharded across GPUs
  * draws the jitter an unsharded one would.  out_closest: device [P][3] or NULL.  out_dist: device [P].  out_grad: device
  * [P][3].  out_face: device [P] int32 or NULL.  out_normal: device [P][3] or NULL (compute_normal=True).     */
-int pvamd_mesh_query(const pvamd_mesh_t* mesh, const float* points, int64_t P, uint64_t jitter_seed,
-                     int64_t index_base, float* out_closest, float* out_dist, float* out_grad, int32_t* out_face,
+int pvamd_mesh_query(const pvamd_mesh_t* mesh, const float* points, const int32_t* order, int64_t P,
+                     uint64_t jitter_seed, int64_t index_base, float* out_closest, float* out_dist, float* out_grad, int32_t* out_face,
                      float* out_normal, void* stream);
 
 /* batch_chamfer_dist (chamfer.py:79-94) against a mesh: for each of B world->object transforms, transform the
  * N points, unsigned distance to the mesh, accumulate sum_n (scale*d)^2.  The caller divides by the GLOBAL N
  * (after an all-reduce when the points are sharded across GPUs).
- * W: device [B][4][4].  points: device [N][3].  out_sum: device [B] float64, ZEROED by this call.       */
-int pvamd_chamfer_mesh(const pvamd_mesh_t* mesh, const float* W, int32_t B, const float* points, int64_t N,
-                       float scale, double* out_sum, void* stream);
+ * W: device [B][4][4].  points: device [N][3].  order: as for pvamd_mesh_query, or NULL.
+ * out_sum: device [B] float64, ZEROED by this call.                                                          */
+int pvamd_chamfer_mesh(const pvamd_mesh_t* mesh, const float* W, int32_t B, const float* points,
+                       const int32_t* order, int64_t N, float scale, double* out_sum, void* stream);
 
 /* Same against a cached grid (obj_sdf branch, chamfer.py:84-85).  grid: host.                            */
 int pvamd_chamfer_grid(const pvamd_grid_t* grid, const float* W, int32_t B, const float* points, int64_t N,

@@ -14,6 +14,8 @@ LIB_PATH = os.path.join(_HERE, "csrc", "libpvamd.so")
 ABI_VERSION = 2
 OOB_LOOKUP_GT_SDF = 0
 OOB_BOUNDING_BOX = 1
+TRI_REC = 28
+TRI_TILE = 256
 
 _c_float_p = ctypes.POINTER(ctypes.c_float)
 
@@ -44,8 +46,10 @@ class GridDesc(ctypes.Structure):
 class MeshDesc(ctypes.Structure):
     """pvamd_mesh_t"""
     _fields_ = [
-        ("tri", ctypes.c_void_p),
         ("normal", ctypes.c_void_p),
+        ("rec", ctypes.c_void_p),
+        ("tiles", ctypes.c_void_p),
+        ("rec_of_face", ctypes.c_void_p),
         ("F", ctypes.c_int32),
         ("reserved", ctypes.c_int32),
         ("ray_dir", ctypes.c_double * 3),
@@ -70,11 +74,16 @@ SIGNATURES = {
     "pvamd_composed_query": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int32, ctypes.c_void_p, ctypes.c_int32,
                                             ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p,
                                             ctypes.c_void_p, ctypes.c_void_p]),
-    "pvamd_mesh_query": (ctypes.c_int, [ctypes.POINTER(MeshDesc), ctypes.c_void_p, ctypes.c_int64, ctypes.c_uint64,
+    "pvamd_morton_keys": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p,
+                                         ctypes.c_void_p]),
+    "pvamd_mesh_prepare": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int32, ctypes.c_float,
+                                          ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]),
+    "pvamd_mesh_query": (ctypes.c_int, [ctypes.POINTER(MeshDesc), ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64,
+                                        ctypes.c_uint64,
                                         ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
                                         ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]),
     "pvamd_chamfer_mesh": (ctypes.c_int, [ctypes.POINTER(MeshDesc), ctypes.c_void_p, ctypes.c_int32, ctypes.c_void_p,
-                                          ctypes.c_int64, ctypes.c_float, ctypes.c_void_p, ctypes.c_void_p]),
+                                          ctypes.c_void_p, ctypes.c_int64, ctypes.c_float, ctypes.c_void_p, ctypes.c_void_p]),
     "pvamd_chamfer_grid": (ctypes.c_int, [ctypes.POINTER(GridDesc), ctypes.c_void_p, ctypes.c_int32, ctypes.c_void_p,
                                           ctypes.c_int64, ctypes.c_float, ctypes.c_void_p, ctypes.c_void_p]),
     "pvamd_transform_stack": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int32, ctypes.c_int32,
@@ -148,3 +157,18 @@ def as_query_points(points):
     lead = points.shape[:-1]
     flat = points.detach().reshape(-1, 3).to(device=dev, dtype=torch.float32).contiguous()
     return flat, lead, points.dtype if points.dtype.is_floating_point else torch.float32, points.device
+
+
+def morton_order(points, min_points=2048):
+    """int32 permutation that walks fp32 [P,3] device points along a Z-order curve (None below `min_points`, where
+    sorting costs more than it saves).  Spatially coherent waves are what lets the mesh kernels skip far tiles.
+    One key kernel + one device sort; nothing comes back to the host."""
+    P = points.shape[0]
+    if P < min_points:
+        return None
+    finite = torch.nan_to_num(points, nan=0.0, posinf=0.0, neginf=0.0)  # (no host sync: always one cheap pass)
+    lo, hi = torch.aminmax(finite, dim=0)
+    box = torch.stack((lo, hi)).contiguous()
+    keys = torch.empty((P,), dtype=torch.int32, device=points.device)
+    check(load().pvamd_morton_keys(ptr(points), P, ptr(box), ptr(keys), stream_ptr()), "pvamd_morton_keys")
+    return torch.argsort(keys).to(torch.int32)

@@ -65,7 +65,9 @@ def batch_chamfer_dist(world_to_object: torch.tensor, model_points_world_frame_e
             sums = ((float(scale) * d.to(device=dev, dtype=torch.float32)) ** 2).double().sum(dim=-1)
         else:
             desc = obj_factory._mesh_desc()
-            _lib.check(lib.pvamd_chamfer_mesh(ctypes.byref(desc), _lib.ptr(Wd), B, _lib.ptr(pts), N, float(scale),
+            order = _lib.morton_order(pts)
+            _lib.check(lib.pvamd_chamfer_mesh(ctypes.byref(desc), _lib.ptr(Wd), B, _lib.ptr(pts), _lib.ptr(order), N,
+                                              float(scale),
                                               _lib.ptr(sums), _lib.stream_ptr()), "pvamd_chamfer_mesh")
     total_n = N
     if reduce_group is not None:

@@ -51,6 +51,20 @@ class TriMesh:
         return self.vertices.mean(axis=0)
 
 
+def morton_order(points, bits=10):
+    """Permutation that sorts 3-D points along a Z-order curve (2^bits cells per axis over their bounding box)."""
+    p = np.asarray(points, dtype=np.float64).reshape(-1, 3)
+    if len(p) == 0:
+        return np.zeros((0,), dtype=np.int64)
+    lo, hi = p.min(axis=0), p.max(axis=0)
+    cell = np.clip(((p - lo) / np.maximum(hi - lo, 1e-30) * (2 ** bits - 1)).astype(np.int64), 0, 2 ** bits - 1)
+    key = np.zeros(len(p), dtype=np.int64)
+    for b in range(bits):
+        for d in range(3):
+            key |= ((cell[:, d] >> b) & 1) << (3 * b + d)
+    return np.argsort(key, kind="stable")
+
+
 def _parse_obj(text):
     verts, faces = [], []
     for line in text.splitlines():

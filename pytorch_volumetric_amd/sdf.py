@@ -117,14 +117,33 @@ class ObjectFactory(abc.ABC):
 
     # ---- device state ----
     def _mesh_desc(self):
+        """Upload + prepare the mesh once per device: triangles in Morton order of their centroids (what makes the
+        kernels' tile spheres tight), per-triangle records, tile spheres, face-id map."""
         dev = _lib.require_gpu()
         if self._tri_dev is None or self._tri_dev.device != dev:
+            lib = _lib.load()
             soup = self._mesh.triangle_soup().astype(np.float32)  # the scene stores float32 vertices
-            self._tri_dev = torch.from_numpy(np.ascontiguousarray(soup)).to(dev)
+            order = mesh_io.morton_order(soup.mean(axis=1))
+            F = soup.shape[0]
+            self._tri_dev = torch.from_numpy(np.ascontiguousarray(soup[order])).to(dev)
+            face_id = torch.from_numpy(order.astype(np.int32)).to(dev)
             self._normal_dev = torch.from_numpy(np.ascontiguousarray(self._face_normals.astype(np.float32))).to(dev)
+            self._rec_dev = torch.empty((max(F, 1), _lib.TRI_REC), dtype=torch.float32, device=dev)
+            self._tiles_dev = torch.empty(((F + _lib.TRI_TILE - 1) // _lib.TRI_TILE + 1, 4), dtype=torch.float32,
+                                          device=dev)
+            self._rec_of_face_dev = torch.empty((max(F, 1),), dtype=torch.int32, device=dev)
+            lo, hi = self._mesh.aabb()
+            abs_margin = 1e-6 * float(np.abs(self._mesh.vertices).max() + np.linalg.norm(hi - lo)) if F else 0.0
+            with torch.cuda.device(dev):
+                _lib.check(lib.pvamd_mesh_prepare(_lib.ptr(self._tri_dev), _lib.ptr(face_id), F, abs_margin,
+                                                  _lib.ptr(self._rec_dev), _lib.ptr(self._tiles_dev),
+                                                  _lib.ptr(self._rec_of_face_dev), _lib.stream_ptr()),
+                           "pvamd_mesh_prepare")
         desc = _lib.MeshDesc()
-        desc.tri = self._tri_dev.data_ptr()
         desc.normal = self._normal_dev.data_ptr()
+        desc.rec = self._rec_dev.data_ptr()
+        desc.tiles = self._tiles_dev.data_ptr()
+        desc.rec_of_face = self._rec_of_face_dev.data_ptr()
         desc.F = int(self._tri_dev.shape[0])
         ray = self.bounding_box(padding=1.0)[:, 1]  # sdf.py:147
         for d in range(3):
@@ -158,7 +177,9 @@ class ObjectFactory(abc.ABC):
         normal = torch.empty((P, 3), dtype=torch.float32, device=dev) if compute_normal else None
         desc = self._mesh_desc()
         with torch.cuda.device(dev):
-            _lib.check(lib.pvamd_mesh_query(ctypes.byref(desc), _lib.ptr(flat), P, ctypes.c_uint64(self.jitter_seed),
+            order = _lib.morton_order(flat)
+            _lib.check(lib.pvamd_mesh_query(ctypes.byref(desc), _lib.ptr(flat), _lib.ptr(order), P,
+                                            ctypes.c_uint64(self.jitter_seed),
                                             int(index_base), _lib.ptr(closest), _lib.ptr(dist), _lib.ptr(grad),
                                             _lib.ptr(face), _lib.ptr(normal), _lib.stream_ptr()), "pvamd_mesh_query")
         self._last_face_ids = face
