@@ -60,6 +60,50 @@ PVAMD_DEV void rotate_back(const float* __restrict__ M, const Best& b, float& ox
     oz = fmaf(M[10], gz, fmaf(M[6], gy, mul_rn(M[2], gx)));
 }
 
+// ---- leaf culling ----
+// Per (leaf, configuration) a sphere in the OBJECT frame: centre = centre of the leaf's valid range box, squared
+// radius of that box (a point farther than that is certainly out of range, so its value is the bounding-box
+// distance), and the radius of the leaf's surface bounding box about the same centre (that distance is at least
+// |p - c| - r_bb).  A leaf whose lower bound cannot beat the running minimum of any of the wave's 256 points is skipped
+// as a whole; the bounds are inflated, so skipping never changes a result (first-minimum semantics need a strictly
+// smaller value to replace the incumbent).  Pays off for spatially coherent queries (grids, slices, scans).
+constexpr int kMaxCullLeaves = 64;
+
+PVAMD_DEV void build_cull_spheres(const pvamd_grid_t* __restrict__ grids, int S, const float* __restrict__ tf, int A,
+                                  int a, float (*cull)[8]) {
+    for (int s = threadIdx.x; s < S && s < kMaxCullLeaves; s += blockDim.x) {
+        const pvamd_grid_t& g = grids[s];
+        const float* M = tf + 16 * ((int64_t)s * A + a);
+        float cl[3], r2 = 0.f, e2 = 0.f;
+#pragma unroll
+        for (int d = 0; d < 3; ++d) {
+            cl[d] = 0.5f * (g.vlo[d] + g.vhi[d]);
+            const float h = 0.5f * (g.vhi[d] - g.vlo[d]);
+            r2 += h * h;
+            const float e = fmaxf(fabsf(g.bb_min[d] - cl[d]), fabsf(g.bb_max[d] - cl[d]));
+            e2 += e * e;
+        }
+        // c_obj = R^T (c_leaf - t)
+        const float ux = cl[0] - M[3], uy = cl[1] - M[7], uz = cl[2] - M[11];
+        cull[s][0] = M[0] * ux + M[4] * uy + M[8] * uz;
+        cull[s][1] = M[1] * ux + M[5] * uy + M[9] * uz;
+        cull[s][2] = M[2] * ux + M[6] * uy + M[10] * uz;
+        const float scale = fmaxf(fmaxf(fabsf(cl[0]), fabsf(cl[1])), fabsf(cl[2])) + sqrt_rn(r2) + sqrt_rn(e2);
+        const float rr = sqrt_rn(r2) * 1.0001f + 1e-5f * scale;
+        cull[s][3] = rr * rr;                                   // beyond this (squared) the point is out of range
+        cull[s][4] = sqrt_rn(e2) * 1.0001f + 1e-5f * scale;    // radius of the surface bounding box
+        cull[s][5] = cull[s][6] = cull[s][7] = 0.f;
+    }
+}
+
+// true when leaf `c` provably cannot replace the incumbent minimum of this point
+PVAMD_DEV bool leaf_cannot_win(const float* __restrict__ c, float px, float py, float pz, const Best& best) {
+    const float dx = px - c[0], dy = py - c[1], dz = pz - c[2];
+    const float d2 = fmaf(dz, dz, fmaf(dy, dy, dx * dx));
+    const float t = best.v + c[4];
+    return (best.s >= 0) && (d2 > c[3]) && ((t <= 0.f) || (d2 >= t * t * 1.0003f));
+}
+
 // One wave = 256 consecutive points of one configuration per pass; all global traffic in contiguous 1 KB pieces
 // through a wave-private LDS slice (same scheme as cached_query_wave, see cached.hip).
 constexpr int kWavesPerBlock = 4;
@@ -74,11 +118,14 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void composed_query_wave(const
                                                                            float* __restrict__ grad,
                                                                            int* __restrict__ leaf) {
     __shared__ __attribute__((aligned(16))) float lds[kWavesPerBlock][1024];
+    __shared__ float cull[kMaxCullLeaves][8];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     float* spf = lds[wave];
     f32x4_alias* sp = reinterpret_cast<f32x4_alias*>(spf);
     float* svf = spf + 768;
     const int a = blockIdx.y;
+    build_cull_spheres(grids, S, tf, A, a, cull);
+    __syncthreads();
     const int64_t wstride = (int64_t)gridDim.x * kWavesPerBlock;
     for (int64_t tile = (int64_t)blockIdx.x * kWavesPerBlock + wave; tile < ntiles; tile += wstride) {
         const f32x4* src = pts4 + tile * 192;  // re-read for every configuration: L2-resident
@@ -98,6 +145,14 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void composed_query_wave(const
         }
         PVAMD_WAVE_SYNC();
         for (int s = 0; s < S; ++s) {
+            if (s < kMaxCullLeaves) {
+                const float* c = cull[s];  // wave-uniform: LDS broadcast
+                const bool dead = (int)leaf_cannot_win(c, px[0], py[0], pz[0], best[0]) &
+                                  (int)leaf_cannot_win(c, px[1], py[1], pz[1], best[1]) &
+                                  (int)leaf_cannot_win(c, px[2], py[2], pz[2], best[2]) &
+                                  (int)leaf_cannot_win(c, px[3], py[3], pz[3], best[3]);
+                if (__all(dead)) continue;
+            }
             const float* M = tf + 16 * ((int64_t)s * A + a);  // wave-uniform: scalar loads
             const pvamd_grid_t& g = grids[s];
 #pragma unroll

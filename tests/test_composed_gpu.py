@@ -119,3 +119,31 @@ def test_full_size_c3_properties():
     oval, ograd, _ = oracle.composed_query([og] * S, tfm.numpy(), 1, pts[:50_000].cpu().numpy())
     assert np.array_equal(v1[:50_000].cpu().numpy(), oval[0], equal_nan=True)
     assert np.array_equal(g1[:50_000].cpu().numpy(), ograd[0], equal_nan=True)
+
+
+def test_leaf_culling_is_exact_on_coherent_and_far_queries():
+    """Grid-ordered points (whole waves far from most leaves -> leaves skipped) and points far outside every leaf must
+    still match the oracle bit for bit; so must a scene where a leaf's grid range is SMALLER than its bounding box."""
+    S, A = 8, 3
+    leaves = [make_leaf(f64=(s % 2 == 0), padding=0.05) for s in range(S)]
+    tfm = H.random_rigid(S * A, seed=77, trans=1.5)
+    comp = pv.ComposedSDF(leaves, None)
+    comp.set_transforms(pv.Transform3d(matrix=tfm), batch_dim=(A,))
+    ax = torch.linspace(-2.0, 2.0, 48)
+    pts = torch.cartesian_prod(ax, ax, ax)[: 48 * 48 * 48 // 256 * 256]
+    far = H.uniform_points(2048, [30.0] * 3, [40.0] * 3, seed=1)
+    pts = torch.cat((pts, far))
+    val, grad = comp(pts.cuda())
+    oval, ograd, oleaf = oracle.composed_query([H.oracle_grid_from_cached(l) for l in leaves], tfm.numpy(), A, pts.numpy())
+    assert np.array_equal(val.cpu().numpy(), oval, equal_nan=True)
+    assert np.array_equal(grad.cpu().numpy(), ograd, equal_nan=True)
+    # range box inside the bounding box (negative padding): the out-of-range value can be 0 with a NaN gradient
+    gt = H.drill_like_gt()
+    tight = pv.CachedSDF("tight", 0.01, H.padded_range(H.DRILL_BB, -0.02), gt, device="cuda", cache_path=None)
+    comp2 = pv.ComposedSDF([tight, leaves[0]], pv.Transform3d(matrix=tfm[:2]))
+    q = H.uniform_points(65_536, [-2.0] * 3, [2.0] * 3, seed=5)
+    v2, g2 = comp2(q.cuda())
+    ov, og, _ = oracle.composed_query([H.oracle_grid_from_cached(tight), H.oracle_grid_from_cached(leaves[0])],
+                                      tfm[:2].numpy(), 1, q.numpy())
+    assert np.array_equal(v2.cpu().numpy(), ov[0], equal_nan=True)
+    assert np.array_equal(g2.cpu().numpy(), og[0], equal_nan=True)

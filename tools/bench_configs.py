@@ -113,6 +113,13 @@ def main():
         "points": P3, "leaves": S, "gpu_s": t, "gpu_queries_per_s": P3 / t, "algorithmic_GBs": 28 * P3 / t / 1e9,
         "frac_hbm_peak": 28 * P3 / t / 1e9 / HBM_PEAK, "includes": "python call + output allocation",
         "cpu_queries_per_s": 400_000 / tc}
+    # the same count of points on a regular grid (the README's query pattern): spatially coherent waves
+    n_side = round(P3 ** (1 / 3))
+    ax = torch.linspace(-0.5, 0.5, n_side)
+    grid3 = torch.cartesian_prod(ax, ax, ax)[:P3].contiguous().cuda()
+    tg, _ = gpu_time(lambda: comp(grid3), reps=20)
+    out["C3_composed_8_drills_4M"]["grid_ordered_points"] = {"points": int(grid3.shape[0]), "gpu_s": tg,
+                                                             "gpu_queries_per_s": grid3.shape[0] / tg}
 
     # ---------------- C4: RobotSDF, 7-DOF / 8 links, A=200 configs x 262,144 points ----------------
     with tempfile.TemporaryDirectory() as tmp:
@@ -133,6 +140,14 @@ def main():
         "frac_hbm_peak": 16 * pairs4 / t / 1e9 / HBM_PEAK, "set_joint_configuration_s": t_cfg,
         "link_grid_voxels": [int(np.prod(s._view.shape)) for s in robot.sdf.sdfs],
         "note": "synthetic KUKA-like arm (KUKA assets unavailable offline); link caches res 0.02 pad 0.1"}
+    n4 = round(P4 ** (1 / 3))
+    grid4 = torch.cartesian_prod(torch.linspace(-0.7, 0.7, n4), torch.linspace(-0.7, 0.7, n4),
+                                 torch.linspace(-0.2, 1.5, n4))
+    grid4 = grid4[: (grid4.shape[0] // 256) * 256].contiguous().cuda()
+    tg, _ = gpu_time(lambda: robot(grid4), reps=10)
+    out["C4_robot_8links"]["grid_ordered_points"] = {"points": int(grid4.shape[0]), "gpu_s": tg,
+                                                     "gpu_pairs_per_s": A * grid4.shape[0] / tg,
+                                                     "algorithmic_GBs": 16 * A * grid4.shape[0] / tg / 1e9}
 
     # ---------------- C5: chamfer, source points -> 99,500-triangle sphere mesh ----------------
     m = mesh_io.uv_sphere_mesh(0.1, 250, 200)
