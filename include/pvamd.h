@@ -93,6 +93,17 @@ typedef struct pvamd_mesh {
     double       ray_dir[3];
 } pvamd_mesh_t;
 
+/* One frame of a kinematic tree (URDF link + the joint that attaches it to its parent), frames sorted parents-first. */
+typedef struct pvamd_joint {
+    int32_t parent;      /* index of the parent frame, -1 for the root                                       */
+    int32_t jtype;       /* 0 fixed, 1 revolute / continuous, 2 prismatic                                    */
+    int32_t jcol;        /* column of q that drives this joint (ignored for fixed joints)                    */
+    int32_t leaf_slot;   /* s >= 0: also write this frame's world matrix to link_world_out[s*A + a]; -1: no  */
+    float   axis[3];     /* unit joint axis in the joint frame                                               */
+    float   reserved;
+    float   origin[12];  /* rows 0..2 of the parent-link -> joint-frame transform (URDF <origin>)            */
+} pvamd_joint_t;
+
 int         pvamd_abi_version(void);
 const char* pvamd_build_info(void);      /* static string: arch, compiler, build flags */
 /* number of devices visible / name of device 0 -- lets a host language check the GPU without a HIP binding */
@@ -177,6 +188,13 @@ int pvamd_chamfer_grid(const pvamd_grid_t* grid, const float* W, int32_t B, cons
  * out: device [S*A][4][4].  The 4x4x4 products run on the f32 MFMA (v_mfma_f32_4x4x1_16b_f32).            */
 int pvamd_transform_stack(const float* offset_inv, const float* link_world, int32_t S, int32_t A,
                           float* out, void* stream);
+
+/* Forward kinematics for A configurations (RobotSDF.set_joint_configuration, model_to_sdf.py:94-102):
+ * world[f] = world[parent f] @ origin[f] @ motion(joint f, q).  joints: device [F].  q, sin_q, cos_q: device [A][M]
+ * (joint values and their sine / cosine).  scratch: device [F][12][A] fp32 (all frames' matrices, rows 0..2, kept for
+ * children to read).  link_world_out: device [S*A][4][4], leaf-major, the input of pvamd_transform_stack.          */
+int pvamd_chain_fk(const pvamd_joint_t* joints, int32_t F, const float* q, const float* sin_q, const float* cos_q,
+                   int32_t A, int32_t M, float* scratch, float* link_world_out, void* stream);
 
 #ifdef __cplusplus
 }

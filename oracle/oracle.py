@@ -195,3 +195,24 @@ def transform_stack(offset_inv, link_world, S, A):
     out = np.empty((S * A, 4, 4), np.float32)
     load().oracle_transform_stack(_p(offset_inv), _p(link_world), ctypes.c_int32(S), ctypes.c_int32(A), _p(out))
     return out
+
+
+class OracleJoint(ctypes.Structure):
+    _fields_ = [("parent", ctypes.c_int32), ("jtype", ctypes.c_int32), ("jcol", ctypes.c_int32),
+                ("leaf_slot", ctypes.c_int32), ("axis", ctypes.c_float * 3), ("reserved", ctypes.c_float),
+                ("origin", ctypes.c_float * 12)]
+
+
+def chain_fk(joint_table, q, n_leaves):
+    """joint_table: bytes of F pvamd_joint_t records (Chain.joint_table()); q: [A,M] float32.
+    Returns (world [F,A,3,4], link_world [S*A,4,4])."""
+    F = len(joint_table) // ctypes.sizeof(OracleJoint)
+    joints = (OracleJoint * F).from_buffer_copy(joint_table)
+    q = _f32(q).reshape(-1, max(1, np.asarray(q).shape[-1]))
+    A, M = q.shape
+    sq, cq = np.sin(q).astype(np.float32), np.cos(q).astype(np.float32)
+    world = np.zeros((F, A, 12), np.float32)
+    link_world = np.zeros((max(1, n_leaves) * A, 4, 4), np.float32)
+    load().oracle_chain_fk(joints, ctypes.c_int32(F), _p(q), _p(sq), _p(cq), ctypes.c_int32(A), ctypes.c_int32(M),
+                           _p(world), _p(link_world))
+    return world.reshape(F, A, 3, 4), link_world, sq, cq

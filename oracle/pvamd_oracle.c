@@ -443,3 +443,59 @@ void oracle_transform_stack(const float* offset_inv, const float* link_world, in
             matmul4(offset_inv + 16 * (int64_t)s, inv, out + 16 * ((int64_t)s * A + a));
         }
 }
+
+/* ------------------------------------------------------------------------------------------------------------
+ * Forward kinematics (model_to_sdf.py:94-102; pytorch_kinematics Chain.forward_kinematics, absent here: restated as
+ * world[f] = world[parent] @ origin[f] @ motion(joint, q) with Rodrigues' rotation for revolute joints).
+ * Same operation sequence as csrc/fk.hip.
+ * ---------------------------------------------------------------------------------------------------------- */
+typedef struct oracle_joint {
+    int32_t parent, jtype, jcol, leaf_slot;
+    float axis[3], reserved;
+    float origin[12];
+} oracle_joint_t;
+
+static void compose_affine(const float* A, const float* B, float* C) {
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 4; ++j) {
+            float acc = A[4 * i] * B[j];
+            acc = fmaf(A[4 * i + 1], B[4 + j], acc);
+            acc = fmaf(A[4 * i + 2], B[8 + j], acc);
+            if (j == 3) acc = acc + A[4 * i + 3];
+            C[4 * i + j] = acc;
+        }
+}
+
+/* world: [F][A][12] (rows 0..2), link_world: [S*A][16] leaf-major */
+void oracle_chain_fk(const oracle_joint_t* joints, int32_t F, const float* q, const float* sin_q, const float* cos_q,
+                     int32_t A, int32_t M, float* world, float* link_world) {
+    for (int32_t a = 0; a < A; ++a)
+        for (int32_t f = 0; f < F; ++f) {
+            const oracle_joint_t* J = &joints[f];
+            float P[12] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0}, m[12], out[12];
+            if (J->parent >= 0) memcpy(P, world + 12 * ((int64_t)J->parent * A + a), sizeof(P));
+            compose_affine(P, J->origin, m);
+            if (J->jtype == 1) {
+                const float s = sin_q[(int64_t)a * M + J->jcol], c = cos_q[(int64_t)a * M + J->jcol];
+                const float x = J->axis[0], y = J->axis[1], z = J->axis[2];
+                const float t = 1.f - c, tx = t * x, ty = t * y, tz = t * z;
+                const float R[12] = {fmaf(tx, x, c),        fmaf(tx, y, -(s * z)), fmaf(tx, z, s * y),    0.f,
+                                     fmaf(tx, y, s * z),    fmaf(ty, y, c),        fmaf(ty, z, -(s * x)), 0.f,
+                                     fmaf(tx, z, -(s * y)), fmaf(ty, z, s * x),    fmaf(tz, z, c),        0.f};
+                compose_affine(m, R, out);
+                memcpy(m, out, sizeof(m));
+            } else if (J->jtype == 2) {
+                const float d = q[(int64_t)a * M + J->jcol];
+                const float T[12] = {1, 0, 0, J->axis[0] * d, 0, 1, 0, J->axis[1] * d, 0, 0, 1, J->axis[2] * d};
+                compose_affine(m, T, out);
+                memcpy(m, out, sizeof(m));
+            }
+            memcpy(world + 12 * ((int64_t)f * A + a), m, sizeof(m));
+            if (J->leaf_slot >= 0) {
+                float* o = link_world + 16 * ((int64_t)J->leaf_slot * A + a);
+                memcpy(o, m, sizeof(m));
+                o[12] = o[13] = o[14] = 0.f;
+                o[15] = 1.f;
+            }
+        }
+}

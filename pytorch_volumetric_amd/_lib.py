@@ -56,6 +56,13 @@ class MeshDesc(ctypes.Structure):
     ]
 
 
+class JointDesc(ctypes.Structure):
+    """pvamd_joint_t"""
+    _fields_ = [("parent", ctypes.c_int32), ("jtype", ctypes.c_int32), ("jcol", ctypes.c_int32),
+                ("leaf_slot", ctypes.c_int32), ("axis", ctypes.c_float * 3), ("reserved", ctypes.c_float),
+                ("origin", ctypes.c_float * 12)]
+
+
 # name -> (restype, argtypes); the test-suite checks every one of these is exported by the .so and declared in
 # include/pvamd.h
 SIGNATURES = {
@@ -86,6 +93,8 @@ SIGNATURES = {
                                           ctypes.c_void_p, ctypes.c_int64, ctypes.c_float, ctypes.c_void_p, ctypes.c_void_p]),
     "pvamd_chamfer_grid": (ctypes.c_int, [ctypes.POINTER(GridDesc), ctypes.c_void_p, ctypes.c_int32, ctypes.c_void_p,
                                           ctypes.c_int64, ctypes.c_float, ctypes.c_void_p, ctypes.c_void_p]),
+    "pvamd_chain_fk": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int32, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
+                                      ctypes.c_int32, ctypes.c_int32, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]),
     "pvamd_transform_stack": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int32, ctypes.c_int32,
                                              ctypes.c_void_p, ctypes.c_void_p]),
 }

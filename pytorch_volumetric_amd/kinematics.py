@@ -11,6 +11,7 @@ from typing import Dict, List, Optional
 import numpy as np
 import torch
 
+from pytorch_volumetric_amd import _lib
 from pytorch_volumetric_amd import transforms as tf
 
 
@@ -85,6 +86,50 @@ class Chain:
     @property
     def n_joints(self):
         return len(self.get_joint_parameter_names())
+
+    def joint_table(self, leaf_links=()):
+        """The chain as an array of pvamd_joint_t records (bytes) for the on-device FK kernel; `leaf_links[s]` = name of
+        the link whose world matrix goes to slot s of the leaf-major output."""
+        import ctypes
+        slots = {}
+        for s, name in enumerate(leaf_links):
+            slots.setdefault(name, []).append(s)
+        table = []
+        col = 0
+        for f in self._frames:
+            jt = f.joint.joint_type
+            code = {"fixed": 0, "revolute": 1, "continuous": 1, "prismatic": 2}.get(jt)
+            if code is None:
+                raise ValueError(f"unsupported joint type {jt}")
+            rec = _lib.JointDesc()
+            rec.parent = -1 if f.parent is None else f.parent
+            rec.jtype = code
+            rec.jcol = col if code else -1
+            col += 1 if code else 0
+            rec.leaf_slot = -1
+            for k in range(3):
+                rec.axis[k] = float(f.joint.axis[k])
+            o = np.asarray(f.joint.origin, dtype=np.float64)
+            for k in range(12):
+                rec.origin[k] = float(o[k // 4, k % 4])
+            table.append((rec, slots.get(f.name, [])))
+        # a link with several mesh visuals fills several slots: duplicate its record as a fixed child at identity
+        out = []
+        index_of = {}
+        for i, (rec, sl) in enumerate(table):
+            index_of[i] = len(out)
+            if rec.parent >= 0:
+                rec.parent = index_of[rec.parent]
+            rec.leaf_slot = sl[0] if sl else -1
+            out.append(rec)
+            for extra in sl[1:]:
+                dup = _lib.JointDesc()
+                dup.parent, dup.jtype, dup.jcol, dup.leaf_slot = index_of[i], 0, -1, extra
+                for k in range(12):
+                    dup.origin[k] = 1.0 if k % 5 == 0 else 0.0
+                out.append(dup)
+        arr = (_lib.JointDesc * len(out))(*out)
+        return bytes(arr)
 
     def forward_kinematics(self, th, end_only=False):
         """th: (M,) or (A, M) joint values -> {link name: Transform3d of (A,4,4) world_T_link}."""

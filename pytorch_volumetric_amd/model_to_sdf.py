@@ -88,23 +88,49 @@ class RobotSDF(sdf.ObjectFrameSDF):
         else:
             self.configuration_batch = None
         self.q = joint_config
-        fk = self.chain.forward_kinematics(joint_config, end_only=False)
-        link_world = torch.cat([tf.as_matrix(fk[name]) for name in self.sdf_to_link_name])  # (S*A,4,4) leaf-major
         S = len(self.sdf_to_link_name)
-        A = link_world.shape[0] // S
-
-        # object_to_link[s*A+a] = offset[s]^-1 @ world_T_link[s,a]^-1 on the matrix cores
         lib = _lib.load()
         dev = _lib.require_gpu()
-        offset_inv = tf.rigid_inverse(self.offset_transforms.get_matrix()).to(device=dev, dtype=torch.float32)
-        link_world_d = link_world.to(device=dev, dtype=torch.float32).contiguous()
-        stack = torch.empty_like(link_world_d)
+        offset_inv = self._offset_inv_dev(dev)
         with torch.cuda.device(dev):
-            _lib.check(lib.pvamd_transform_stack(_lib.ptr(offset_inv.contiguous()), _lib.ptr(link_world_d), S, A,
+            if hasattr(self.chain, "joint_table"):
+                # on-device FK (pvamd_chain_fk): no per-frame host-driven ops, nothing returns to the host
+                q = joint_config.reshape(-1, M).to(device=dev, dtype=torch.float32).contiguous()
+                A = q.shape[0]
+                joints, F = self._joint_table_dev(dev)
+                sin_q, cos_q = torch.sin(q), torch.cos(q)
+                scratch = torch.empty((F, 12, A), dtype=torch.float32, device=dev)
+                link_world_d = torch.empty((S * A, 4, 4), dtype=torch.float32, device=dev)
+                _lib.check(lib.pvamd_chain_fk(_lib.ptr(joints), F, _lib.ptr(q), _lib.ptr(sin_q), _lib.ptr(cos_q), A, M,
+                                              _lib.ptr(scratch), _lib.ptr(link_world_d), _lib.stream_ptr()),
+                           "pvamd_chain_fk")
+            else:
+                # a foreign chain object (e.g. pytorch_kinematics.Chain): use its own forward kinematics
+                fk = self.chain.forward_kinematics(joint_config, end_only=False)
+                link_world = torch.cat([tf.as_matrix(fk[name]) for name in self.sdf_to_link_name])  # leaf-major
+                A = link_world.shape[0] // S
+                link_world_d = link_world.to(device=dev, dtype=torch.float32).contiguous()
+            # object_to_link[s*A+a] = offset[s]^-1 @ world_T_link[s,a]^-1 on the matrix cores
+            stack = torch.empty_like(link_world_d)
+            _lib.check(lib.pvamd_transform_stack(_lib.ptr(offset_inv), _lib.ptr(link_world_d), S, A,
                                                  _lib.ptr(stack), _lib.stream_ptr()), "pvamd_transform_stack")
         self.object_to_link_frames = tf.Transform3d(matrix=stack)
         if self.sdf is not None:
             self.sdf.set_transforms(self.object_to_link_frames, batch_dim=self.configuration_batch)
+
+    def _offset_inv_dev(self, dev):
+        if getattr(self, "_offset_inv_cache", None) is None or self._offset_inv_cache.device != dev:
+            self._offset_inv_cache = tf.rigid_inverse(self.offset_transforms.get_matrix()).to(
+                device=dev, dtype=torch.float32).contiguous()
+        return self._offset_inv_cache
+
+    def _joint_table_dev(self, dev):
+        if getattr(self, "_joint_cache", None) is None or self._joint_cache[0].device != dev:
+            raw = self.chain.joint_table(self.sdf_to_link_name)
+            t = torch.frombuffer(bytearray(raw), dtype=torch.uint8).to(dev)
+            import ctypes
+            self._joint_cache = (t, len(raw) // ctypes.sizeof(_lib.JointDesc))
+        return self._joint_cache
 
     def __call__(self, points_in_object_frame):
         """

@@ -188,3 +188,26 @@ def test_sample_mesh_points_is_seeded_and_on_the_surface(tmp_path):
     assert torch.equal(p3, p1)
     with pytest.raises(RuntimeError):
         pv.sample_mesh_points(None, num_points=7, seed=4, name="box", dbpath=db)
+
+
+def test_oracle_fk_matches_torch_fk_on_a_branched_tree():
+    """oracle_chain_fk (the statement csrc/fk.hip mirrors) vs the float64 torch FK of kinematics.Chain."""
+    from oracle import oracle
+    urdf = """<robot name="t"><link name="base"/><link name="l1"/><link name="l2"/><link name="tool"/><link name="side"/>
+    <joint name="j1" type="revolute"><parent link="base"/><child link="l1"/><origin xyz="0 0 0.1" rpy="0.1 0.2 0.3"/><axis xyz="0 0 1"/></joint>
+    <joint name="j2" type="prismatic"><parent link="l1"/><child link="l2"/><origin xyz="0.2 0 0" rpy="0 0.5 0"/><axis xyz="1 1 0"/></joint>
+    <joint name="jf" type="fixed"><parent link="l2"/><child link="tool"/><origin xyz="0 0 0.05" rpy="0 0 1.0"/></joint>
+    <joint name="j3" type="continuous"><parent link="l1"/><child link="side"/><origin xyz="0 0.1 0" rpy="0 0 0"/><axis xyz="0 1 0"/></joint>
+    </robot>"""
+    chain = kinematics.build_chain_from_urdf(urdf, dtype=torch.float64)
+    names = chain.get_frame_names(exclude_fixed=False)
+    assert chain.get_joint_parameter_names() == ["j1", "j2", "j3"]
+    q = torch.randn(9, 3, generator=torch.Generator().manual_seed(0), dtype=torch.float64)
+    fk = chain.forward_kinematics(q)
+    leaves = ["tool", "side", "l1"]
+    world, link_world, _, _ = oracle.chain_fk(chain.joint_table(leaves), q.float().numpy(), len(leaves))
+    for f, name in enumerate(names):
+        assert np.abs(world[f] - fk[name].get_matrix()[:, :3, :].numpy()).max() < 2e-6
+    lw = link_world.reshape(len(leaves), 9, 4, 4)
+    for s, name in enumerate(leaves):
+        assert np.abs(lw[s] - fk[name].get_matrix().numpy()).max() < 2e-6

@@ -102,3 +102,35 @@ def test_robot_sdf_wrench_urdf_single_mesh_link():
     v_local, _ = leaf(local.cuda())
     # fp32 round trip through FK^-1 moves points by ~1e-7: allow the few that cross a voxel boundary
     assert (torch.isclose(v_world, v_local, atol=1e-6).float().mean() > 0.97)
+
+
+def test_on_device_fk_matches_oracle_bitwise_and_torch_fk(tmp_path):
+    chain = synthetic_arm(str(tmp_path))
+    leaves = [f"link_{i}" for i in range(8)]
+    raw = chain.joint_table(leaves)
+    import ctypes
+    F = len(raw) // ctypes.sizeof(pv._lib.JointDesc)
+    A, M = 77, 7
+    q = torch.randn(A, M, generator=torch.Generator().manual_seed(1)) * 0.8
+    qd = q.cuda().contiguous()
+    sq, cq = torch.sin(qd), torch.cos(qd)
+    joints = torch.frombuffer(bytearray(raw), dtype=torch.uint8).cuda()
+    scratch = torch.empty((F, 12, A), device="cuda")
+    lw = torch.empty((8 * A, 4, 4), device="cuda")
+    lib = pv._lib.load()
+    pv._lib.check(lib.pvamd_chain_fk(pv._lib.ptr(joints), F, pv._lib.ptr(qd), pv._lib.ptr(sq), pv._lib.ptr(cq), A, M,
+                                     pv._lib.ptr(scratch), pv._lib.ptr(lw), pv._lib.stream_ptr()), "pvamd_chain_fk")
+    # the oracle with the SAME sin/cos arrays (device sinf/cosf differ from libm in the last ulp)
+    joints_o = (oracle.OracleJoint * F).from_buffer_copy(raw)
+    world = np.zeros((F, A, 12), np.float32)
+    olw = np.zeros((8 * A, 4, 4), np.float32)
+    import ctypes as C
+    qn, sn, cn = q.numpy(), sq.cpu().numpy(), cq.cpu().numpy()
+    oracle.load().oracle_chain_fk(joints_o, C.c_int32(F), C.c_void_p(qn.ctypes.data), C.c_void_p(sn.ctypes.data),
+                                  C.c_void_p(cn.ctypes.data), C.c_int32(A), C.c_int32(M), C.c_void_p(world.ctypes.data),
+                                  C.c_void_p(olw.ctypes.data))
+    assert np.array_equal(lw.cpu().numpy(), olw)
+    assert np.array_equal(scratch.cpu().numpy().transpose(0, 2, 1), world)
+    fk = chain.forward_kinematics(q)
+    ref = torch.cat([fk[n].get_matrix() for n in leaves])
+    assert torch.allclose(lw.cpu(), ref, atol=2e-6)
