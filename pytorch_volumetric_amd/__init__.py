@@ -7,7 +7,8 @@ from pytorch_volumetric_amd.chamfer import batch_chamfer_dist, PlausibleDiversit
     pairwise_distance_chamfer
 from pytorch_volumetric_amd.sdf import sample_mesh_points, ObjectFrameSDF, MeshSDF, CachedSDF, ComposedSDF, SDFQuery, \
     ObjectFactory, MeshObjectFactory, OutOfBoundsStrategy, SphereSDF
-from pytorch_volumetric_amd.voxel import get_divisible_range_by_resolution, get_coordinates_and_points_in_grid
+from pytorch_volumetric_amd.voxel import Voxels, VoxelGrid, VoxelSet, ExpandingVoxelGrid, get_divisible_range_by_resolution, \
+    get_coordinates_and_points_in_grid, voxel_down_sample
 from pytorch_volumetric_amd.model_to_sdf import RobotSDF, cache_link_sdf_factory, aabb_to_ordered_end_points
 from pytorch_volumetric_amd.volume import is_inside
 from pytorch_volumetric_amd.transforms import Transform3d, Translate, Rotate

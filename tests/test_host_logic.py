@@ -211,3 +211,32 @@ def test_oracle_fk_matches_torch_fk_on_a_branched_tree():
     lw = link_world.reshape(len(leaves), 9, 4, 4)
     for s, name in enumerate(leaves):
         assert np.abs(lw[s] - fk[name].get_matrix().numpy()).max() < 2e-6
+
+
+def test_voxel_containers_thin_port():
+    """tests/test_voxel_sdf.py of the reference (headless): down-sampling gives fewer points, each within 2*res of an
+    original; plus set/get round trip, expansion and resize."""
+    g = torch.Generator().manual_seed(0)
+    pts = torch.rand(5000, 3, generator=g) * torch.tensor([0.4, 0.3, 0.2])
+    res = 0.02
+    down = pv.voxel_down_sample(pts, res)
+    assert 0 < down.shape[0] < pts.shape[0]
+    assert torch.cdist(down, pts).min(dim=1).values.max() < 2 * res
+    flat = torch.cat((pts[:, :2], torch.full((5000, 1), 0.7)), dim=1)
+    down2 = pv.voxel_down_sample(flat, res, range_per_dim=np.array([[-1, 1], [-1, 1], [0.7, 0.7]]), ignore_flat_dim=True)
+    assert down2.shape[1] == 3 and torch.allclose(down2[:, 2].float(), torch.tensor(0.7))
+    vg = pv.VoxelGrid(0.1, [(-0.5, 0.5), (-0.5, 0.5), (0.0, 1.0)])
+    q = torch.tensor([[0.1, -0.2, 0.3], [0.44, 0.44, 0.96]])
+    vg[q] = torch.tensor([2.0, 3.0])
+    assert torch.equal(vg[q], torch.tensor([2.0, 3.0]))
+    pos, val = vg.get_known_pos_and_values()
+    assert pos.shape == (2, 3) and sorted(val.tolist()) == [2.0, 3.0]
+    assert torch.allclose(pos.sort(dim=0).values, torch.tensor([[0.1, -0.2, 0.3], [0.4, 0.4, 1.0]]), atol=1e-6)
+    ev = pv.ExpandingVoxelGrid(0.1, [(-0.5, 0.5)] * 3)
+    ev[torch.tensor([[0.9, 0.0, 0.0]])] = torch.tensor([5.0])
+    assert ev.range_per_dim[0][1] >= 0.9 and ev[torch.tensor([[0.9, 0.0, 0.0]])].item() == 5.0
+    vg.resize_to_fit()
+    assert vg[q].tolist() == [2.0, 3.0]
+    vs = pv.VoxelSet(torch.zeros(0, 3), torch.zeros(0))
+    vs[q] = torch.tensor([1.0, 1.0])
+    assert vs.get_known_pos_and_values()[0].shape == (2, 3)
