@@ -85,10 +85,31 @@ def cpu_baseline(cached, pts, seconds):
         dt = time.perf_counter() - t0
         if dt >= seconds and reps >= 3:
             break
-    return {"value": len(host_pts) * reps / dt, "unit": "queries/s", "cores": oracle.num_threads(), "kind": "port",
-            "host_cpus": os.cpu_count(),
-            "sample": f"{reps} x {len(host_pts)} of the same query points through oracle/pvamd_oracle.c "
-                      f"(OpenMP, {oracle.num_threads()} threads), {dt:.1f} s wall"}
+    out = {"value": len(host_pts) * reps / dt, "unit": "queries/s", "cores": oracle.num_threads(), "kind": "port",
+           "host_cpus": os.cpu_count(),
+           "sample": f"{reps} x {len(host_pts)} of the same query points through oracle/pvamd_oracle.c "
+                     f"(OpenMP, {oracle.num_threads()} threads), {dt:.1f} s wall"}
+    # second CPU figure: the reference's own op sequence (sdf.py:535-571) restated op for op in torch on the host cores
+    try:
+        from oracle.torch_opforop import CachedOpForOp
+        packed = cached._packed.cpu()
+        view = cached._view
+        ref = CachedOpForOp(packed[:, 0].reshape(view.shape).contiguous(), packed[:, 1:4].contiguous(), view.min, view.max,
+                            cached.bb.cpu())
+        tp = pts.cpu()
+        ref(tp[:1000])
+        n, t1 = 0, time.perf_counter()
+        while True:
+            ref(tp)
+            n += 1
+            d1 = time.perf_counter() - t1
+            if d1 >= seconds / 2 and n >= 2:
+                break
+        out["torch_opforop"] = {"value": len(tp) * n / d1, "unit": "queries/s", "threads": torch.get_num_threads(),
+                                "sample": f"{n} x {len(tp)} points, oracle/torch_opforop.py, {d1:.1f} s wall"}
+    except Exception as exc:  # never let the secondary baseline break the bench line
+        out["torch_opforop"] = {"error": repr(exc)}
+    return out
 
 
 def main():

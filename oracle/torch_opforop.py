@@ -1,0 +1,42 @@
+"""Op-for-op torch restatement of CachedSDF.__call__ (reference sdf.py:535-571) -- TEST INFRASTRUCTURE ONLY.
+
+BASELINE.md's "B1": the same sequence of stock torch ops and intermediates the reference executes (index -> ravel ->
+range mask -> two masked gather/scatters -> compaction of the out-of-range points -> bounding-box branch -> two masked
+scatters), so that bench.py can time "what a reference user gets on the CPU" next to the fused C port.  The absent
+third-party view (multidim_indexing) is replaced by the three expressions its call sites amount to.
+"""
+import torch
+
+
+class CachedOpForOp:
+    def __init__(self, val_grid, grad_flat, vmin, vmax, bb):
+        self.raw_data = val_grid.reshape(-1)          # view.raw_data
+        self.shape = tuple(val_grid.shape)
+        self.voxels_grad = grad_flat                  # sdf.py:523
+        self.vmin, self.vmax = vmin, vmax
+        self.res = (vmax - vmin) / (torch.tensor(self.shape) - 1)
+        self.bb = bb
+
+    def __call__(self, pts):
+        keys = torch.round((pts - self.vmin) / self.res).to(torch.long)                    # :537
+        ravelled = (keys[..., 0] * self.shape[1] + keys[..., 1]) * self.shape[2] + keys[..., 2]  # :538
+        inbound = ((self.vmin <= pts) & (pts <= self.vmax)).all(dim=-1)                    # :540
+        oob = ~inbound                                                                      # :541
+        val = torch.zeros(ravelled.shape, dtype=pts.dtype)                                  # :546
+        grad = torch.zeros(keys.shape, dtype=pts.dtype)                                     # :547
+        val[inbound] = self.raw_data[ravelled[inbound]]                                     # :549
+        grad[inbound] = self.voxels_grad[ravelled[inbound]]                                 # :550
+        p = pts[oob]                                                                        # :552
+        bb = self.bb.to(pts.dtype)
+        dmin = bb[:, 0] - p                                                                 # :559
+        dmin_active = dmin > 0
+        dmin[~dmin_active] = 0
+        dmax = p - bb[:, 1]                                                                 # :562
+        dmax_active = dmax > 0
+        dmax[~dmax_active] = 0
+        dtotal = dmin + dmax                                                                # :565
+        dtotal[dmin_active] = -dtotal[dmin_active]                                          # :567
+        dist = dtotal.norm(dim=-1)                                                          # :568
+        grad[oob] = dtotal / dist.unsqueeze(-1)                                             # :570
+        val[oob] = dist                                                                     # :571
+        return val, grad

@@ -139,6 +139,8 @@ class ObjectFactory(abc.ABC):
                                                   _lib.ptr(self._rec_dev), _lib.ptr(self._tiles_dev),
                                                   _lib.ptr(self._rec_of_face_dev), _lib.stream_ptr()),
                            "pvamd_mesh_prepare")
+        if getattr(self, "_mesh_desc_cache", None) is not None and self._mesh_desc_cache.rec == self._rec_dev.data_ptr():
+            return self._mesh_desc_cache
         desc = _lib.MeshDesc()
         desc.normal = self._normal_dev.data_ptr()
         desc.rec = self._rec_dev.data_ptr()
@@ -148,6 +150,7 @@ class ObjectFactory(abc.ABC):
         ray = self.bounding_box(padding=1.0)[:, 1]  # sdf.py:147
         for d in range(3):
             desc.ray_dir[d] = float(ray[d])
+        self._mesh_desc_cache = desc
         return desc
 
     @property
@@ -385,6 +388,12 @@ class CachedSDF(ObjectFrameSDF):
         return self.gt_sdf.surface_bounding_box(**kwargs)
 
     def _grid_desc(self, oob_mode=None):
+        """pvamd_grid_t for this cache (built once per out-of-bounds mode: filling it costs ~40 host scalar reads)."""
+        mode_key = self.out_of_bounds_strategy if oob_mode is None else oob_mode
+        cache = self.__dict__.setdefault("_desc_by_mode", {})
+        hit = cache.get(mode_key)
+        if hit is not None and hit.vox == self._packed.data_ptr():
+            return hit
         desc = _lib.GridDesc()
         desc.vox = self._packed.data_ptr()
         self._view.fill(desc)
@@ -394,6 +403,7 @@ class CachedSDF(ObjectFrameSDF):
         mode = self.out_of_bounds_strategy if oob_mode is None else oob_mode
         desc.oob_mode = _lib.OOB_BOUNDING_BOX if mode == OutOfBoundsStrategy.BOUNDING_BOX else _lib.OOB_LOOKUP_GT_SDF
         _lib.check(_lib.load().pvamd_grid_finalize(ctypes.byref(desc)), "pvamd_grid_finalize")
+        cache[mode_key] = desc
         return desc
 
     def __call__(self, points_in_object_frame):

@@ -150,3 +150,22 @@ def test_transform_stack_matches_float64_algebra():
     ref = np.einsum("sij,sajk->saik", np.linalg.inv(off.astype(np.float64)),
                     np.linalg.inv(world.astype(np.float64)).reshape(S, A, 4, 4)).reshape(-1, 4, 4)
     assert np.abs(out - ref).max() < 2e-6
+
+
+def test_torch_opforop_baseline_agrees_with_the_c_oracle():
+    """The op-for-op torch restatement timed by bench.py (B1) and the C oracle (B2) compute the same thing."""
+    from oracle.torch_opforop import CachedOpForOp
+    for tag in ("f64", "f32"):
+        rng = G[f"cached/{tag}/range_snapped"]
+        dt = torch.float64 if tag == "f64" else torch.float32
+        ref = CachedOpForOp(torch.from_numpy(G[f"cached/{tag}/val_grid"]), torch.from_numpy(G[f"cached/{tag}/grad_grid"]),
+                            torch.tensor(rng[:, 0], dtype=dt), torch.tensor(rng[:, 1], dtype=dt),
+                            torch.from_numpy(G[f"cached/{tag}/bb"]))
+        pts = torch.from_numpy(G[f"cached/{tag}/points"])
+        v, g = ref(pts)
+        # identical to what the reference's own code produced (make_golden.py group B) ...
+        assert np.array_equal(v.numpy(), G[f"cached/{tag}/val"])
+        assert np.array_equal(g.numpy(), G[f"cached/{tag}/grad"], equal_nan=True)
+        # ... and to the C oracle up to torch's norm rounding in the out-of-range branch
+        ov, og, oob = oracle.cached_query(golden_grid(tag), pts.numpy())
+        assert np.array_equal(v.numpy()[~oob], ov[~oob]) and np.abs(v.numpy() - ov).max() <= 1.2e-7
