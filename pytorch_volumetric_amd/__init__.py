@@ -1,18 +1,20 @@
 """MI355X-native batched SDF query engine with the pytorch_volumetric API (drop-in for the SDF-query hot path).
 
-Exports the reference's names (pytorch_volumetric/__init__.py:1-9) that lie on that path; the voxel containers,
-visualisation helpers and point-cloud down-sampling of the reference are out of scope.
+Every name pytorch_volumetric exports for that path is available here; see INTEGRATION.md for the differences.
 """
-from pytorch_volumetric_amd.chamfer import batch_chamfer_dist, PlausibleDiversity, pairwise_distance, \
-    pairwise_distance_chamfer
-from pytorch_volumetric_amd.sdf import sample_mesh_points, ObjectFrameSDF, MeshSDF, CachedSDF, ComposedSDF, SDFQuery, \
-    ObjectFactory, MeshObjectFactory, OutOfBoundsStrategy, SphereSDF
-from pytorch_volumetric_amd.voxel import Voxels, VoxelGrid, VoxelSet, ExpandingVoxelGrid, get_divisible_range_by_resolution, \
-    get_coordinates_and_points_in_grid, voxel_down_sample
-from pytorch_volumetric_amd.model_to_sdf import RobotSDF, cache_link_sdf_factory, aabb_to_ordered_end_points
+from pytorch_volumetric_amd import _lib, mesh_io
+from pytorch_volumetric_amd.sdf import (CachedSDF, ComposedSDF, MeshObjectFactory, MeshSDF, ObjectFactory,
+                                        ObjectFrameSDF, OutOfBoundsStrategy, SDFQuery, SphereSDF, sample_mesh_points)
+from pytorch_volumetric_amd.model_to_sdf import RobotSDF, aabb_to_ordered_end_points, cache_link_sdf_factory
+from pytorch_volumetric_amd.chamfer import (PlausibleDiversity, batch_chamfer_dist, pairwise_distance,
+                                            pairwise_distance_chamfer)
+from pytorch_volumetric_amd.voxel import get_coordinates_and_points_in_grid, get_divisible_range_by_resolution
+from pytorch_volumetric_amd.voxel_containers import (ExpandingVoxelGrid, VoxelGrid, VoxelSet, Voxels,
+                                                     voxel_down_sample)
 from pytorch_volumetric_amd.volume import is_inside
-from pytorch_volumetric_amd.transforms import Transform3d, Translate, Rotate
+# stand-ins for the pytorch_kinematics members the path touches, and the multi-GPU helpers
+from pytorch_volumetric_amd.transforms import Rotate, Transform3d, Translate
 from pytorch_volumetric_amd.kinematics import Chain, build_chain_from_urdf, build_serial_chain_from_urdf
-from pytorch_volumetric_amd.dist import ShardedSDF, sharded_chamfer, shard_range
+from pytorch_volumetric_amd.dist import ShardedSDF, shard_range, sharded_chamfer
 
 __version__ = "0.1.0"

@@ -38,27 +38,27 @@ class RobotSDF(sdf.ObjectFrameSDF):
         self.sdf_to_link_name = []
         self.configuration_batch = None
 
-        sdfs = []
-        offsets = []
-        for frame_name in self.frame_names:
-            frame = self.chain.find_frame(frame_name)
-            for link_vis in frame.link.visuals:
-                if link_vis.geom_type == "mesh":
-                    logger.info(f"{frame.link.name} offset {link_vis.offset}")
-                    link_obj = sdf.MeshObjectFactory(link_vis.geom_param[0], scale=link_vis.geom_param[1],
-                                                     path_prefix=path_prefix)
-                    sdfs.append(link_sdf_cls(link_obj))
-                    self.sdf_to_link_name.append(frame.link.name)
-                    offsets.append(link_vis.offset)
-                else:
-                    logger.warning(f"Cannot handle non-mesh link visual type {link_vis} for {frame.link.name}")
-        if not sdfs:
-            raise RuntimeError("robot description has no mesh visuals to build an SDF from")
-
+        sdfs, offsets = self._collect_mesh_links(path_prefix, link_sdf_cls)
         self.offset_transforms = tf.Transform3d(matrix=torch.cat([tf.as_matrix(o) for o in offsets], dim=0)).to(
             device=self.device, dtype=self.dtype)
         self.sdf = sdf.ComposedSDF(sdfs, self.object_to_link_frames)
         self.set_joint_configuration(default_joint_config)
+
+    def _collect_mesh_links(self, path_prefix, link_sdf_cls):
+        """One leaf SDF (+ its visual offset) per mesh visual of the chain, in frame order (model_to_sdf.py:41-56)."""
+        sdfs, offsets = [], []
+        for link in (self.chain.find_frame(name).link for name in self.frame_names):
+            for visual in link.visuals:
+                if visual.geom_type != "mesh":
+                    logger.warning(f"Cannot handle non-mesh link visual type {visual} for {link.name}")
+                    continue
+                mesh_file, mesh_scale = visual.geom_param[0], visual.geom_param[1]
+                sdfs.append(link_sdf_cls(sdf.MeshObjectFactory(mesh_file, scale=mesh_scale, path_prefix=path_prefix)))
+                offsets.append(visual.offset)
+                self.sdf_to_link_name.append(link.name)
+        if not sdfs:
+            raise RuntimeError("robot description has no mesh visuals to build an SDF from")
+        return sdfs, offsets
 
     def surface_bounding_box(self, **kwargs):
         return self.sdf.surface_bounding_box(**kwargs)

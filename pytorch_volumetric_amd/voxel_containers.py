@@ -1,0 +1,172 @@
+"""Mutable voxel containers and point-cloud down-sampling: the API of the reference's voxel.py:28-171.
+
+These are NOT on the SDF-query hot path (SURVEY.md section 2 marks them out of scope; section 8(f) ranks them last of
+the "next" rows), so they are kept thin: plain torch on whatever device the caller uses, any dimensionality, over the
+same value-range indexing rule the query kernels implement (index = round_half_even((p - min) / res), valid iff
+min <= p <= max).
+"""
+import abc
+
+import numpy as np
+import torch
+
+from pytorch_volumetric_amd.voxel import (bounds_contain_another_bounds, get_coordinates_and_points_in_grid,
+                                          get_divisible_range_by_resolution)
+
+
+class ValueRangeView:
+    """Dense d-dimensional storage addressed by real-valued coordinates."""
+
+    def __init__(self, source, value_ranges, invalid_value=0):
+        self.device, self.dtype = source.device, source.dtype
+        self.shape = tuple(source.shape)
+        self.raw_data = source.reshape(-1)
+        self._min = torch.tensor([b[0] for b in value_ranges], device=self.device)
+        self._max = torch.tensor([b[1] for b in value_ranges], device=self.device)
+        self._extent = torch.tensor(self.shape, device=self.device)
+        self._resolution = (self._max - self._min) / (self._extent - 1).clamp_min(1)
+        self.invalid_value = invalid_value
+
+    def ensure_index_key(self, key):
+        return torch.round((key - self._min) / self._resolution).to(torch.long)
+
+    def ensure_value_key(self, index):
+        return index.to(self._resolution.dtype) * self._resolution + self._min
+
+    def ravel_multi_index(self, key, shape=None):
+        flat = key[..., 0].clone()
+        for d, n in enumerate((shape or self.shape)[1:], start=1):
+            flat = flat * n + key[..., d]
+        return flat
+
+    def get_valid_values(self, key):
+        return ((key >= self._min) & (key <= self._max)).all(dim=-1)
+
+    def _flat(self, pts):
+        return self.ravel_multi_index(self.ensure_index_key(pts).clamp_min(0).minimum(self._extent - 1))
+
+    def __getitem__(self, pts):
+        ok = self.get_valid_values(pts)
+        out = self.raw_data[self._flat(pts)].clone()
+        out[~ok] = self.invalid_value(pts[~ok]) if callable(self.invalid_value) else self.invalid_value
+        return out
+
+    def __setitem__(self, pts, value):
+        ok = self.get_valid_values(pts)
+        per_point = torch.is_tensor(value) and value.dim() > 0
+        self.raw_data[self._flat(pts[ok])] = value[ok] if per_point else value
+
+
+class Voxels(abc.ABC):
+    """positions <-> values container protocol"""
+
+    @abc.abstractmethod
+    def get_known_pos_and_values(self):
+        ...
+
+    @abc.abstractmethod
+    def __getitem__(self, pts):
+        ...
+
+    @abc.abstractmethod
+    def __setitem__(self, pts, value):
+        ...
+
+
+class VoxelGrid(Voxels):
+    """Dense grid over a fixed range; 0 means "unknown"."""
+
+    def __init__(self, resolution, range_per_dim, dtype=torch.float, device='cpu'):
+        self.resolution, self.dtype, self.device = resolution, dtype, device
+        self.invalid_val = 0
+        self._create_voxels(resolution, range_per_dim)
+
+    def _create_voxels(self, resolution, range_per_dim):
+        snapped = get_divisible_range_by_resolution(resolution, range_per_dim)
+        self.coords, self.pts = get_coordinates_and_points_in_grid(resolution, snapped, device=self.device)
+        self._data = torch.zeros(tuple(len(c) for c in self.coords), dtype=self.dtype, device=self.device)
+        self.voxels = ValueRangeView(self._data, snapped, invalid_value=self.invalid_val)
+        self.range_per_dim = np.array(snapped)
+
+    def get_known_pos_and_values(self):
+        idx = (self._data != self.invalid_val).nonzero()  # (K, d) multi-indices
+        return self.voxels.ensure_value_key(idx), self._data[tuple(idx.unbind(-1))]
+
+    def _rebuild(self, new_range):
+        pos, val = self.get_known_pos_and_values()
+        self._create_voxels(self.resolution, new_range)
+        if pos.numel():
+            self.voxels[pos] = val
+
+    def resize_to_fit(self):
+        """shrink / move the range to the known voxels plus one cell of margin"""
+        pos, _ = self.get_known_pos_and_values()
+        if pos.numel():
+            lo, hi = pos.amin(dim=0).cpu().numpy(), pos.amax(dim=0).cpu().numpy()
+            self._rebuild(np.stack((lo - self.resolution, hi + self.resolution), axis=1))
+
+    def get_voxel_values(self):
+        return self._data
+
+    def get_voxel_center_points(self):
+        return self.pts
+
+    def __getitem__(self, pts):
+        return self.voxels[pts]
+
+    def __setitem__(self, pts, value):
+        self.voxels[pts] = value
+
+
+class ExpandingVoxelGrid(VoxelGrid):
+    """VoxelGrid whose range grows, in whole cells, to contain whatever is written to it."""
+
+    def __setitem__(self, pts, value):
+        if pts.numel():
+            lo, hi = pts.amin(dim=0).cpu().numpy(), pts.amax(dim=0).cpu().numpy()
+            cells_below = np.ceil(np.maximum(self.range_per_dim[:, 0] - lo, 0) / self.resolution)
+            cells_above = np.ceil(np.maximum(hi - self.range_per_dim[:, 1], 0) / self.resolution)
+            if cells_below.any() or cells_above.any():
+                self._rebuild(np.stack((self.range_per_dim[:, 0] - cells_below * self.resolution,
+                                        self.range_per_dim[:, 1] + cells_above * self.resolution), axis=1))
+        super().__setitem__(pts, value)
+
+
+class VoxelSet(Voxels):
+    """Sparse list of (position, value) pairs; append-only."""
+
+    def __init__(self, positions, values):
+        self.positions, self.values = positions, values
+
+    def __getitem__(self, pts):
+        raise RuntimeError("Cannot get arbitrary points on a voxel set")
+
+    def __setitem__(self, pts, value):
+        self.positions = torch.cat((self.positions, pts.reshape(-1, self.positions.shape[-1])))
+        self.values = torch.cat((self.values, value))
+
+    def get_known_pos_and_values(self):
+        return self.positions, self.values
+
+
+def voxel_down_sample(points, resolution, range_per_dim=None, ignore_flat_dim=False):
+    """Centres of the occupied cells of a `resolution` grid laid over an N x D point cloud.
+
+    range_per_dim: optional (D,2) range; used as given unless it contains the data's own (2-cell padded) bounds, in
+    which case the data bounds are used.  ignore_flat_dim: a last dimension with min == max is carried through."""
+    if len(points) == 0:
+        return points
+    pad = 2 * resolution
+    data_bounds = np.stack((points.amin(dim=0).cpu().numpy() - pad, points.amax(dim=0).cpu().numpy() + pad), axis=1)
+    if range_per_dim is None or bounds_contain_another_bounds(range_per_dim, data_bounds):
+        range_per_dim = data_bounds
+    flat_value = None
+    if ignore_flat_dim and range_per_dim[-1][0] == range_per_dim[-1][1]:
+        flat_value = range_per_dim[-1][0]
+        range_per_dim, points = range_per_dim[:-1], points[..., :-1]
+    occupancy = VoxelGrid(resolution, range_per_dim, device=points.device, dtype=torch.bool)
+    occupancy[points] = 1
+    centres, _ = occupancy.get_known_pos_and_values()
+    if flat_value is not None:
+        centres = torch.cat((centres, torch.full((len(centres), 1), float(flat_value), device=points.device)), dim=-1)
+    return centres
