@@ -16,7 +16,10 @@ namespace pvamd {
 constexpr int kWavesPerBlock = 4;
 constexpr int kTilePoints = 256;
 
-template <bool F64, bool WRITE_OOB>
+// LD_NT / ST_NT: non-temporal loads / stores.  Measured (tools/kbench.hip): batches whose points are cache-resident
+// (<= a few M points, e.g. produced by the previous kernel or re-used) prefer plain loads + nt stores (6.6 -> 6.3 us per
+// 1M points); batches far beyond the 256 MB Infinity Cache prefer nt loads + plain stores (0.370 -> 0.358 ms per 64M).
+template <bool F64, bool WRITE_OOB, bool LD_NT, bool ST_NT>
 __global__ __launch_bounds__(kWavesPerBlock * 64) void cached_query_wave(const pvamd_grid_t g,
                                                                          const f32x4* __restrict__ pts4,
                                                                          int64_t ntiles, f32x4* __restrict__ val4,
@@ -30,12 +33,19 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void cached_query_wave(const p
     const int64_t wstride = (int64_t)gridDim.x * kWavesPerBlock;
     int64_t tile = (int64_t)blockIdx.x * kWavesPerBlock + wave;
     f32x4 a, b, c;
-    if (tile < ntiles) {
-        const f32x4* src = pts4 + tile * 192;
-        a = __builtin_nontemporal_load(src + lane);
-        b = __builtin_nontemporal_load(src + lane + 64);
-        c = __builtin_nontemporal_load(src + lane + 128);
-    }
+    auto load3 = [&](int64_t t) {
+        const f32x4* src = pts4 + t * 192;
+        if (LD_NT) {
+            a = __builtin_nontemporal_load(src + lane);
+            b = __builtin_nontemporal_load(src + lane + 64);
+            c = __builtin_nontemporal_load(src + lane + 128);
+        } else {
+            a = src[lane];
+            b = src[lane + 64];
+            c = src[lane + 128];
+        }
+    };
+    if (tile < ntiles) load3(tile);
     for (; tile < ntiles; tile += wstride) {
         sp[lane] = a;
         sp[lane + 64] = b;
@@ -43,12 +53,7 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void cached_query_wave(const p
         // software prefetch: the next tile's HBM loads are in flight while this tile is looked up (the wave fences
         // below stop the compiler from doing this itself); 0.47 -> 0.42 ms per 64M points (profiles/r01_kbench.txt)
         const int64_t next = tile + wstride;
-        if (next < ntiles) {
-            const f32x4* src = pts4 + next * 192;
-            a = __builtin_nontemporal_load(src + lane);
-            b = __builtin_nontemporal_load(src + lane + 64);
-            c = __builtin_nontemporal_load(src + lane + 128);
-        }
+        if (next < ntiles) load3(next);
         PVAMD_WAVE_SYNC();
         float px[4], py[4], pz[4];
 #pragma unroll
@@ -71,11 +76,18 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void cached_query_wave(const p
             if constexpr (WRITE_OOB) oob[tile * kTilePoints + p] = valid ? 0 : 1;
         }
         PVAMD_WAVE_SYNC();
-        __builtin_nontemporal_store(sp[192 + lane], val4 + tile * 64 + lane);
         f32x4* dst = grad4 + tile * 192;
-        __builtin_nontemporal_store(sp[lane], dst + lane);
-        __builtin_nontemporal_store(sp[lane + 64], dst + lane + 64);
-        __builtin_nontemporal_store(sp[lane + 128], dst + lane + 128);
+        if (ST_NT) {
+            __builtin_nontemporal_store(sp[192 + lane], val4 + tile * 64 + lane);
+            __builtin_nontemporal_store(sp[lane], dst + lane);
+            __builtin_nontemporal_store(sp[lane + 64], dst + lane + 64);
+            __builtin_nontemporal_store(sp[lane + 128], dst + lane + 128);
+        } else {
+            val4[tile * 64 + lane] = sp[192 + lane];
+            dst[lane] = sp[lane];
+            dst[lane + 64] = sp[lane + 64];
+            dst[lane + 128] = sp[lane + 128];
+        }
         PVAMD_WAVE_SYNC();
     }
 }
@@ -168,13 +180,20 @@ extern "C" int pvamd_cached_query(const pvamd_grid_t* grid, const float* points,
         const f32x4* p4 = reinterpret_cast<const f32x4*>(points);
         f32x4* v4 = reinterpret_cast<f32x4*>(out_val);
         f32x4* g4 = reinterpret_cast<f32x4*>(out_grad);
+        const bool big = P > ((int64_t)8 << 20);  // > 8M points (96 MB of xyz): streaming regime
+#define PVAMD_LAUNCH_CQ(F64_, OOB_)                                                                                      \
+    do {                                                                                                                \
+        if (big) hipLaunchKernelGGL((cached_query_wave<F64_, OOB_, true, false>), grid_dim, block, 0, s, *grid, p4, ntiles, v4, g4, out_oob); \
+        else hipLaunchKernelGGL((cached_query_wave<F64_, OOB_, false, true>), grid_dim, block, 0, s, *grid, p4, ntiles, v4, g4, out_oob);    \
+    } while (0)
         if (f64) {
-            if (out_oob) hipLaunchKernelGGL((cached_query_wave<true, true>), grid_dim, block, 0, s, *grid, p4, ntiles, v4, g4, out_oob);
-            else hipLaunchKernelGGL((cached_query_wave<true, false>), grid_dim, block, 0, s, *grid, p4, ntiles, v4, g4, out_oob);
+            if (out_oob) PVAMD_LAUNCH_CQ(true, true);
+            else PVAMD_LAUNCH_CQ(true, false);
         } else {
-            if (out_oob) hipLaunchKernelGGL((cached_query_wave<false, true>), grid_dim, block, 0, s, *grid, p4, ntiles, v4, g4, out_oob);
-            else hipLaunchKernelGGL((cached_query_wave<false, false>), grid_dim, block, 0, s, *grid, p4, ntiles, v4, g4, out_oob);
+            if (out_oob) PVAMD_LAUNCH_CQ(false, true);
+            else PVAMD_LAUNCH_CQ(false, false);
         }
+#undef PVAMD_LAUNCH_CQ
     }
     const int64_t first = ntiles * kTilePoints;
     if (first < P) {

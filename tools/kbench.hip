@@ -178,7 +178,7 @@ __global__ __launch_bounds__(256) void q_x3(const pvamd_grid_t g, const float* _
 }
 
 // ---- q_wave with the next tile's global loads issued before the current tile is processed ----
-template <bool F64, int WAVES>
+template <bool F64, int WAVES, int LDP = 0, int STP = 0>
 __global__ __launch_bounds__(WAVES * 64) void q_wave_pf(const pvamd_grid_t g, const f32x4* __restrict__ pts4, int64_t ntiles, f32x4* __restrict__ val4, f32x4* __restrict__ grad4) {
     __shared__ __attribute__((aligned(16))) float lds[WAVES][1024];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -188,11 +188,11 @@ __global__ __launch_bounds__(WAVES * 64) void q_wave_pf(const pvamd_grid_t g, co
     const int64_t wstride = (int64_t)gridDim.x * WAVES;
     int64_t tile = (int64_t)blockIdx.x * WAVES + wave;
     f32x4 a, b, c;
-    if (tile < ntiles) { const f32x4* src = pts4 + tile * 192; a = __builtin_nontemporal_load(src + lane); b = __builtin_nontemporal_load(src + lane + 64); c = __builtin_nontemporal_load(src + lane + 128); }
+    if (tile < ntiles) { const f32x4* src = pts4 + tile * 192; if (LDP) { a = src[lane]; b = src[lane + 64]; c = src[lane + 128]; } else { a = __builtin_nontemporal_load(src + lane); b = __builtin_nontemporal_load(src + lane + 64); c = __builtin_nontemporal_load(src + lane + 128); } }
     for (; tile < ntiles; tile += wstride) {
         sp[lane] = a; sp[lane + 64] = b; sp[lane + 128] = c;
         const int64_t nt = tile + wstride;
-        if (nt < ntiles) { const f32x4* src = pts4 + nt * 192; a = __builtin_nontemporal_load(src + lane); b = __builtin_nontemporal_load(src + lane + 64); c = __builtin_nontemporal_load(src + lane + 128); }
+        if (nt < ntiles) { const f32x4* src = pts4 + nt * 192; if (LDP) { a = src[lane]; b = src[lane + 64]; c = src[lane + 128]; } else { a = __builtin_nontemporal_load(src + lane); b = __builtin_nontemporal_load(src + lane + 64); c = __builtin_nontemporal_load(src + lane + 128); } }
         PVAMD_WAVE_SYNC();
         float px[4], py[4], pz[4];
 #pragma unroll
@@ -206,13 +206,24 @@ __global__ __launch_bounds__(WAVES * 64) void q_wave_pf(const pvamd_grid_t g, co
             svf[p] = r.x; spf[3 * p] = r.y; spf[3 * p + 1] = r.z; spf[3 * p + 2] = r.w;
         }
         PVAMD_WAVE_SYNC();
-        __builtin_nontemporal_store(sp[192 + lane], val4 + tile * 64 + lane);
         f32x4* dst = grad4 + tile * 192;
+        if (STP) { val4[tile * 64 + lane] = sp[192 + lane]; dst[lane] = sp[lane]; dst[lane + 64] = sp[lane + 64]; dst[lane + 128] = sp[lane + 128]; }
+        else {
+        __builtin_nontemporal_store(sp[192 + lane], val4 + tile * 64 + lane);
         __builtin_nontemporal_store(sp[lane], dst + lane);
         __builtin_nontemporal_store(sp[lane + 64], dst + lane + 64);
-        __builtin_nontemporal_store(sp[lane + 128], dst + lane + 128);
+        __builtin_nontemporal_store(sp[lane + 128], dst + lane + 128); }
         PVAMD_WAVE_SYNC();
     }
+}
+
+__global__ __launch_bounds__(256) void copy16_plain(const f32x4* __restrict__ in, f32x4* __restrict__ out, int64_t n) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) out[i] = in[i];
+}
+__global__ __launch_bounds__(256) void copy16_nt(const f32x4* __restrict__ in, f32x4* __restrict__ out, int64_t n) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) __builtin_nontemporal_store(__builtin_nontemporal_load(in + i), out + i);
 }
 
 static float frand() { return (float)rand() / (float)RAND_MAX; }
@@ -238,6 +249,7 @@ int main(int argc, char** argv) {
     for (int64_t i = 0; i < P; ++i) for (int d = 0; d < 3; ++d) hp[3 * i + d] = (float)(g.dmin[d] - margin + frand() * (g.dmax[d] - g.dmin[d] + 2 * margin));
     float *dp, *dval, *dgrad; CK(hipMalloc(&dp, P * 12)); CK(hipMalloc(&dval, P * 4)); CK(hipMalloc(&dgrad, P * 12));
     CK(hipMemcpy(dp, hp.data(), P * 12, hipMemcpyHostToDevice));
+    float* dout16; CK(hipMalloc(&dout16, P * 16));
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
     const int64_t ng = P / 4; const int64_t ntiles = P / 1024; const int64_t nwt = P / 256;
     const unsigned grid = (unsigned)std::min<int64_t>((ng + 255) / 256, 2048);
@@ -245,10 +257,14 @@ int main(int argc, char** argv) {
     const f32x4* p4 = (const f32x4*)dp; f32x4* v4 = (f32x4*)dval; f32x4* g4 = (f32x4*)dgrad;
     struct V { const char* name; int id; };
     std::vector<V> vs = {{"copy_linear(28B/pt)", 0}, {"copy_strided", 1}, {"q_strided f64 gather nt (product)", 2}, {"q_strided f32 gather nt", 3},
-                         {"q_strided f64 NOgather nt", 4}, {"q_strided f32 NOgather nt", 5}, {"q_strided f64 gather plain-ld/st", 6}, {"q_lds f64", 7}, {"q_lds f32", 8}, {"q_wave f64 plain W4", 9}, {"q_wave f64 ntgather W4", 10}, {"q_wave f32 plain W4", 11}, {"q_wave f64 plain W8", 12}, {"q_wave f64 plain W16", 13}, {"q_wave f64 plain W4 grid4096", 14}, {"q_x3 f64 unr4", 15}, {"q_x3 f64 unr2", 16}, {"q_x3 f64 unr1", 17}, {"q_x3 f64 unr8", 18}, {"q_wave_pf f64 W4 g2048", 19}, {"q_wave_pf f64 W4 g1024", 20}, {"q_x3 f32 unr4", 21}, {"PRODUCT libpvamd.so pvamd_cached_query", 22}};
+                         {"q_strided f64 NOgather nt", 4}, {"q_strided f32 NOgather nt", 5}, {"q_strided f64 gather plain-ld/st", 6}, {"q_lds f64", 7}, {"q_lds f32", 8}, {"q_wave f64 plain W4", 9}, {"q_wave f64 ntgather W4", 10}, {"q_wave f32 plain W4", 11}, {"q_wave f64 plain W8", 12}, {"q_wave f64 plain W16", 13}, {"q_wave f64 plain W4 grid4096", 14}, {"q_x3 f64 unr4", 15}, {"q_x3 f64 unr2", 16}, {"q_x3 f64 unr1", 17}, {"q_x3 f64 unr8", 18}, {"q_wave_pf f64 W4 g2048", 19}, {"q_wave_pf f64 W4 g1024", 20}, {"q_x3 f32 unr4", 21}, {"PRODUCT libpvamd.so pvamd_cached_query", 22}, {"q_wave_pf f64 plainLD ntST", 23}, {"q_wave_pf f64 ntLD plainST", 24}, {"q_wave_pf f64 plainLD plainST", 25}, {"copy16 plain (32B/elt: GB/s x 32/28)", 26}, {"copy16 nt", 27}};
     typedef int (*cq_t)(const pvamd_grid_t*, const float*, int64_t, float*, float*, uint8_t*, void*);
     void* so = dlopen("pytorch_volumetric_amd/csrc/libpvamd.so", RTLD_NOW);
     cq_t product = so ? (cq_t)dlsym(so, "pvamd_cached_query") : nullptr;
+    typedef int (*fin_t)(pvamd_grid_t*);
+    fin_t finalize = so ? (fin_t)dlsym(so, "pvamd_grid_finalize") : nullptr;
+    g.index_f64 = 1;  // the README flow (numpy ranges): float64 index semantics
+    if (finalize) finalize(&g); else printf("no pvamd_grid_finalize: variants that need the derived fields will misbehave\n");
     if (!product) printf("libpvamd.so not found (run from the repo root): product row is a no-op\n");
     std::vector<std::vector<float>> times(vs.size());
     auto launch = [&](int id) {
@@ -274,12 +290,16 @@ int main(int argc, char** argv) {
             case 19: hipLaunchKernelGGL((q_wave_pf<true, 4>), dim3((unsigned)std::min<int64_t>((nwt + 3) / 4, 2048)), dim3(256), 0, 0, g, p4, nwt, v4, g4); break;
             case 20: hipLaunchKernelGGL((q_wave_pf<true, 4>), dim3((unsigned)std::min<int64_t>((nwt + 3) / 4, 1024)), dim3(256), 0, 0, g, p4, nwt, v4, g4); break;
             case 21: hipLaunchKernelGGL((q_x3<false, 4>), dim3((unsigned)std::min<int64_t>((P + 1023) / 1024, 4096)), dim3(256), 0, 0, g, dp, P, dval, dgrad); break;
+            case 23: hipLaunchKernelGGL((q_wave_pf<true, 4, 1, 0>), dim3((unsigned)std::min<int64_t>((nwt + 3) / 4, 1024)), dim3(256), 0, 0, g, p4, nwt, v4, g4); break;
+            case 24: hipLaunchKernelGGL((q_wave_pf<true, 4, 0, 1>), dim3((unsigned)std::min<int64_t>((nwt + 3) / 4, 1024)), dim3(256), 0, 0, g, p4, nwt, v4, g4); break;
+            case 25: hipLaunchKernelGGL((q_wave_pf<true, 4, 1, 1>), dim3((unsigned)std::min<int64_t>((nwt + 3) / 4, 1024)), dim3(256), 0, 0, g, p4, nwt, v4, g4); break;
+            case 26: hipLaunchKernelGGL(copy16_plain, dim3(2048), dim3(256), 0, 0, p4, (f32x4*)dout16, P * 3 / 4); break;
+            case 27: hipLaunchKernelGGL(copy16_nt, dim3(2048), dim3(256), 0, 0, p4, (f32x4*)dout16, P * 3 / 4); break;
             case 22: if (product) product(&g, dp, P, dval, dgrad, nullptr, nullptr); break;
             case 14: hipLaunchKernelGGL((q_wave<true, 0, 4>), dim3((unsigned)std::min<int64_t>((nwt + 3) / 4, 4096)), dim3(256), 0, 0, g, p4, nwt, v4, g4); break;
         }
     };
     // copy_linear writes 16 B/pt: needs an output of P*16 bytes -> reuse a dedicated buffer
-    float* dout16; CK(hipMalloc(&dout16, P * 16));
     auto launch_fixed = [&](int id) { if (id == 0) hipLaunchKernelGGL(copy_linear, dim3(2048), dim3(256), 0, 0, p4, P * 3 / 4, (f32x4*)dout16, P); else launch(id); };
     for (size_t k = 0; k < vs.size(); ++k) launch_fixed(vs[k].id);
     CK(hipDeviceSynchronize());
