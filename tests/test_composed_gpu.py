@@ -147,3 +147,36 @@ def test_leaf_culling_is_exact_on_coherent_and_far_queries():
                                       tfm[:2].numpy(), 1, q.numpy())
     assert np.array_equal(v2.cpu().numpy(), ov[0], equal_nan=True)
     assert np.array_equal(g2.cpu().numpy(), og[0], equal_nan=True)
+
+
+def test_more_leaves_than_the_culling_table_holds():
+    """S = 70 > 64: leaves beyond the LDS culling table take the un-culled branch of the same loop."""
+    S = 70
+    leaf = make_leaf(res=0.02)
+    tfm = H.random_rigid(S, seed=9, trans=0.8)
+    comp = pv.ComposedSDF([leaf] * S, pv.Transform3d(matrix=tfm))
+    pts = scene_points(4096 + 3, seed=4, extent=1.0)
+    val, grad = comp(pts.cuda())
+    og = H.oracle_grid_from_cached(leaf)
+    oval, ograd, oleaf = oracle.composed_query([og] * S, tfm.numpy(), 1, pts.numpy())
+    assert np.array_equal(val.cpu().numpy(), oval[0], equal_nan=True)
+    assert np.array_equal(grad.cpu().numpy(), ograd[0], equal_nan=True)
+    assert oleaf.max() >= 64  # the late leaves do win somewhere
+
+
+def test_compose_of_mesh_sdfs_like_the_reference_test():
+    """tests/test_sdf.py:61-80 of the reference: two drills (MeshSDF leaves) placed with pure translations."""
+    obj = pv.MeshObjectFactory(H.mesh_path("ycb_power_drill.npz"))
+    sdf1, sdf2 = pv.MeshSDF(obj), pv.MeshSDF(obj)
+    tsf = pv.Translate(0.1, 0, 0).stack(pv.Translate(-0.2, 0, 0.2))
+    comp = pv.ComposedSDF([sdf1, sdf2], tsf)
+    _, pts = pv.get_coordinates_and_points_in_grid(0.002, obj.bounding_box(0.01))
+    pts = pts[torch.randperm(len(pts), generator=torch.Generator().manual_seed(0))[:1000]].cuda()
+    vals, grads = comp(pts)
+    assert vals.shape == (1000,) and grads.shape == (1000, 3)
+    v1, g1 = sdf1(pts + torch.tensor([0.1, 0.0, 0.0], device="cuda"))
+    v2, g2 = sdf2(pts + torch.tensor([-0.2, 0.0, 0.2], device="cuda"))
+    # the jitter is indexed by point number, so the per-leaf queries above see the same rays as inside the composition
+    expect = torch.minimum(v1, v2)
+    assert torch.allclose(vals, expect, atol=1e-6)
+    assert torch.allclose(grads, torch.where((v2 < v1).unsqueeze(-1), g2, g1), atol=1e-5)

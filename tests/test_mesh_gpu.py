@@ -159,3 +159,22 @@ def test_culling_is_exact_for_far_and_degenerate_queries():
     nan_pt = torch.tensor([[float("nan"), 0.0, 0.0], [0.5, 0.5, 3.0]])
     res = obj.object_frame_closest_point(nan_pt.cuda())
     assert torch.isnan(res.distance[0]) and abs(res.distance[1].item() - 2.0) < 1e-6
+
+
+def test_reference_debug_assertions_hold_for_a_mesh_backed_cache():
+    """The reference's in-source checks (sdf.py:508-512, 574-590, enabled by debug_check_sdf): voxel centres read back
+    their own value; the BOUNDING_BOX fallback under-approximates the true distance and points roughly the same way;
+    in-range values are within one resolution of ground truth."""
+    obj = factory("ycb_power_drill.npz")
+    gt = pv.MeshSDF(obj)
+    cached = pv.CachedSDF("drill", 0.01, obj.bounding_box(padding=0.1), gt, device="cuda", cache_path=None,
+                          debug_check_sdf=True)  # runs the centre check in __init__ and the one-voxel check per call
+    lo = np.array([r[0] for r in cached.ranges]) - 0.3
+    hi = np.array([r[1] for r in cached.ranges]) + 0.3
+    pts = H.uniform_points(20_000, lo, hi, seed=3).cuda()
+    val, grad = cached(pts)
+    oob = ~cached.voxels.get_valid_values(pts)
+    v_gt, g_gt = gt(pts[oob])
+    assert (v_gt - val[oob] > 0).all()                                   # sdf.py:576-578
+    cos = torch.cosine_similarity(g_gt, grad[oob], dim=-1)               # sdf.py:580-582
+    assert (cos > 0.7).all() and cos.mean() > 0.95
