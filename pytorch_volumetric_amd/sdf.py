@@ -357,12 +357,16 @@ class CachedSDF(ObjectFrameSDF):
         if val is None or clean_cache:
             if gt_sdf is None:
                 raise RuntimeError("Cached SDF did not find the cache and requires an initialize queryable SDF")
-            coords, pts = get_coordinates_and_points_in_grid(self.resolution, self.ranges)
-            sdf_val, sdf_grad = gt_sdf(pts)  # with a MeshSDF this is the brute-force kernel over every voxel centre
-            val = sdf_val.reshape([len(coord) for coord in coords]).cpu()
-            grad = sdf_grad.reshape(-1, 3).cpu()
+            # per-axis coordinates exactly as the reference builds them (fp32 arange on the host); their cartesian
+            # product is formed on the GPU so that a 10^7-voxel grid never exists in host memory
+            coords, _ = get_coordinates_and_points_in_grid(self.resolution, self.ranges, get_points=False)
+            dev_q = _lib.require_gpu()
+            pts = torch.cartesian_prod(*[c.to(dev_q) for c in coords])
+            sdf_val, sdf_grad = gt_sdf(pts)  # with a MeshSDF this is the mesh kernel over every voxel centre
+            val = sdf_val.reshape([len(coord) for coord in coords])
+            grad = sdf_grad.reshape(-1, 3)
             if cache_path is not None:
-                data[self.name] = val, grad
+                data[self.name] = val.cpu(), grad.cpu()
                 torch.save(data, cache_path)
                 logger.info("caching sdf for %s to %s", self.name, cache_path)
 
