@@ -226,10 +226,12 @@ def main():
             v1, g1 = comp(qq.reshape(3, 500, 3))
             out["composed/single/tf"], out["composed/points"] = M[:S].numpy(), qq.numpy()
             out["composed/single/val"], out["composed/single/grad"] = v1.numpy(), g1.numpy()  # FLAT (P,) / (P,3)
+            out["composed/single/bbox"] = comp.surface_bounding_box(padding=0.02).numpy()     # sdf.py:347-368
             comp.set_transforms(ShimTransform3d(matrix=M), batch_dim=(A,))
             v2, g2 = comp(qq.reshape(3, 500, 3))
             out["composed/batched/tf"] = M.numpy()
             out["composed/batched/val"], out["composed/batched/grad"] = v2.numpy(), g2.numpy()  # (4,3,500[,3])
+            out["composed/batched/bbox"] = comp.surface_bounding_box(padding=0.02).numpy()
         os.remove(cache_file)
 
     np.savez_compressed(OUT, **out)

@@ -240,3 +240,24 @@ def test_voxel_containers_thin_port():
     vs = pv.VoxelSet(torch.zeros(0, 3), torch.zeros(0))
     vs[q] = torch.tensor([1.0, 1.0])
     assert vs.get_known_pos_and_values()[0].shape == (2, 3)
+
+
+def test_composed_surface_bounding_box_matches_the_reference_glue():
+    """sdf.py:347-368 run verbatim (make_golden.py group B), including its choice of transforming only the min-row and
+    max-row of each leaf box."""
+    class Leaf(pv.ObjectFrameSDF):
+        def __init__(self):
+            self.s = pv.SphereSDF(float(G["sphere/radius"]))
+
+        def __call__(self, p):
+            return self.s(p)
+
+        def surface_bounding_box(self, **kw):
+            return self.s.surface_bounding_box(**kw)
+
+    comp = pv.ComposedSDF([Leaf()] * 3, torch.from_numpy(G["composed/single/tf"]))
+    assert np.allclose(comp.surface_bounding_box(padding=0.02).numpy(), G["composed/single/bbox"], atol=1e-6)
+    comp.set_transforms(torch.from_numpy(G["composed/batched/tf"]), batch_dim=(4,))
+    bb = comp.surface_bounding_box(padding=0.02)
+    assert bb.shape == tuple(G["composed/batched/bbox"].shape) == (4, 3, 2)
+    assert np.allclose(bb.numpy(), G["composed/batched/bbox"], atol=1e-6)
