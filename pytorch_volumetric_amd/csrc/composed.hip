@@ -108,8 +108,11 @@ PVAMD_DEV bool leaf_cannot_win(const float* __restrict__ c, float px, float py, 
 // through a wave-private LDS slice (same scheme as cached_query_wave, see cached.hip).
 constexpr int kWavesPerBlock = 4;
 constexpr int kTilePoints = 256;
+#ifndef PVAMD_COMPOSED_PPP
+#define PVAMD_COMPOSED_PPP 2
+#endif
 
-template <bool ANY_F64>
+template <bool ANY_F64, int PPP>
 __global__ __launch_bounds__(kWavesPerBlock * 64) void composed_query_wave(const pvamd_grid_t* __restrict__ grids, int S,
                                                                            const float* __restrict__ tf, int A,
                                                                            const f32x4* __restrict__ pts4,
@@ -133,43 +136,46 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void composed_query_wave(const
         sp[lane + 64] = src[lane + 64];
         sp[lane + 128] = src[lane + 128];
         PVAMD_WAVE_SYNC();
-        float px[4], py[4], pz[4];
-        Best best[4];
+        // PPP points per lane go through the leaf loop together (fewer live registers -> more waves per SIMD; the
+        // leaf constants are scalar loads, so re-walking the leaves per pass costs SALU/SMEM, not VALU)
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const int p = lane + 64 * k;
-            px[k] = spf[3 * p];
-            py[k] = spf[3 * p + 1];
-            pz[k] = spf[3 * p + 2];
-            best[k] = Best{0.f, 0.f, 0.f, 0.f, -1, false};
-        }
-        PVAMD_WAVE_SYNC();
-        for (int s = 0; s < S; ++s) {
-            if (s < kMaxCullLeaves) {
-                const float* c = cull[s];  // wave-uniform: LDS broadcast
-                const bool dead = (int)leaf_cannot_win(c, px[0], py[0], pz[0], best[0]) &
-                                  (int)leaf_cannot_win(c, px[1], py[1], pz[1], best[1]) &
-                                  (int)leaf_cannot_win(c, px[2], py[2], pz[2], best[2]) &
-                                  (int)leaf_cannot_win(c, px[3], py[3], pz[3], best[3]);
-                if (__all(dead)) continue;
+        for (int h = 0; h < 4; h += PPP) {
+            float px[PPP], py[PPP], pz[PPP];
+            Best best[PPP];
+#pragma unroll
+            for (int k = 0; k < PPP; ++k) {
+                const int p = lane + 64 * (h + k);
+                px[k] = spf[3 * p];
+                py[k] = spf[3 * p + 1];
+                pz[k] = spf[3 * p + 2];
+                best[k] = Best{0.f, 0.f, 0.f, 0.f, -1, false};
             }
-            const float* M = tf + 16 * ((int64_t)s * A + a);  // wave-uniform: scalar loads
-            const pvamd_grid_t& g = grids[s];
+            for (int s = 0; s < S; ++s) {
+                if (s < kMaxCullLeaves) {
+                    const float* c = cull[s];  // wave-uniform: LDS broadcast
+                    bool dead = true;
 #pragma unroll
-            for (int k = 0; k < 4; ++k) visit_leaf<ANY_F64>(g, M, s, px[k], py[k], pz[k], best[k]);
-        }
+                    for (int k = 0; k < PPP; ++k) dead = dead && leaf_cannot_win(c, px[k], py[k], pz[k], best[k]);
+                    if (__all(dead)) continue;
+                }
+                const float* M = tf + 16 * ((int64_t)s * A + a);  // wave-uniform: scalar loads
+                const pvamd_grid_t& g = grids[s];
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const int p = lane + 64 * k;
-            // per-lane winner: these matrix reads are vector loads, but the S*A stack is tiny and cache-resident
-            const float* M = tf + 16 * ((int64_t)best[k].s * A + a);
-            float gx, gy, gz;
-            rotate_back(M, best[k], gx, gy, gz);
-            svf[p] = best[k].v;
-            spf[3 * p] = gx;
-            spf[3 * p + 1] = gy;
-            spf[3 * p + 2] = gz;
-            if (leaf) leaf[(int64_t)a * P + tile * kTilePoints + p] = best[k].s;
+                for (int k = 0; k < PPP; ++k) visit_leaf<ANY_F64>(g, M, s, px[k], py[k], pz[k], best[k]);
+            }
+#pragma unroll
+            for (int k = 0; k < PPP; ++k) {
+                const int p = lane + 64 * (h + k);
+                // per-lane winner: these matrix reads are vector loads, but the S*A stack is tiny and cache-resident
+                const float* M = tf + 16 * ((int64_t)best[k].s * A + a);
+                float gx, gy, gz;
+                rotate_back(M, best[k], gx, gy, gz);
+                svf[p] = best[k].v;  // a lane overwrites only the LDS slots of the points it owns
+                spf[3 * p] = gx;
+                spf[3 * p + 1] = gy;
+                spf[3 * p + 2] = gz;
+                if (leaf) leaf[(int64_t)a * P + tile * kTilePoints + p] = best[k].s;
+            }
         }
         PVAMD_WAVE_SYNC();
         const int64_t o = (int64_t)a * P + tile * kTilePoints;  // multiple of 4: rows start 16-byte aligned
@@ -227,7 +233,7 @@ extern "C" int pvamd_composed_query(const pvamd_grid_t* grids, int32_t S, const 
     if (ntiles > 0) {
         const int64_t need = (ntiles + kWavesPerBlock - 1) / kWavesPerBlock;
         const unsigned gx = (unsigned)(need < cap ? need : (cap < 1 ? 1 : cap));
-        hipLaunchKernelGGL((composed_query_wave<true>), dim3(gx, A), dim3(kWavesPerBlock * 64), 0, s, grids, S, tf, A,
+        hipLaunchKernelGGL((composed_query_wave<true, PVAMD_COMPOSED_PPP>), dim3(gx, A), dim3(kWavesPerBlock * 64), 0, s, grids, S, tf, A,
                            reinterpret_cast<const f32x4*>(points), ntiles, P, out_val, out_grad, out_leaf);
     }
     const int64_t first = ntiles * kTilePoints;
