@@ -229,7 +229,7 @@ def main():
             "parity": {"checked_points": n_chk, "max_abs_val_err_vs_oracle": max_err,
                        "grad_mismatches_vs_oracle": grad_mismatch},
         }
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:  # the CPU baseline is timed on rank 0 of the 1-GPU run only
             out["cpu_baseline"] = cpu_baseline(cached, pts, args.cpu_seconds)
 
     if not args.no_large and rank == 0 and world == 1:
