@@ -139,6 +139,10 @@ class RobotSDF(sdf.ObjectFrameSDF):
         """
         return self.sdf(points_in_object_frame)
 
+    def query_into(self, points, out_val, out_grad):
+        """Allocation-free form of __call__ (see ComposedSDF.query_into); outputs are (A,P) and (A,P,3)."""
+        self.sdf.query_into(points, out_val, out_grad)
+
 
 def cache_link_sdf_factory(resolution=0.01, padding=0.1, **kwargs):
     """model_to_sdf.py:128-133"""

@@ -588,6 +588,25 @@ class ComposedSDF(ObjectFrameSDF):
             val, grad = val.reshape(-1), grad.reshape(-1, 3)
         return val.to(device=out_device, dtype=dtype), grad.to(device=out_device, dtype=dtype)
 
+    def query_into(self, points, out_val, out_grad):
+        """Allocation-free fused query for inner loops / graph capture: contiguous fp32 (P,3) GPU points, results into
+        the caller's fp32 (A,P) / (A,P,3) buffers (A = number of configurations, 1 without a transform batch).  Needs
+        every leaf to be a BOUNDING_BOX CachedSDF.  One C-ABI call, one kernel launch on the current stream."""
+        if not self._fusable():
+            raise ValueError("query_into needs every leaf to be a CachedSDF with the BOUNDING_BOX strategy")
+        A = math.prod(self.tsf_batch) if self.tsf_batch is not None else 1
+        P = points.shape[0]
+        if not (points.is_cuda and points.dtype == torch.float32 and points.is_contiguous() and points.shape == (P, 3)):
+            raise ValueError("query_into needs contiguous fp32 (P,3) points on the GPU")
+        if out_val.numel() != A * P or out_grad.numel() != 3 * A * P or out_val.dtype != torch.float32 or \
+                out_grad.dtype != torch.float32 or not (out_val.is_contiguous() and out_grad.is_contiguous()):
+            raise ValueError("query_into needs contiguous fp32 outputs with A*P and A*P*3 elements")
+        dev = points.device
+        _lib.check(_lib.load().pvamd_composed_query(_lib.ptr(self._leaf_grids(dev)), len(self.sdfs),
+                                                    _lib.ptr(self._tf_device(dev)), A, _lib.ptr(points), P,
+                                                    _lib.ptr(out_val), _lib.ptr(out_grad), None, _lib.stream_ptr()),
+                   "pvamd_composed_query")
+
     def _generic(self, flat, S, A):
         """Leaves that are not cached grids (MeshSDF, SphereSDF, nested compositions): per-leaf query kernels with
         the transform / rotate-back / first-minimum glue done on device."""

@@ -134,3 +134,49 @@ def test_on_device_fk_matches_oracle_bitwise_and_torch_fk(tmp_path):
     fk = chain.forward_kinematics(q)
     ref = torch.cat([fk[n].get_matrix() for n in leaves])
     assert torch.allclose(lw.cpu(), ref, atol=2e-6)
+
+
+def test_query_into_and_graph_replay(tmp_path):
+    """A planner-style inner loop: set_joint_configuration + query_into captured once in a hipGraph and replayed."""
+    chain = synthetic_arm(str(tmp_path))
+    s = pv.RobotSDF(chain, path_prefix=str(tmp_path),
+                    link_sdf_cls=pv.cache_link_sdf_factory(resolution=0.02, padding=0.2, device="cuda", cache_path=None))
+    A, P = 16, 4096
+    q = torch.randn(A, 7, generator=torch.Generator().manual_seed(3)) * 0.5
+    s.set_joint_configuration(q)
+    pts = H.uniform_points(P, [-0.6, -0.6, -0.2], [0.6, 0.6, 1.4], seed=2).cuda().contiguous()
+    ref_v, ref_g = s(pts)
+    val = torch.empty((A, P), device="cuda")
+    grad = torch.empty((A, P, 3), device="cuda")
+    s.query_into(pts, val, grad)
+    assert torch.equal(val, ref_v) and torch.equal(grad.nan_to_num(5.), ref_g.nan_to_num(5.))
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph, stream=side):
+            s.query_into(pts, val, grad)
+    torch.cuda.current_stream().wait_stream(side)
+    val.zero_()
+    graph.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(val, ref_v)
+
+
+def test_sharded_sdf_over_rccl_single_rank():
+    """The nccl (= RCCL) code path of ShardedSDF on one GPU: device tensors through all_gather_into_tensor."""
+    import torch.distributed as dist
+    from tests.test_cached_gpu import make_cached, query_points
+    if not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        c = make_cached()
+        pts = query_points(c, 10_001, seed=4).cuda()
+        v, g = c(pts)
+        sv, sg = pv.ShardedSDF(c)(pts.reshape(73, 137, 3))
+        assert sv.shape == (73, 137) and sv.is_cuda
+        assert torch.equal(sv.reshape(-1), v) and torch.equal(sg.reshape(-1, 3).nan_to_num(3.), g.nan_to_num(3.))
+    finally:
+        dist.destroy_process_group()
