@@ -450,8 +450,11 @@ static MeshArgs mesh_args(const pvamd_mesh_t& mesh) {
 // medial axis of the mesh is equidistant to much of the surface and must test most triangles exactly), so even when
 // there are plenty of points a group is split over 8 waves: it bounds the slowest group's time at 1/8 (measured on
 // C5: 45 ms with one wave per group -> see profiles/), at the price of repeating the per-tile bookkeeping per wave.
+#ifndef PVAMD_BIG_SLICES
+#define PVAMD_BIG_SLICES 8
+#endif
 static int pick_slices(int64_t point_tiles) {
-    return point_tiles >= (int64_t)kNumCU * 16 ? 8 : 16;
+    return point_tiles >= (int64_t)kNumCU * 16 ? PVAMD_BIG_SLICES : 16;
 }
 
 }  // namespace pvamd
