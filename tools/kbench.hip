@@ -226,6 +226,36 @@ __global__ __launch_bounds__(256) void copy16_nt(const f32x4* __restrict__ in, f
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) __builtin_nontemporal_store(__builtin_nontemporal_load(in + i), out + i);
 }
 
+// ---- 64-point sub-tiles, software-pipelined inside each wave: one point per lane per pass, the next sub-tile's loads in
+// flight while the current one is looked up.  Meant for SMALL batches (1M points), where a wave otherwise owns a single
+// 256-point tile and all waves march through load -> gather -> store in lockstep. ----
+template <bool F64, int WAVES>
+__global__ __launch_bounds__(WAVES * 64) void q_wave64(const pvamd_grid_t g, const f32x4* __restrict__ pts4, int64_t nsub, f32x4* __restrict__ val4, f32x4* __restrict__ grad4) {
+    __shared__ __attribute__((aligned(16))) float lds[WAVES][256];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    float* spf = lds[wave];
+    f32x4_alias* sp = reinterpret_cast<f32x4_alias*>(spf);
+    const int64_t wstride = (int64_t)gridDim.x * WAVES;
+    int64_t sub = (int64_t)blockIdx.x * WAVES + wave;
+    f32x4 a = {0.f, 0.f, 0.f, 0.f};
+    if (sub < nsub && lane < 48) a = pts4[sub * 48 + lane];
+    for (; sub < nsub; sub += wstride) {
+        if (lane < 48) sp[lane] = a;
+        const int64_t nx = sub + wstride;
+        if (nx < nsub && lane < 48) a = pts4[nx * 48 + lane];
+        PVAMD_WAVE_SYNC();
+        const float px = spf[3 * lane], py = spf[3 * lane + 1], pz = spf[3 * lane + 2];
+        PVAMD_WAVE_SYNC();
+        bool valid;
+        const float4 r = cached_lookup<F64>(g, px, py, pz, valid);
+        spf[192 + lane] = r.x; spf[3 * lane] = r.y; spf[3 * lane + 1] = r.z; spf[3 * lane + 2] = r.w;
+        PVAMD_WAVE_SYNC();
+        if (lane < 16) __builtin_nontemporal_store(sp[48 + lane], val4 + sub * 16 + lane);
+        if (lane < 48) __builtin_nontemporal_store(sp[lane], grad4 + sub * 48 + lane);
+        PVAMD_WAVE_SYNC();
+    }
+}
+
 static float frand() { return (float)rand() / (float)RAND_MAX; }
 
 int main(int argc, char** argv) {
@@ -257,7 +287,7 @@ int main(int argc, char** argv) {
     const f32x4* p4 = (const f32x4*)dp; f32x4* v4 = (f32x4*)dval; f32x4* g4 = (f32x4*)dgrad;
     struct V { const char* name; int id; };
     std::vector<V> vs = {{"copy_linear(28B/pt)", 0}, {"copy_strided", 1}, {"q_strided f64 gather nt (product)", 2}, {"q_strided f32 gather nt", 3},
-                         {"q_strided f64 NOgather nt", 4}, {"q_strided f32 NOgather nt", 5}, {"q_strided f64 gather plain-ld/st", 6}, {"q_lds f64", 7}, {"q_lds f32", 8}, {"q_wave f64 plain W4", 9}, {"q_wave f64 ntgather W4", 10}, {"q_wave f32 plain W4", 11}, {"q_wave f64 plain W8", 12}, {"q_wave f64 plain W16", 13}, {"q_wave f64 plain W4 grid4096", 14}, {"q_x3 f64 unr4", 15}, {"q_x3 f64 unr2", 16}, {"q_x3 f64 unr1", 17}, {"q_x3 f64 unr8", 18}, {"q_wave_pf f64 W4 g2048", 19}, {"q_wave_pf f64 W4 g1024", 20}, {"q_x3 f32 unr4", 21}, {"PRODUCT libpvamd.so pvamd_cached_query", 22}, {"q_wave_pf f64 plainLD ntST", 23}, {"q_wave_pf f64 ntLD plainST", 24}, {"q_wave_pf f64 plainLD plainST", 25}, {"copy16 plain (32B/elt: GB/s x 32/28)", 26}, {"copy16 nt", 27}};
+                         {"q_strided f64 NOgather nt", 4}, {"q_strided f32 NOgather nt", 5}, {"q_strided f64 gather plain-ld/st", 6}, {"q_lds f64", 7}, {"q_lds f32", 8}, {"q_wave f64 plain W4", 9}, {"q_wave f64 ntgather W4", 10}, {"q_wave f32 plain W4", 11}, {"q_wave f64 plain W8", 12}, {"q_wave f64 plain W16", 13}, {"q_wave f64 plain W4 grid4096", 14}, {"q_x3 f64 unr4", 15}, {"q_x3 f64 unr2", 16}, {"q_x3 f64 unr1", 17}, {"q_x3 f64 unr8", 18}, {"q_wave_pf f64 W4 g2048", 19}, {"q_wave_pf f64 W4 g1024", 20}, {"q_x3 f32 unr4", 21}, {"PRODUCT libpvamd.so pvamd_cached_query", 22}, {"q_wave_pf f64 plainLD ntST", 23}, {"q_wave_pf f64 ntLD plainST", 24}, {"q_wave_pf f64 plainLD plainST", 25}, {"copy16 plain (32B/elt: GB/s x 32/28)", 26}, {"copy16 nt", 27}, {"q_wave64 f64 W4 g1024", 28}, {"q_wave64 f64 W4 g2048", 29}, {"q_wave64 f64 W4 g4096", 30}, {"q_wave64 f64 W8 g1024", 31}};
     typedef int (*cq_t)(const pvamd_grid_t*, const float*, int64_t, float*, float*, uint8_t*, void*);
     void* so = dlopen("pytorch_volumetric_amd/csrc/libpvamd.so", RTLD_NOW);
     cq_t product = so ? (cq_t)dlsym(so, "pvamd_cached_query") : nullptr;
@@ -295,6 +325,10 @@ int main(int argc, char** argv) {
             case 25: hipLaunchKernelGGL((q_wave_pf<true, 4, 1, 1>), dim3((unsigned)std::min<int64_t>((nwt + 3) / 4, 1024)), dim3(256), 0, 0, g, p4, nwt, v4, g4); break;
             case 26: hipLaunchKernelGGL(copy16_plain, dim3(2048), dim3(256), 0, 0, p4, (f32x4*)dout16, P * 3 / 4); break;
             case 27: hipLaunchKernelGGL(copy16_nt, dim3(2048), dim3(256), 0, 0, p4, (f32x4*)dout16, P * 3 / 4); break;
+            case 28: hipLaunchKernelGGL((q_wave64<true, 4>), dim3((unsigned)std::min<int64_t>((P / 64 + 3) / 4, 1024)), dim3(256), 0, 0, g, p4, P / 64, v4, g4); break;
+            case 29: hipLaunchKernelGGL((q_wave64<true, 4>), dim3((unsigned)std::min<int64_t>((P / 64 + 3) / 4, 2048)), dim3(256), 0, 0, g, p4, P / 64, v4, g4); break;
+            case 30: hipLaunchKernelGGL((q_wave64<true, 4>), dim3((unsigned)std::min<int64_t>((P / 64 + 3) / 4, 4096)), dim3(256), 0, 0, g, p4, P / 64, v4, g4); break;
+            case 31: hipLaunchKernelGGL((q_wave64<true, 8>), dim3((unsigned)std::min<int64_t>((P / 64 + 7) / 8, 1024)), dim3(512), 0, 0, g, p4, P / 64, v4, g4); break;
             case 22: if (product) product(&g, dp, P, dval, dgrad, nullptr, nullptr); break;
             case 14: hipLaunchKernelGGL((q_wave<true, 0, 4>), dim3((unsigned)std::min<int64_t>((nwt + 3) / 4, 4096)), dim3(256), 0, 0, g, p4, nwt, v4, g4); break;
         }
