@@ -111,3 +111,26 @@ def test_c5_shape_sphere_mesh_chamfer_slice_matches_analytic():
     err = pv.batch_chamfer_dist(W, pts, obj, scale=1.0)
     ref = ((pts.norm(dim=-1) - 0.1) ** 2).mean()
     assert abs(err.item() - ref.item()) < 1e-5 * max(1.0, ref.item()) + 2e-6
+
+
+def test_full_size_c5_properties():
+    """BASELINE C5 at full size (2,097,152 source points -> 99,500-triangle sphere): analytic answer, permutation
+    invariance, quadratic scaling, additivity over a split of the points (what the multi-GPU all-reduce relies on)."""
+    r = 0.1
+    obj = pv.MeshObjectFactory(mesh=mesh_io.uv_sphere_mesh(r, 250, 200))
+    N = 1 << 21
+    pts = H.uniform_points(N, [-0.15] * 3, [0.15] * 3, seed=2).cuda()
+    W = torch.eye(4).unsqueeze(0).cuda()
+    e1 = pv.batch_chamfer_dist(W, pts, obj, scale=1.0)
+    ref = ((pts.norm(dim=-1) - r) ** 2).double().mean()
+    # faceting error of the lat-long sphere is ~ r (1 - cos(pi/250)) = 8e-6 in distance
+    assert abs(e1.item() - ref.item()) < 2e-6
+    perm = torch.randperm(N, device="cuda", generator=torch.Generator(device="cuda").manual_seed(1))
+    e2 = pv.batch_chamfer_dist(W, pts[perm], obj, scale=1.0)
+    assert abs(e1.item() - e2.item()) <= 1e-6 * e1.item()
+    e3 = pv.batch_chamfer_dist(W, pts, obj, scale=1000.0)
+    assert abs(e3.item() / e1.item() - 1e6) < 1.0
+    half = N // 2
+    ea = pv.batch_chamfer_dist(W, pts[:half], obj, scale=1.0)
+    eb = pv.batch_chamfer_dist(W, pts[half:], obj, scale=1.0)
+    assert abs(0.5 * (ea.item() + eb.item()) - e1.item()) <= 1e-6 * e1.item()

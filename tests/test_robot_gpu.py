@@ -180,3 +180,34 @@ def test_sharded_sdf_over_rccl_single_rank():
         assert torch.equal(sv.reshape(-1), v) and torch.equal(sg.reshape(-1, 3).nan_to_num(3.), g.nan_to_num(3.))
     finally:
         dist.destroy_process_group()
+
+
+def test_full_size_c4_properties(tmp_path):
+    """BASELINE C4 at full size (8 links, 200 configurations x 262,144 points = 52.4M pairs, 839 MB of output): parity
+    through size-independent properties -- config batch == single-config queries, determinism, a slice vs the oracle."""
+    chain = synthetic_arm(str(tmp_path))
+    s = pv.RobotSDF(chain, path_prefix=str(tmp_path),
+                    link_sdf_cls=pv.cache_link_sdf_factory(resolution=0.02, padding=0.1, device="cuda", cache_path=None))
+    A, P = 200, 1 << 18
+    th0 = torch.tensor([0.0, -np.pi / 4, 0.0, np.pi / 2, 0.0, np.pi / 4, 0.0])
+    th = torch.cat((th0.view(1, -1), th0 + torch.randn(A - 1, 7, generator=torch.Generator().manual_seed(0)) * 0.1))
+    pts = H.uniform_points(P, [-0.7, -0.7, -0.2], [0.7, 0.7, 1.5], seed=1).cuda()
+    s.set_joint_configuration(th)
+    val, grad = s(pts)
+    assert val.shape == (A, P) and grad.shape == (A, P, 3)
+    stack = s.object_to_link_frames.get_matrix().clone()  # (S*A,4,4) leaf-major, from the FK + MFMA kernels
+    v2, _ = s(pts)
+    assert torch.equal(val, v2)
+    for a in (0, 57, 199):
+        s.set_joint_configuration(th[a])
+        v, g = s(pts)
+        assert torch.equal(v, val[a]) and torch.equal(g.nan_to_num(4.), grad[a].nan_to_num(4.))
+    # oracle on a slice: 3 configurations x 20,000 points, same transform stack
+    S = len(s.sdf.sdfs)
+    sel = [0, 57, 199]
+    tf_sel = stack.reshape(S, A, 4, 4)[:, sel].reshape(-1, 4, 4).cpu().numpy()
+    ogrids = [H.oracle_grid_from_cached(leaf) for leaf in s.sdf.sdfs]
+    ov, og, _ = oracle.composed_query(ogrids, tf_sel, len(sel), pts[:20_000].cpu().numpy())
+    assert np.array_equal(val[sel, :20_000].cpu().numpy(), ov, equal_nan=True)
+    assert np.array_equal(grad[sel, :20_000].cpu().numpy(), og, equal_nan=True)
+    assert (val < 0).any()  # some points are inside the arm
