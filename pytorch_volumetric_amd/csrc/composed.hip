@@ -96,12 +96,16 @@ PVAMD_DEV void build_cull_spheres(const pvamd_grid_t* __restrict__ grids, int S,
     }
 }
 
-// true when leaf `c` provably cannot replace the incumbent minimum of this point
-PVAMD_DEV bool leaf_cannot_win(const float* __restrict__ c, float px, float py, float pz, const Best& best) {
+// 1 when leaf `c` provably cannot replace the incumbent minimum of this point.  Straight-line (no short-circuit): the
+// compiler turned the && / || form into a tree of exec-mask branches that kept the scalar unit busier than the test.
+PVAMD_DEV int leaf_cannot_win(const float* __restrict__ c, float px, float py, float pz, const Best& best) {
     const float dx = px - c[0], dy = py - c[1], dz = pz - c[2];
     const float d2 = fmaf(dz, dz, fmaf(dy, dy, dx * dx));
     const float t = best.v + c[4];
-    return (best.s >= 0) && (d2 > c[3]) && ((t <= 0.f) || (d2 >= t * t * 1.0003f));
+    const int has_best = best.s >= 0;
+    const int out_of_range = d2 > c[3];
+    const int beaten = (int)(t <= 0.f) | (int)(d2 >= t * t * 1.0003f);
+    return has_best & out_of_range & beaten;
 }
 
 // One wave = 256 consecutive points of one configuration per pass; all global traffic in contiguous 1 KB pieces
@@ -153,9 +157,9 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void composed_query_wave(const
             for (int s = 0; s < S; ++s) {
                 if (s < kMaxCullLeaves) {
                     const float* c = cull[s];  // wave-uniform: LDS broadcast
-                    bool dead = true;
+                    int dead = 1;
 #pragma unroll
-                    for (int k = 0; k < PPP; ++k) dead = dead && leaf_cannot_win(c, px[k], py[k], pz[k], best[k]);
+                    for (int k = 0; k < PPP; ++k) dead &= leaf_cannot_win(c, px[k], py[k], pz[k], best[k]);
                     if (__all(dead)) continue;
                 }
                 const float* M = tf + 16 * ((int64_t)s * A + a);  // wave-uniform: scalar loads
