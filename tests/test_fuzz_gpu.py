@@ -1,0 +1,129 @@
+"""-m gpu: randomized differential tests, HIP path vs CPU oracle, over many small random configurations -- grid
+shapes and resolutions, ranges far from the origin (where the fp32 index estimate has to fall back to the exact
+division often), float32/float64 index arithmetic, random meshes and poses, awkward point counts."""
+import numpy as np
+import pytest
+import torch
+
+import pytorch_volumetric_amd as pv
+from oracle import oracle
+from pytorch_volumetric_amd import mesh_io
+from tests import helpers as H
+
+pytestmark = pytest.mark.gpu
+
+
+class BoxGT(pv.ObjectFrameSDF):
+    """analytic box SDF as ground truth for arbitrary grids"""
+
+    def __init__(self, lo, hi):
+        self.lo, self.hi = torch.tensor(lo, dtype=torch.float64), torch.tensor(hi, dtype=torch.float64)
+
+    def __call__(self, p):
+        c, h = ((self.lo + self.hi) / 2).to(p.device), ((self.hi - self.lo) / 2).to(p.device)
+        q = (p.double() - c).abs() - h
+        v = q.clamp(min=0).norm(dim=-1) + q.max(dim=-1).values.clamp(max=0)
+        g = torch.nn.functional.normalize(torch.sign(p.double() - c) * (q >= q.max(dim=-1, keepdim=True).values), dim=-1)
+        return v.to(p.dtype), g.to(p.dtype)
+
+    def surface_bounding_box(self, padding=0., padding_ratio=0.):
+        return torch.stack((self.lo - padding, self.hi + padding), dim=1)
+
+
+def random_cached(rng, f64, far=False):
+    centre = rng.uniform(-1, 1, 3) * (1000.0 if far else 1.0)
+    half = rng.uniform(0.05, 0.4, 3)
+    res = float(rng.choice([0.013, 0.02, 0.05, 0.1]))
+    pad = float(rng.uniform(0.0, 0.3))
+    lo, hi = centre - half, centre + half
+    rng_np = np.stack((lo - pad, hi + pad), axis=1)
+    rng_in = rng_np if f64 else [(float(a), float(b)) for a, b in rng_np]
+    c = pv.CachedSDF("fuzz", res, rng_in, BoxGT(lo, hi), device="cuda", cache_path=None)
+    return c, rng_np
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_cached_query_fuzz(seed):
+    rng = np.random.default_rng(seed)
+    f64, far = bool(seed % 2), seed % 3 == 0
+    c, r = random_cached(rng, f64, far)
+    og = H.oracle_grid_from_cached(c)
+    n = int(rng.choice([1, 63, 255, 256, 257, 4097, 50_001]))
+    span = r[:, 1] - r[:, 0]
+    pts = (r[:, 0] - 0.2 * span + rng.random((n, 3)) * 1.4 * span).astype(np.float32)
+    # sprinkle exact voxel centres, half-voxel planes, range corners and specials
+    k = min(n, 40)
+    view = c._view
+    mn = (view.dmin if f64 else view.fmin).double().numpy()
+    rs = (view.dres if f64 else view.fres).double().numpy()
+    idx = rng.integers(0, np.array(view.shape), size=(k, 3))
+    pts[:k] = (mn + (idx + rng.choice([0.0, 0.5, 0.4999999, 0.5000001], size=(k, 3))) * rs).astype(np.float32)
+    if n > 45:
+        pts[41] = [np.nan, pts[41, 1], pts[41, 2]]
+        pts[42] = [np.inf, 0, 0]
+        pts[43] = (r[:, 0]).astype(np.float32)
+        pts[44] = (r[:, 1]).astype(np.float32)
+    t = torch.from_numpy(pts).cuda()
+    val, grad = c(t)
+    oval, ograd, ooob = oracle.cached_query(og, pts)
+    assert np.array_equal(val.cpu().numpy(), oval, equal_nan=True)
+    assert np.array_equal(grad.cpu().numpy(), ograd, equal_nan=True)
+    key = c.voxels.ensure_index_key(t).cpu().numpy()
+    okey, _, ovalid = oracle.voxel_index(og, pts)
+    finite = np.isfinite(pts).all(axis=1)
+    assert np.array_equal(key[finite], okey[finite])
+    assert np.array_equal(c.voxels.get_valid_values(t).cpu().numpy(), ovalid)
+    assert np.array_equal(c.outside_surface(t, 0.01).cpu().numpy(), oracle.cached_outside(og, pts, 0.01))
+
+
+@pytest.mark.parametrize("seed", range(8))
+def test_composed_query_fuzz(seed):
+    rng = np.random.default_rng(100 + seed)
+    S, A = int(rng.integers(1, 12)), int(rng.choice([1, 2, 5]))
+    leaves = [random_cached(rng, bool(rng.integers(0, 2)))[0] for _ in range(S)]
+    tfm = H.random_rigid(S * A, seed=seed, trans=1.5)
+    comp = pv.ComposedSDF(leaves, None)
+    comp.set_transforms(tfm, batch_dim=(A,) if A > 1 else None)
+    n = int(rng.choice([7, 256, 1000, 4096, 10_003]))
+    pts = (rng.random((n, 3)) * 6 - 3).astype(np.float32)
+    val, grad = comp(torch.from_numpy(pts).cuda())
+    oval, ograd, _ = oracle.composed_query([H.oracle_grid_from_cached(l) for l in leaves], tfm.numpy(), A, pts)
+    assert np.array_equal(val.cpu().numpy().reshape(A, -1), oval, equal_nan=True)
+    assert np.array_equal(grad.cpu().numpy().reshape(A, -1, 3), ograd, equal_nan=True)
+
+
+def random_mesh(rng):
+    kind = rng.integers(0, 3)
+    if kind == 0:
+        m = mesh_io.uv_sphere_mesh(float(rng.uniform(0.05, 0.5)), int(rng.integers(5, 40)), int(rng.integers(3, 20)),
+                                   scale=tuple(rng.uniform(0.3, 1.5, 3)), center=tuple(rng.uniform(-1, 1, 3)))
+    elif kind == 1:
+        m = mesh_io.box_mesh(tuple(rng.uniform(0.05, 1.0, 3)), tuple(rng.uniform(-2, 2, 3)))
+    else:  # triangle soup with no structure at all (open, self-intersecting): parity must still hold
+        v = rng.uniform(-1, 1, (int(rng.integers(4, 300)), 3))
+        f = rng.integers(0, len(v), (int(rng.integers(1, 700)), 3))
+        f = f[(f[:, 0] != f[:, 1]) & (f[:, 1] != f[:, 2]) & (f[:, 0] != f[:, 2])]
+        m = mesh_io.TriMesh(v, f if len(f) else np.array([[0, 1, 2]]))
+    return m
+
+
+@pytest.mark.parametrize("seed", range(10))
+def test_mesh_query_and_chamfer_fuzz(seed):
+    rng = np.random.default_rng(200 + seed)
+    obj = pv.MeshObjectFactory(mesh=random_mesh(rng))
+    om = H.oracle_mesh_from_factory(obj)
+    bb = obj.bounding_box(padding_ratio=0.6)
+    n = int(rng.choice([1, 64, 65, 700, 2048, 5001]))
+    pts = (bb[:, 0] + rng.random((n, 3)) * (bb[:, 1] - bb[:, 0])).astype(np.float32)
+    obj.jitter_seed = 1000 + seed
+    res = obj.object_frame_closest_point(torch.from_numpy(pts).cuda(), compute_normal=True)
+    oc, od, og, of, on = oracle.mesh_query(om, pts, seed=1000 + seed)
+    assert np.array_equal(obj._last_face_ids.cpu().numpy(), of)
+    assert np.array_equal(res.closest.cpu().numpy(), oc)
+    assert np.array_equal(res.distance.cpu().numpy(), od)
+    assert np.array_equal(res.gradient.cpu().numpy(), og, equal_nan=True)
+    B = int(rng.integers(1, 6))
+    W = H.random_rigid(B, seed=seed, trans=0.3)
+    err = pv.batch_chamfer_dist(W, torch.from_numpy(pts), obj, scale=10.0)
+    oerr = oracle.chamfer_mesh(om, W.numpy(), pts, scale=10.0) / n
+    assert np.allclose(err.double().numpy(), oerr, rtol=1e-6, atol=1e-12)
