@@ -14,16 +14,21 @@ class CachedOpForOp:
         self.shape = tuple(val_grid.shape)
         self.voxels_grad = grad_flat                  # sdf.py:523
         self.vmin, self.vmax = vmin, vmax
-        self.res = (vmax - vmin) / (torch.tensor(self.shape) - 1)
+        self.res = (vmax - vmin) / (torch.tensor(self.shape, device=vmin.device) - 1)
         self.bb = bb
+
+    def to(self, device):
+        """Same op sequence on another device (e.g. the stock torch-ROCm kernels on the MI355X itself)."""
+        return CachedOpForOp(self.raw_data.reshape(self.shape).to(device), self.voxels_grad.to(device),
+                             self.vmin.to(device), self.vmax.to(device), self.bb.to(device))
 
     def __call__(self, pts):
         keys = torch.round((pts - self.vmin) / self.res).to(torch.long)                    # :537
         ravelled = (keys[..., 0] * self.shape[1] + keys[..., 1]) * self.shape[2] + keys[..., 2]  # :538
         inbound = ((self.vmin <= pts) & (pts <= self.vmax)).all(dim=-1)                    # :540
         oob = ~inbound                                                                      # :541
-        val = torch.zeros(ravelled.shape, dtype=pts.dtype)                                  # :546
-        grad = torch.zeros(keys.shape, dtype=pts.dtype)                                     # :547
+        val = torch.zeros(ravelled.shape, dtype=pts.dtype, device=pts.device)               # :546
+        grad = torch.zeros(keys.shape, dtype=pts.dtype, device=pts.device)                  # :547
         val[inbound] = self.raw_data[ravelled[inbound]]                                     # :549
         grad[inbound] = self.voxels_grad[ravelled[inbound]]                                 # :550
         p = pts[oob]                                                                        # :552

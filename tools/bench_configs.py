@@ -100,6 +100,27 @@ def main():
     torch.cuda.synchronize()
     out["cache_build_drill_0.01"] = {"voxels": int(np.prod(cached._view.shape)), "wall_s": time.perf_counter() - t0}
 
+    # ---------------- C2 side by side: the reference's op sequence with stock torch-ROCm kernels on the same GPU -------
+    from oracle.torch_opforop import CachedOpForOp
+    packed = cached._packed
+    ref_gpu = CachedOpForOp(packed[:, 0].reshape(cached._view.shape).contiguous(), packed[:, 1:4].contiguous(),
+                            cached._view.min.cuda(), cached._view.max.cuda(), cached.bb)
+    lo2 = torch.tensor([r[0] for r in cached.ranges], dtype=torch.float32) - 0.05
+    hi2 = torch.tensor([r[1] for r in cached.ranges], dtype=torch.float32) + 0.05
+    pts2 = H.uniform_points(1 << 20, lo2, hi2, seed=7).cuda()
+    t_ref, _ = gpu_time(lambda: ref_gpu(pts2), reps=20)
+    t_ours, _ = gpu_time(lambda: cached(pts2), reps=50)
+    v_ref, g_ref = ref_gpu(pts2)
+    v_our, g_our = cached(pts2)
+    inb = cached.voxels.get_valid_values(pts2)
+    out["C2_vs_reference_ops_on_same_gpu"] = {
+        "points": 1 << 20, "reference_op_sequence_torch_rocm_s": t_ref, "this_build_python_call_s": t_ours,
+        "ratio": t_ref / t_ours,
+        "max_abs_val_diff": float((v_ref - v_our).abs().max()),
+        "in_range_bit_identical": bool(torch.equal(v_ref[inb], v_our[inb]) and torch.equal(g_ref[inb], g_our[inb])),
+        "note": "oracle/torch_opforop.py = sdf.py:535-571 op for op (index helper restated); includes the boolean-mask "
+                "compactions and their host syncs, as a reference user would see them on this GPU"}
+
     # ---------------- C3: ComposedSDF of 8 transformed drills, 4M points ----------------
     S, P3 = 8, 1 << 22
     tfm = H.random_rigid(S, seed=0)
