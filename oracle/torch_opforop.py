@@ -45,3 +45,39 @@ class CachedOpForOp:
         grad[oob] = dtotal / dist.unsqueeze(-1)                                             # :570
         val[oob] = dist                                                                     # :571
         return val, grad
+
+
+class ComposedOpForOp:
+    """ComposedSDF.__call__ (reference sdf.py:392-433) op for op: broadcast transform of all points into every leaf
+    frame (materialising (S*A, P, 3)), a Python loop of per-leaf CachedSDF calls, gradient rotation by the inverse
+    transforms, cat, argmin over leaves, gather.  TEST INFRASTRUCTURE ONLY (timed next to the fused kernel)."""
+
+    def __init__(self, leaves, obj_to_leaf, batch=None):
+        self.leaves = leaves                     # list of CachedOpForOp
+        self.m = obj_to_leaf                     # (S*A, 4, 4), leaf-major
+        self.batch = batch                       # A or None
+        self.m_inv = torch.linalg.inv(obj_to_leaf)  # :380
+
+    def __call__(self, points):
+        pts_shape = points.shape
+        p = points.reshape(-1, 3)                                                        # :395
+        S = len(self.leaves)
+        A = self.batch or 1
+        x = p.unsqueeze(0) @ self.m[:, :3, :3].transpose(-1, -2) + self.m[:, None, :3, 3]  # :399 (S*A, P, 3)
+        x = x.reshape(S, A, *p.shape)                                                    # :402
+        vs, gs = [], []
+        for i, leaf in enumerate(self.leaves):                                           # :405
+            v, g = leaf(x[i])                                                            # :407
+            rot = self.m_inv[i * A:(i + 1) * A, :3, :3]
+            g = g @ rot.transpose(-1, -2)                                                # :409 transform_normals
+            vs.append(v)
+            gs.append(g)
+        v = torch.cat(vs).reshape(S, -1)                                                 # :414-418
+        g = torch.cat(gs).reshape(S, -1, 3)
+        closest = torch.argmin(v, 0)                                                     # :421
+        idx = torch.arange(0, v.shape[1], device=v.device)
+        vv, gg = v[closest, idx], g[closest, idx]                                        # :425-426
+        if self.batch is not None:
+            vv = vv.reshape(A, *pts_shape[:-1])
+            gg = gg.reshape(A, *pts_shape[:-1], 3)
+        return vv, gg

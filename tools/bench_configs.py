@@ -134,6 +134,16 @@ def main():
         "points": P3, "leaves": S, "gpu_s": t, "gpu_queries_per_s": P3 / t, "algorithmic_GBs": 28 * P3 / t / 1e9,
         "frac_hbm_peak": 28 * P3 / t / 1e9 / HBM_PEAK, "includes": "python call + output allocation",
         "cpu_queries_per_s": 400_000 / tc}
+    from oracle.torch_opforop import ComposedOpForOp
+    ref_comp = ComposedOpForOp([ref_gpu] * S, tfm.cuda())
+    t_refc, _ = gpu_time(lambda: ref_comp(pts3), warm=1, reps=5)
+    v_r, _ = ref_comp(pts3[:200_000])
+    v_o, _ = comp(pts3[:200_000])
+    out["C3_composed_8_drills_4M"]["reference_op_sequence_on_same_gpu"] = {
+        "gpu_s": t_refc, "ratio_vs_this_build": t_refc / t,
+        "values_within_1e-6": float(torch.isclose(v_r, v_o, atol=1e-6).float().mean())}
+    del ref_comp
+    torch.cuda.empty_cache()
     # the same count of points on a regular grid (the README's query pattern): spatially coherent waves
     n_side = round(P3 ** (1 / 3))
     ax = torch.linspace(-0.5, 0.5, n_side)
@@ -161,6 +171,16 @@ def main():
         "frac_hbm_peak": 16 * pairs4 / t / 1e9 / HBM_PEAK, "set_joint_configuration_s": t_cfg,
         "link_grid_voxels": [int(np.prod(s._view.shape)) for s in robot.sdf.sdfs],
         "note": "synthetic KUKA-like arm (KUKA assets unavailable offline); link caches res 0.02 pad 0.1"}
+    leaves_ref = []
+    for leaf in robot.sdf.sdfs:
+        pk = leaf._packed
+        leaves_ref.append(CachedOpForOp(pk[:, 0].reshape(leaf._view.shape).contiguous(), pk[:, 1:4].contiguous(),
+                                        leaf._view.min.cuda(), leaf._view.max.cuda(), leaf.bb))
+    ref_robot = ComposedOpForOp(leaves_ref, robot.object_to_link_frames.get_matrix(), batch=A)
+    t_refr, _ = gpu_time(lambda: ref_robot(pts4), warm=1, reps=3)
+    out["C4_robot_8links"]["reference_op_sequence_on_same_gpu"] = {"gpu_s": t_refr, "ratio_vs_this_build": t_refr / t}
+    del ref_robot, leaves_ref
+    torch.cuda.empty_cache()
     n4 = round(P4 ** (1 / 3))
     grid4 = torch.cartesian_prod(torch.linspace(-0.7, 0.7, n4), torch.linspace(-0.7, 0.7, n4),
                                  torch.linspace(-0.2, 1.5, n4))
