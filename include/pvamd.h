@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define PVAMD_ABI_VERSION 2
+#define PVAMD_ABI_VERSION 3
 
 #define PVAMD_E_NULL      (-1)  /* a required pointer is NULL            */
 #define PVAMD_E_SHAPE     (-2)  /* a size/shape argument is out of range */
@@ -75,14 +75,18 @@ typedef struct pvamd_grid {
  * normal:  device [F][3] fp32 unit face normals (sdf.py:119-120), indexed by ORIGINAL face id
  * rec:     device [F][PVAMD_TRI_REC] per-triangle records written by pvamd_mesh_prepare, in the (spatially sorted)
  *          order the caller chose; each record carries its original face id
- * tiles:   device [ceil(F/PVAMD_TRI_TILE)][4] bounding sphere (cx, cy, cz, r) of each run of PVAMD_TRI_TILE records
+ * tiles:   device float[PVAMD_TILES_FLOATS(F)]: [T][4] bounding sphere (cx, cy, cz, r) of each run of PVAMD_TRI_TILE
+ *          records (T = ceil(F/PVAMD_TRI_TILE)), followed by [T][PVAMD_TRI_TILE/PVAMD_TRI_GROUP][4] spheres of each run
+ *          of PVAMD_TRI_GROUP records
  * rec_of_face: device [F] int32, position of the record of original face id f (inverse of the chosen order)
  * ray_dir: the reference passes bounding_box(padding=1.0)[:,1] as the last three floats of each ray
  *          (sdf.py:147-152); open3d reads those as the ray DIRECTION (tnear=0, tfar=inf).  Kept as float64
  *          because the reference adds its jitter in float64 before rounding to float32 (sdf.py:149-150).
  */
-#define PVAMD_TRI_REC  28   /* floats per prepared triangle record */
-#define PVAMD_TRI_TILE 256  /* triangles per LDS tile / per tile sphere */
+#define PVAMD_TRI_REC   24   /* floats per prepared triangle record */
+#define PVAMD_TRI_TILE  256  /* triangles per LDS tile / per tile sphere */
+#define PVAMD_TRI_GROUP 16   /* triangles per group sphere */
+#define PVAMD_TILES_FLOATS(F) ((((F) + PVAMD_TRI_TILE - 1) / PVAMD_TRI_TILE) * (4 + 4 * (PVAMD_TRI_TILE / PVAMD_TRI_GROUP)))
 typedef struct pvamd_mesh {
     const float* normal;     /* device */
     const float* rec;        /* device */
@@ -143,14 +147,15 @@ int pvamd_composed_query(const pvamd_grid_t* grids, int32_t S, const float* tf, 
                          const float* points, int64_t P,
                          float* out_val, float* out_grad, int32_t* out_leaf, void* stream);
 
-/* Prepare a mesh for the query kernels: per-triangle records (corners, edge vectors, geometric normal for the ray
- * test, bounding sphere, original face id) and one bounding sphere per run of PVAMD_TRI_TILE records.  The spheres only
- * ever SKIP work that provably cannot change a result (they are inflated by abs_margin and a relative 1e-5), so query
- * results are bit-identical to the untiled brute force whatever order the triangles are given in; spatially sorted
- * input (e.g. Morton order of centroids) is what makes the skipping effective.
+/* Prepare a mesh for the query kernels: per-triangle records (corners, original face id, bounding sphere, and the
+ * triangle's in-plane bounding rectangle: centre, two unit axes, half extents) plus one bounding sphere per run of
+ * PVAMD_TRI_GROUP and of PVAMD_TRI_TILE records.  The bounds only ever SKIP work that provably cannot change a result
+ * (computed in float64 for the rounded values stored, inflated by abs_margin and a relative 1e-5), so query results
+ * are bit-identical to the untiled brute force whatever order the triangles are given in; spatially sorted input
+ * (e.g. Morton order of centroids) is what makes the skipping effective.
  * tri: device [F][3][3] fp32 soup in the order to process.  face_id: device [F] int32 original ids, or NULL for 0..F-1.
  * abs_margin: absolute slack, >= 1e-6 * (largest |vertex coordinate| + bounding-box diagonal).
- * rec_out: device [F][PVAMD_TRI_REC] (16-byte aligned).  tiles_out: device [ceil(F/PVAMD_TRI_TILE)][4].
+ * rec_out: device [F][PVAMD_TRI_REC] (16-byte aligned).  tiles_out: device float[PVAMD_TILES_FLOATS(F)].
  * rec_of_face_out: device [F] int32.                                                                            */
 int pvamd_mesh_prepare(const float* tri, const int32_t* face_id, int32_t F, float abs_margin, float* rec_out,
                        float* tiles_out, int32_t* rec_of_face_out, void* stream);

@@ -11,11 +11,17 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libpvamd.so")
 
-ABI_VERSION = 2
+ABI_VERSION = 3
 OOB_LOOKUP_GT_SDF = 0
 OOB_BOUNDING_BOX = 1
-TRI_REC = 28
+TRI_REC = 24
 TRI_TILE = 256
+TRI_GROUP = 16
+
+
+def tiles_floats(F):
+    """PVAMD_TILES_FLOATS(F): tile spheres followed by group spheres."""
+    return ((F + TRI_TILE - 1) // TRI_TILE) * (4 + 4 * (TRI_TILE // TRI_GROUP))
 
 _c_float_p = ctypes.POINTER(ctypes.c_float)
 

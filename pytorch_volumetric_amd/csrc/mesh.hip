@@ -19,9 +19,18 @@
 
 namespace pvamd {
 
-constexpr int kRec = PVAMD_TRI_REC;    // floats per record
-constexpr int kTile = PVAMD_TRI_TILE;  // records per tile: 256 * 112 B = 28 KB of LDS
-// record layout (float index): 0-2 ctr, 3 r | 4-6 a, 7 face id bits | 8-10 b | 12-14 c | 16-18 ab | 20-22 ac | 24-26 Ng
+constexpr int kRec = PVAMD_TRI_REC;      // floats per record
+constexpr int kTile = PVAMD_TRI_TILE;    // records per tile: 256 * 96 B = 24 KB of LDS
+constexpr int kGroup = PVAMD_TRI_GROUP;  // records per group: own bounding sphere
+constexpr int kGroupsPerTile = kTile / kGroup;
+// record layout (float index):
+//   0-2 ctr, 3 r       bounding sphere (ctr = centre of the in-plane bounding rectangle)
+//   4-6 u,   7 hu      unit vector along the longest edge, half extent of the triangle along it (about ctr)
+//   8-10 v, 11 hv      unit in-plane vector across it, half extent
+//  12-14 a, 15 face id (bits)
+//  16-18 b, 19 m0      m0: absolute slack of the rectangle test (plane fit + rounding of the frame)
+//  20-22 c, 23 0
+// `tiles` buffer: [ntiles][4] tile spheres, then [ntiles][16][4] group spheres.
 
 struct MeshArgs {
     const float* normal;
@@ -33,47 +42,107 @@ struct MeshArgs {
 };
 
 // ---------------------------------------------------------------------------------------------------------------
-// prepare
+// prepare (double precision throughout; every stored bound is rounded outwards)
 // ---------------------------------------------------------------------------------------------------------------
+struct D3 { double x, y, z; };
+PVAMD_DEV D3 d3(double x, double y, double z) { return D3{x, y, z}; }
+PVAMD_DEV D3 dsub(D3 a, D3 b) { return d3(a.x - b.x, a.y - b.y, a.z - b.z); }
+PVAMD_DEV double ddot(D3 a, D3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+PVAMD_DEV D3 dcross(D3 a, D3 b) { return d3(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x); }
+PVAMD_DEV D3 dscale(D3 a, double k) { return d3(a.x * k, a.y * k, a.z * k); }
+PVAMD_DEV D3 dunit(D3 a, D3 fallback) {
+    const double n = sqrt(ddot(a, a));
+    return (n > 0.0 && n < 1e300) ? dscale(a, 1.0 / n) : fallback;
+}
+PVAMD_DEV double dmax3(double a, double b, double c) { return fmax(a, fmax(b, c)); }
+PVAMD_DEV double dmin3(double a, double b, double c) { return fmin(a, fmin(b, c)); }
+
 __global__ __launch_bounds__(256) void mesh_prepare_records(const float* __restrict__ tri, const int* __restrict__ face_id,
                                                             int F, float abs_margin, float* __restrict__ rec) {
     const int f = blockIdx.x * blockDim.x + threadIdx.x;
     if (f >= F) return;
     const float* t = tri + 9 * (int64_t)f;
-    const V3 a = v3(t[0], t[1], t[2]), b = v3(t[3], t[4], t[5]), c = v3(t[6], t[7], t[8]);
-    const V3 ab = sub(b, a), ac = sub(c, a);
-    const V3 Ng = cross(ac, sub(a, b));  // Embree: e1 = v0 - v1, e2 = v2 - v0, Ng = cross(e2, e1)
-    // bounding sphere: centroid + largest corner distance, inflated so that round-off can never make it too small
-    const V3 ctr = v3((a.x + b.x + c.x) * (1.f / 3.f), (a.y + b.y + c.y) * (1.f / 3.f), (a.z + b.z + c.z) * (1.f / 3.f));
-    const V3 da = sub(a, ctr), db = sub(b, ctr), dc = sub(c, ctr);
-    const float r2 = fmaxf(dot(da, da), fmaxf(dot(db, db), dot(dc, dc)));
-    const float r = sqrt_rn(r2) * 1.00001f + abs_margin;
+    const D3 A = d3(t[0], t[1], t[2]), B = d3(t[3], t[4], t[5]), C = d3(t[6], t[7], t[8]);
+    // frame: u along the longest edge, n the plane normal, v = n x u
+    const D3 eab = dsub(B, A), ebc = dsub(C, B), eca = dsub(A, C);
+    const double lab = ddot(eab, eab), lbc = ddot(ebc, ebc), lca = ddot(eca, eca);
+    D3 e = eab;
+    if (lbc > lab && lbc >= lca) e = ebc;
+    else if (lca > lab && lca > lbc) e = eca;
+    const D3 U = dunit(e, d3(1.0, 0.0, 0.0));
+    // a vector not parallel to U, for triangles without a usable normal (zero area)
+    const double ax = fabs(U.x), ay = fabs(U.y), az = fabs(U.z);
+    const D3 axis = (ax <= ay && ax <= az) ? d3(1.0, 0.0, 0.0) : (ay <= az ? d3(0.0, 1.0, 0.0) : d3(0.0, 0.0, 1.0));
+    const D3 Nd = dunit(dcross(eab, dsub(C, A)), dunit(dcross(U, axis), d3(0.0, 0.0, 1.0)));
+    const D3 V = dunit(dcross(Nd, U), axis);
+    // what the kernels will actually use: the frame rounded to fp32
+    const float uf[3] = {(float)U.x, (float)U.y, (float)U.z}, vf[3] = {(float)V.x, (float)V.y, (float)V.z};
+    const D3 Uf = d3(uf[0], uf[1], uf[2]), Vf = d3(vf[0], vf[1], vf[2]);
+    const D3 Nf = dunit(dcross(Uf, Vf), Nd);
+    // centre of the bounding rectangle (and of the plane slab) in that frame, then rounded to fp32
+    const D3 rb = dsub(B, A), rc = dsub(C, A);
+    const double ub = ddot(Uf, rb), uc = ddot(Uf, rc), vb = ddot(Vf, rb), vc = ddot(Vf, rc), nb = ddot(Nf, rb), nc = ddot(Nf, rc);
+    const double um = 0.5 * (dmin3(0.0, ub, uc) + dmax3(0.0, ub, uc)), vm = 0.5 * (dmin3(0.0, vb, vc) + dmax3(0.0, vb, vc)),
+                 nm = 0.5 * (dmin3(0.0, nb, nc) + dmax3(0.0, nb, nc));
+    const float cf[3] = {(float)(A.x + Uf.x * um + Vf.x * vm + Nf.x * nm), (float)(A.y + Uf.y * um + Vf.y * vm + Nf.y * nm),
+                         (float)(A.z + Uf.z * um + Vf.z * vm + Nf.z * nm)};
+    const D3 Cf = d3(cf[0], cf[1], cf[2]);
+    // extents about the ROUNDED centre in the ROUNDED frame: valid for exactly the numbers the kernels see
+    const D3 qa = dsub(A, Cf), qb = dsub(B, Cf), qc = dsub(C, Cf);
+    const double hu = dmax3(fabs(ddot(Uf, qa)), fabs(ddot(Uf, qb)), fabs(ddot(Uf, qc)));
+    const double hv = dmax3(fabs(ddot(Vf, qa)), fabs(ddot(Vf, qb)), fabs(ddot(Vf, qc)));
+    const double sl = dmax3(fabs(ddot(Nf, qa)), fabs(ddot(Nf, qb)), fabs(ddot(Nf, qc)));
+    const double r = sqrt(dmax3(ddot(qa, qa), ddot(qb, qb), ddot(qc, qc)));
     float* o = rec + (int64_t)kRec * f;
-    o[0] = ctr.x; o[1] = ctr.y; o[2] = ctr.z; o[3] = r;
-    o[4] = a.x; o[5] = a.y; o[6] = a.z; o[7] = __int_as_float(face_id ? face_id[f] : f);
-    o[8] = b.x; o[9] = b.y; o[10] = b.z; o[11] = 0.f;
-    o[12] = c.x; o[13] = c.y; o[14] = c.z; o[15] = 0.f;
-    o[16] = ab.x; o[17] = ab.y; o[18] = ab.z; o[19] = 0.f;
-    o[20] = ac.x; o[21] = ac.y; o[22] = ac.z; o[23] = 0.f;
-    o[24] = Ng.x; o[25] = Ng.y; o[26] = Ng.z; o[27] = 0.f;
+    o[0] = cf[0]; o[1] = cf[1]; o[2] = cf[2]; o[3] = (float)(r * 1.00001) + abs_margin;
+    o[4] = uf[0]; o[5] = uf[1]; o[6] = uf[2]; o[7] = (float)(hu * 1.00001) + abs_margin;
+    o[8] = vf[0]; o[9] = vf[1]; o[10] = vf[2]; o[11] = (float)(hv * 1.00001) + abs_margin;
+    o[12] = t[0]; o[13] = t[1]; o[14] = t[2]; o[15] = __int_as_float(face_id ? face_id[f] : f);
+    o[16] = t[3]; o[17] = t[4]; o[18] = t[5]; o[19] = (float)(1.01e6 * sl * sl) + abs_margin * abs_margin;
+    o[20] = t[6]; o[21] = t[7]; o[22] = t[8]; o[23] = 0.f;
 }
 
-// one block per tile: sphere around the mean of the member centres, radius = max(|c_i - mean| + r_i), inflated
+// sphere around the mean of `width` consecutive lanes' record centres, radius = max(|c_i - mean| + r_i), inflated
+PVAMD_DEV void enclose(bool live, float cx, float cy, float cz, float r, int width, float abs_margin, float out[4]) {
+    float sx = live ? cx : 0.f, sy = live ? cy : 0.f, sz = live ? cz : 0.f, sn = live ? 1.f : 0.f;
+    for (int off = width / 2; off > 0; off >>= 1) {
+        sx += __shfl_xor(sx, off, 64); sy += __shfl_xor(sy, off, 64);
+        sz += __shfl_xor(sz, off, 64); sn += __shfl_xor(sn, off, 64);
+    }
+    sn = fmaxf(sn, 1.f);
+    const float mx = sx / sn, my = sy / sn, mz = sz / sn;
+    float reach = 0.f;
+    if (live) {
+        const float dx = cx - mx, dy = cy - my, dz = cz - mz;
+        reach = sqrt_rn(dx * dx + dy * dy + dz * dz) * 1.00001f + r;
+    }
+    for (int off = width / 2; off > 0; off >>= 1) reach = fmaxf(reach, __shfl_xor(reach, off, 64));
+    out[0] = mx; out[1] = my; out[2] = mz;
+    out[3] = reach * 1.00001f + abs_margin;
+}
+
+// one block per tile: the tile sphere and its 16 group spheres
 __global__ __launch_bounds__(256) void mesh_prepare_tiles(const float* __restrict__ rec, int F, float abs_margin,
                                                           float* __restrict__ tiles) {
     __shared__ float sh[4][4];
-    const int tile = blockIdx.x;
+    const int tile = blockIdx.x, ntiles = gridDim.x;
     const int f = tile * kTile + threadIdx.x;
     const bool live = f < F;
     const float* o = rec + (int64_t)kRec * (live ? f : (F - 1));
-    float cx = live ? o[0] : 0.f, cy = live ? o[1] : 0.f, cz = live ? o[2] : 0.f, n = live ? 1.f : 0.f;
-    float sx = cx, sy = cy, sz = cz, sn = n;
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) {
-        sx += __shfl_down(sx, off, 64); sy += __shfl_down(sy, off, 64);
-        sz += __shfl_down(sz, off, 64); sn += __shfl_down(sn, off, 64);
-    }
+    const float cx = o[0], cy = o[1], cz = o[2], r = o[3];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    float g[4];
+    enclose(live, cx, cy, cz, r, kGroup, abs_margin, g);
+    if (live && (threadIdx.x % kGroup) == 0) {
+        float* w = tiles + 4 * (int64_t)ntiles + 4 * ((int64_t)tile * kGroupsPerTile + threadIdx.x / kGroup);
+        w[0] = g[0]; w[1] = g[1]; w[2] = g[2]; w[3] = g[3];
+    }
+    // the tile: same construction over all of its records
+    float sx = live ? cx : 0.f, sy = live ? cy : 0.f, sz = live ? cz : 0.f, sn = live ? 1.f : 0.f;
+    for (int off = 32; off > 0; off >>= 1) {
+        sx += __shfl_xor(sx, off, 64); sy += __shfl_xor(sy, off, 64);
+        sz += __shfl_xor(sz, off, 64); sn += __shfl_xor(sn, off, 64);
+    }
     if (lane == 0) { sh[wave][0] = sx; sh[wave][1] = sy; sh[wave][2] = sz; sh[wave][3] = sn; }
     __syncthreads();
     const float tn = sh[0][3] + sh[1][3] + sh[2][3] + sh[3][3];
@@ -84,16 +153,15 @@ __global__ __launch_bounds__(256) void mesh_prepare_tiles(const float* __restric
     float reach = 0.f;
     if (live) {
         const float dx = cx - mx, dy = cy - my, dz = cz - mz;
-        reach = sqrt_rn(dx * dx + dy * dy + dz * dz) * 1.00001f + o[3];
+        reach = sqrt_rn(dx * dx + dy * dy + dz * dz) * 1.00001f + r;
     }
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) reach = fmaxf(reach, __shfl_down(reach, off, 64));
+    for (int off = 32; off > 0; off >>= 1) reach = fmaxf(reach, __shfl_xor(reach, off, 64));
     if (lane == 0) sh[wave][0] = reach;
     __syncthreads();
     if (threadIdx.x == 0) {
-        float* t = tiles + 4 * (int64_t)tile;
-        t[0] = mx; t[1] = my; t[2] = mz;
-        t[3] = fmaxf(fmaxf(sh[0][0], sh[1][0]), fmaxf(sh[2][0], sh[3][0])) * 1.00001f + abs_margin;
+        float* w = tiles + 4 * (int64_t)tile;
+        w[0] = mx; w[1] = my; w[2] = mz;
+        w[3] = fmaxf(fmaxf(sh[0][0], sh[1][0]), fmaxf(sh[2][0], sh[3][0])) * 1.00001f + abs_margin;
     }
 }
 
@@ -105,81 +173,10 @@ PVAMD_DEV float norm3_unfused(V3 g) {
     return sqrt_rn(add_rn(add_rn(mul_rn(g.x, g.x), mul_rn(g.y, g.y)), mul_rn(g.z, g.z)));
 }
 
-// Ericson's closest point with the triangle's edge vectors precomputed (same operations as closest_point_triangle)
-PVAMD_DEV V3 closest_point_prepared(V3 p, V3 a, V3 b, V3 c, V3 ab, V3 ac) {
-    const V3 ap = sub(p, a);
-    const float d1 = dot(ab, ap), d2 = dot(ac, ap);
-    if (d1 <= 0.f && d2 <= 0.f) return a;
-    const V3 bp = sub(p, b);
-    const float d3 = dot(ab, bp), d4 = dot(ac, bp);
-    if (d3 >= 0.f && d4 <= d3) return b;
-    const V3 cp = sub(p, c);
-    const float d5 = dot(ab, cp), d6 = dot(ac, cp);
-    if (d6 >= 0.f && d5 <= d6) return c;
-    const float vc = fmaf(d1, d4, -mul_rn(d3, d2));
-    if (vc <= 0.f && d1 >= 0.f && d3 <= 0.f) return madd(div_rn(d1, sub_rn(d1, d3)), ab, a);
-    const float vb = fmaf(d5, d2, -mul_rn(d1, d6));
-    if (vb <= 0.f && d2 >= 0.f && d6 <= 0.f) return madd(div_rn(d2, sub_rn(d2, d6)), ac, a);
-    const float va = fmaf(d3, d6, -mul_rn(d5, d4));
-    const float d43 = sub_rn(d4, d3), d56 = sub_rn(d5, d6);
-    if (va <= 0.f && d43 >= 0.f && d56 >= 0.f) return madd(div_rn(d43, add_rn(d43, d56)), sub(c, b), b);
-    const float denom = div_rn(1.f, add_rn(add_rn(va, vb), vc));
-    return madd(mul_rn(vc, denom), ac, madd(mul_rn(vb, denom), ab, a));
-}
-
-// Embree's Moeller-Trumbore test with the geometric normal precomputed (same operations as ray_hits_triangle:
-// e1 = a - b = -ab and C = a - org = -ap are exact negations, so the dot products below are the same numbers)
-PVAMD_DEV int ray_hits_prepared(V3 org, V3 dir, V3 a, V3 ab, V3 ac, V3 Ng) {
-    const V3 e1 = v3(-ab.x, -ab.y, -ab.z);
-    const V3 C = sub(a, org);
-    const V3 R = cross(C, dir);
-    const float den = dot(Ng, dir);
-    const float absden = fabsf(den);
-    const float sgn = den < 0.f ? -1.f : 1.f;
-    const float U = mul_rn(dot(R, ac), sgn);
-    const float V = mul_rn(dot(R, e1), sgn);
-    const float T = mul_rn(dot(Ng, C), sgn);
-    return ((den != 0.f) && (U >= 0.f) && (V >= 0.f) && (add_rn(U, V) <= absden) && (T > 0.f)) ? 1 : 0;
-}
-
 struct LaneState {
     V3 p;
-    float best_d2, reach, reach2;  // reach = inflated sqrt(best_d2): "closer than this could still win"
-    int best_f;
+    float reach, reach2;  // reach = inflated upper bound on the distance to the mesh: "closer than this could still win"
 };
-
-PVAMD_DEV void set_best(LaneState& s, float d2, int f) {
-    s.best_d2 = d2;
-    s.best_f = f;
-    const float reach = sqrt_rn(d2) * 1.00001f;  // NaN/inf propagate: comparisons against them keep the triangle
-    if (!(reach >= s.reach)) {                   // never loosen a bound that is already tighter (seeded, below)
-        s.reach = reach;
-        s.reach2 = reach * reach;
-    }
-}
-
-// Upper bound on the distance from p to the mesh before any triangle is looked at: every tile sphere contains at
-// least one whole triangle, so min over tiles of (|p - ctr| + r) bounds the nearest-triangle distance from above.
-// Seeding `reach` with it lets the very first tiles be culled (they are visited in storage order, not nearest-first).
-// Also returns the tile that attains the bound for this lane: visiting the nearest tile first tightens `reach` to the
-// true distance immediately, after which almost every other tile fails the sphere test.
-PVAMD_DEV int seed_reach(const MeshArgs& m, LaneState& s) {
-    const int ntiles = (m.F + kTile - 1) / kTile;
-    float bound = INFINITY;
-    int nearest = 0;
-    for (int ti = 0; ti < ntiles; ++ti) {
-        const float* ts = m.tiles + 4 * (int64_t)ti;
-        const V3 w = v3(ts[0] - s.p.x, ts[1] - s.p.y, ts[2] - s.p.z);
-        const float b = sqrt_rn(dot(w, w)) * 1.00001f + ts[3];
-        if (b < bound) {  // a NaN point never passes: keeps INFINITY / tile 0
-            bound = b;
-            nearest = ti;
-        }
-    }
-    s.reach = bound * 1.00001f;
-    s.reach2 = s.reach * s.reach;
-    return nearest;
-}
 
 // sphere (ctr, r) cannot contain a point closer to p than the current best:  |p-ctr| > r + reach
 PVAMD_DEV bool sphere_may_improve(const LaneState& s, float dist2, float r) {
@@ -193,119 +190,290 @@ PVAMD_DEV bool sphere_may_hit(float dist2, float tp, float r) {
     return !(perp2 > fmaf(r, r, 2e-6f * dist2)) && !(tp < -r);
 }
 
-template <int PG, int SLICES, bool WITH_RAY>
-PVAMD_DEV void scan_mesh(const MeshArgs& m, float* __restrict__ tile_lds, LaneState& s, V3 dir, V3 dn, int& hits,
-                         int* __restrict__ ctl_lds) {
-    constexpr int kWaves = PG * SLICES;
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int slice = wave % SLICES;
-    const int ntiles = (m.F + kTile - 1) / kTile;
-    // Visit order: the tiles nearest to the first and the last point of the block (the two ends of a Morton-sorted run
-    // of points), then storage order -- the same for every wave of the block.
-    const int my_nearest = seed_reach(m, s);
-    int first0 = my_nearest, first1 = my_nearest;
-    if (kWaves == 1) {
-        first0 = __shfl(my_nearest, 0, 64);
-        first1 = __shfl(my_nearest, 63, 64);
-    } else {
-        if (wave == 0 && lane == 0) ctl_lds[1] = my_nearest;
-        if (wave == kWaves - 1 && lane == 63) ctl_lds[2] = my_nearest;
-        __syncthreads();
-        first0 = ctl_lds[1];
-        first1 = ctl_lds[2];
-    }
-    for (int step = 0; step < ntiles + 2; ++step) {
-        int ti;
-        if (step == 0) ti = first0;
-        else if (step == 1) { if (first1 == first0) continue; ti = first1; }
-        else { ti = step - 2; if (ti == first0 || ti == first1) continue; }
-        // ---- tile-level cull (block-uniform decision: every wave must agree before the barrier) ----
-        const float* ts = m.tiles + 4 * (int64_t)ti;  // uniform address: scalar loads
-        const V3 wt = v3(ts[0] - s.p.x, ts[1] - s.p.y, ts[2] - s.p.z);
-        const float tdist2 = dot(wt, wt);
-        bool need = sphere_may_improve(s, tdist2, ts[3]);
-        if (WITH_RAY) need = need || sphere_may_hit(tdist2, dot(wt, dn), ts[3]);
-        if (kWaves == 1) {
-            if (!__any(need)) continue;
-            __syncthreads();
+// Second, tighter filter for the closest-point pairs that pass the sphere test.  The triangle lies inside the rectangle
+// |u.(x-ctr)| <= hu, |v.(x-ctr)| <= hv of (nearly) its own plane, so with w = ctr - p
+//     |x - p|^2  >=  max(0, |w|^2 - (u.w)^2 - (v.w)^2)  +  max(0, |u.w| - hu)^2  +  max(0, |v.w| - hv)^2  -  slack,
+// slack = 8e-6 |w|^2 + m0 covering the fp32 evaluation, the rounded frame (not exactly orthonormal) and the distance of
+// the corners from the frame's plane (m0 = 1e6 s^2: 2|w|s <= 1e-6 |w|^2 + 1e6 s^2); hu, hv and m0 were computed in
+// float64 for exactly the rounded ctr/u/v stored here (mesh_prepare_records).  Unlike the sphere this stays tight for
+// long, thin and large triangles.  Any NaN/inf makes the comparison false: the pair is kept.
+PVAMD_DEV bool rect_may_improve(const LaneState& s, V3 w, float dist2, const float* __restrict__ o) {
+    const float u = dot(v3(o[4], o[5], o[6]), w), v = dot(v3(o[8], o[9], o[10]), w);
+    const float h2 = fmaxf(fmaf(-v, v, fmaf(-u, u, dist2)), 0.f);
+    const float du = fmaxf(fabsf(u) - o[7], 0.f), dv = fmaxf(fabsf(v) - o[11], 0.f);
+    const float lb2 = fmaf(dv, dv, fmaf(du, du, h2));
+    return !(lb2 > fmaf(8e-6f, dist2, fmaf(s.reach2, 1.00001f, o[19])));
+}
+
+#ifdef PVAMD_MESH_STATS
+__device__ unsigned long long g_stats[16];
+#define STAT(i, v) do { if ((threadIdx.x & 63) == 0) atomicAdd(&g_stats[i], (unsigned long long)(v)); } while (0)
+extern "C" int pvamd_debug_stats(unsigned long long* out, int reset) {
+    (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_stats), sizeof(g_stats));
+    if (reset) { unsigned long long z[16] = {}; (void)hipMemcpyToSymbol(HIP_SYMBOL(g_stats), z, sizeof(z)); }
+    return 0;
+}
+#else
+#define STAT(i, v)
+#endif
+
+// ---------------------------------------------------------------------------------------------------------------
+// The scan.  One block = 64 points (one per lane) x SLICES waves that all hold the same 64 points.
+//   seed    every wave bounds the distance to the mesh from its share of the tile spheres (min over tiles of
+//           |p - ctr| + r: each sphere contains a whole triangle); the merged bound seeds `reach`, and the tiles
+//           nearest to lane 0 / lane 63 (the two ends of a Morton-sorted run of points) are visited first, which
+//           tightens reach to about the true distance before anything else is looked at.
+//   vote    one pass over the remaining tile spheres, split across the waves, flags the tiles some lane still needs
+//           (closer than reach, or crossed by the lane's ray) in an LDS bit mask; unflagged tiles cost nothing more.
+//   visit   a flagged tile is staged into LDS by the whole block (2 barriers); groups of 16 records are dealt
+//           round-robin to the waves; group sphere, then record spheres, wave-uniform (LDS broadcast reads).
+//   narrow  the broad phase only QUEUES (record, point) pairs -- per wave, in LDS, one queue for closest-point pairs
+//           and one for ray pairs.  Whenever 64 are waiting the wave runs them densely: lane i takes pair i, whichever
+//           point and record that is (typically ~10-60 % of the lanes of a wave need a given record, so running the
+//           exact test per record would idle the rest).  Results fold into per-point LDS slots shared by all waves:
+//           a 64-bit atomicMin on (d2 bits << 32 | face id) IS the lexicographic "smallest d2, lowest original face
+//           id" rule (d2 >= +0, so its bit pattern orders like the float; a NaN sorts above +inf and never wins), hit
+//           counts by atomicAdd.  After a drain every lane tightens its reach from the shared slot, so the waves help
+//           each other cull.
+// A skipped record provably cannot lower a lane's best d^2 nor be hit by its ray, min and + are order-free, so the
+// results are bit-identical to the plain double loop of oracle/pvamd_oracle.c.
+// ---------------------------------------------------------------------------------------------------------------
+constexpr int kQueueCap = 128;     // entries per queue per wave (uint16: record << 6 | owner lane); < 64 + 64 in use
+constexpr int kVoteTiles = 2048;   // tiles per vote pass (64 mask words)
+constexpr unsigned long long kBestInit = 0x7F80000000000000ull;  // (+inf, face 0): a finite candidate always wins
+
+struct MeshShared {
+    float tile[kTile * kRec];  // doubles as [SLICES][64] u64 scratch for the seed merge before the first tile
+    float group[kGroupsPerTile * 4];
+    unsigned long long best[64];
+    int hits[64];
+    float pt[64 * 3];
+    float dir[64 * 3];  // jittered ray direction (exact test)
+    float dn[64 * 3];   // its unit vector (sphere tests)
+    unsigned mask[kVoteTiles / 32];
+};
+
+// enqueue the lanes of `mask` for record j (wave-uniform j): the k-th set lane writes slot n + k
+PVAMD_DEV void enqueue(unsigned short* q, int& n, unsigned long long mask, bool mine, int j) {
+    const int lane = threadIdx.x & 63;
+    if (mine) q[n + __popcll(mask & ((1ull << lane) - 1ull))] = (unsigned short)((j << 6) | lane);
+    n += __popcll(mask);
+}
+
+// Run fn(entry) densely over the queue: always the first (up to) 64 entries; the remainder (n - 64 < 64 by
+// construction) too when `everything`, else it moves to the front and waits for more company.
+template <class Fn>
+PVAMD_DEV void drain(unsigned short* q, int& n, bool everything, Fn&& fn) {
+    const int lane = threadIdx.x & 63;
+    PVAMD_WAVE_SYNC();  // entries were written by other lanes
+    STAT(6, 1);
+    if (lane < n) fn((unsigned)q[lane]);
+    if (n > 64) {
+        const int rem = n - 64;
+        const unsigned v = lane < rem ? (unsigned)q[64 + lane] : 0u;
+        if (everything) {
+            if (lane < rem) fn(v);
+            n = 0;
         } else {
-            __syncthreads();  // previous tile fully consumed; flag reusable
-            if (threadIdx.x == 0) ctl_lds[0] = 0;
-            __syncthreads();
-            if (__any(need) && lane == 0) atomicOr(ctl_lds, 1);
-            __syncthreads();
-            if (ctl_lds[0] == 0) continue;
+            if (lane < rem) q[lane] = (unsigned short)v;
+            n = rem;
         }
-        // ---- stage the tile: contiguous float4 copy ----
-        const int n = min(kTile, m.F - ti * kTile);
-        {
-            const f32x4* src = reinterpret_cast<const f32x4*>(m.rec + (int64_t)kRec * kTile * ti);
-            f32x4_alias* dst = reinterpret_cast<f32x4_alias*>(tile_lds);
-            for (int k = threadIdx.x; k < n * (kRec / 4); k += blockDim.x) dst[k] = src[k];
-        }
-        __syncthreads();
-        if (kWaves > 1 && !__any(need)) continue;  // this wave's 64 points do not need the tile another wave asked for
-        // ---- triangles of this tile, dealt round-robin to the slices of a point group ----
-        for (int j = slice; j < n; j += SLICES) {
-            const float* o = tile_lds + kRec * j;  // wave-uniform address: LDS broadcast reads
-            const V3 w = v3(o[0] - s.p.x, o[1] - s.p.y, o[2] - s.p.z);
-            const float r = o[3];
-            const float dist2 = dot(w, w);
-            const bool need_c = sphere_may_improve(s, dist2, r);
-            bool need_r = false;
-            if (WITH_RAY) need_r = sphere_may_hit(dist2, dot(w, dn), r);
-            if (!__any(need_c || need_r)) continue;
-            const V3 a = v3(o[4], o[5], o[6]);
-            const V3 ab = v3(o[16], o[17], o[18]), ac = v3(o[20], o[21], o[22]);
-            if (__any(need_c)) {
-                const V3 b = v3(o[8], o[9], o[10]), c = v3(o[12], o[13], o[14]);
-                const int f = __float_as_int(o[7]);
-                const V3 q = closest_point_prepared(s.p, a, b, c, ab, ac);
-                const V3 g = sub(q, s.p);
-                const float d2 = dot(g, g);
-                if (d2 < s.best_d2 || (d2 == s.best_d2 && f < s.best_f)) set_best(s, d2, f);
-            }
-            if (WITH_RAY) {
-                if (__any(need_r)) hits += ray_hits_prepared(s.p, dir, a, ab, ac, v3(o[24], o[25], o[26]));
-            }
-        }
+    } else {
+        n = 0;
+    }
+    PVAMD_WAVE_SYNC();
+}
+
+PVAMD_DEV void drain_closest(MeshShared& sh, unsigned short* q, int& n, bool everything, LaneState& s) {
+    if (n == 0) return;
+    drain(q, n, everything, [&](unsigned e) {
+        const float* o = sh.tile + kRec * (e >> 6);
+        const int owner = e & 63;
+        const V3 p = v3(sh.pt[3 * owner], sh.pt[3 * owner + 1], sh.pt[3 * owner + 2]);
+        const V3 c = closest_point_triangle(p, v3(o[12], o[13], o[14]), v3(o[16], o[17], o[18]), v3(o[20], o[21], o[22]));
+        const V3 g = sub(c, p);
+        const float d2 = dot(g, g);
+        atomicMin(&sh.best[owner],
+                  ((unsigned long long)(unsigned)__float_as_int(d2) << 32) | (unsigned)__float_as_int(o[15]));
+    });
+    // tighten this lane's reach from the block-shared slot (other waves' finds included)
+    const float d2 = __int_as_float((int)(unsigned)(sh.best[threadIdx.x & 63] >> 32));
+    const float reach = sqrt_rn(d2) * 1.00001f;
+    if (reach < s.reach) {
+        s.reach = reach;
+        s.reach2 = reach * reach;
     }
 }
 
-// merge the slices of each point group: (d2, face) by lexicographic min, hit counts by sum; valid in slice 0
-template <int PG, int SLICES>
-PVAMD_DEV void merge_slices(float* __restrict__ scratch, LaneState& s, int& hits) {
-    if (SLICES == 1) return;
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int pg = wave / SLICES, slice = wave % SLICES;
-    __syncthreads();  // tile LDS no longer needed: reuse it as scratch [waves][3][64]
-    scratch[(wave * 3 + 0) * 64 + lane] = s.best_d2;
-    scratch[(wave * 3 + 1) * 64 + lane] = __int_as_float(s.best_f);
-    scratch[(wave * 3 + 2) * 64 + lane] = __int_as_float(hits);
+PVAMD_DEV void drain_rays(MeshShared& sh, unsigned short* q, int& n, bool everything) {
+    if (n == 0) return;
+    drain(q, n, everything, [&](unsigned e) {
+        const float* o = sh.tile + kRec * (e >> 6);
+        const int owner = e & 63;
+        const V3 p = v3(sh.pt[3 * owner], sh.pt[3 * owner + 1], sh.pt[3 * owner + 2]);
+        const V3 d = v3(sh.dir[3 * owner], sh.dir[3 * owner + 1], sh.dir[3 * owner + 2]);
+        if (ray_hits_triangle(p, d, v3(o[12], o[13], o[14]), v3(o[16], o[17], o[18]), v3(o[20], o[21], o[22])))
+            atomicAdd(&sh.hits[owner], 1);
+    });
+}
+
+// does any lane of this wave still need tile ti?  (ti wave-uniform: scalar loads)
+template <bool WITH_RAY>
+PVAMD_DEV bool wave_needs_tile(const MeshArgs& m, int ti, const LaneState& s, V3 dn) {
+    const float* ts = m.tiles + 4 * (int64_t)ti;
+    const V3 wt = v3(ts[0] - s.p.x, ts[1] - s.p.y, ts[2] - s.p.z);
+    const float tdist2 = dot(wt, wt);
+    bool need = sphere_may_improve(s, tdist2, ts[3]);
+    if (WITH_RAY) need = need || sphere_may_hit(tdist2, dot(wt, dn), ts[3]);
+    return __any(need);
+}
+
+// Stage tile ti into LDS and run this wave's share of it.  Entry: nobody still reads the previous tile.  Exit: ditto.
+template <int SLICES, bool WITH_RAY>
+PVAMD_DEV void visit_tile(const MeshArgs& m, MeshShared& sh, int ti, int wave, unsigned short* qc, unsigned short* qr,
+                          LaneState& s, V3 dn) {
+    STAT(1, wave == 0);
+    const int n = min(kTile, m.F - ti * kTile);
+    {
+        const f32x4* src = reinterpret_cast<const f32x4*>(m.rec + (int64_t)kRec * kTile * ti);
+        f32x4_alias* dst = reinterpret_cast<f32x4_alias*>(sh.tile);
+        for (int k = threadIdx.x; k < n * (kRec / 4); k += 64 * SLICES) dst[k] = src[k];
+        if (threadIdx.x < kGroupsPerTile * 4)
+            sh.group[threadIdx.x] = m.tiles[4 * (int64_t)((m.F + kTile - 1) / kTile) + (int64_t)ti * kGroupsPerTile * 4 + threadIdx.x];
+    }
     __syncthreads();
-    if (slice == 0) {
-        for (int k = 1; k < SLICES; ++k) {
-            const int w = pg * SLICES + k;
-            const float d2 = scratch[(w * 3 + 0) * 64 + lane];
-            const int f = __float_as_int(scratch[(w * 3 + 1) * 64 + lane]);
-            hits += __float_as_int(scratch[(w * 3 + 2) * 64 + lane]);
-            if (f >= 0 && (s.best_f < 0 || d2 < s.best_d2 || (d2 == s.best_d2 && f < s.best_f))) {
-                s.best_d2 = d2;
-                s.best_f = f;
+    if (wave_needs_tile<WITH_RAY>(m, ti, s, dn)) {  // reach may have tightened since the vote
+        STAT(2, 1);
+        int nc = 0, nr = 0;
+        for (int g0 = wave * kGroup; g0 < n; g0 += SLICES * kGroup) {
+            const float* og = sh.group + 4 * (g0 / kGroup);  // wave-uniform addresses below: LDS broadcast reads
+            const V3 wg = v3(og[0] - s.p.x, og[1] - s.p.y, og[2] - s.p.z);
+            const float rg = og[3];
+            const float gdist2 = dot(wg, wg);
+            bool gneed = sphere_may_improve(s, gdist2, rg);
+            if (WITH_RAY) gneed = gneed || sphere_may_hit(gdist2, dot(wg, dn), rg);
+            STAT(9, 1);
+            if (!__any(gneed)) continue;
+            const int g1 = min(g0 + kGroup, n);
+            for (int j = g0; j < g1; ++j) {
+                const float* o = sh.tile + kRec * j;
+                const V3 w = v3(o[0] - s.p.x, o[1] - s.p.y, o[2] - s.p.z);
+                const float r = o[3];
+                const float dist2 = dot(w, w);
+                const bool near_c = sphere_may_improve(s, dist2, r);
+                STAT(3, 1);
+                if (__any(near_c)) {
+                    STAT(10, 1);
+                    const bool need_c = near_c && rect_may_improve(s, w, dist2, o);
+                    const unsigned long long mc = __ballot(need_c);
+                    if (mc) {
+                        STAT(4, __popcll(mc)); STAT(7, 1);
+                        enqueue(qc, nc, mc, need_c, j);
+                        if (nc >= 64) drain_closest(sh, qc, nc, false, s);
+                    }
+                }
+                if (WITH_RAY) {
+                    const bool need_r = sphere_may_hit(dist2, dot(w, dn), r);
+                    const unsigned long long mr = __ballot(need_r);
+                    if (mr) {
+                        STAT(5, __popcll(mr)); STAT(8, 1);
+                        enqueue(qr, nr, mr, need_r, j);
+                        if (nr >= 64) drain_rays(sh, qr, nr, false);
+                    }
+                }
             }
         }
+        // the tile is about to be replaced: finish everything that points into it
+        drain_closest(sh, qc, nc, true, s);
+        if (WITH_RAY) drain_rays(sh, qr, nr, true);
+    }
+    __syncthreads();
+}
+
+// On entry: s.p set by every wave; wave 0 has filled sh.pt / sh.dir / sh.dn (no barrier needed yet).
+// On exit (after a barrier): sh.best[lane] / sh.hits[lane] hold the block's result for point `lane`.
+template <int SLICES, bool WITH_RAY>
+PVAMD_DEV void scan_mesh(const MeshArgs& m, MeshShared& sh, unsigned short* qc, unsigned short* qr, LaneState& s) {
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int ntiles = (m.F + kTile - 1) / kTile;
+    // ---- seed: this wave's share of the tile spheres ----
+    {
+        float bound = INFINITY;
+        int nearest = 0;
+        for (int ti = wave; ti < ntiles; ti += SLICES) {
+            const float* ts = m.tiles + 4 * (int64_t)ti;
+            const V3 w = v3(ts[0] - s.p.x, ts[1] - s.p.y, ts[2] - s.p.z);
+            const float b = fast_sqrt(dot(w, w)) * 1.00001f + (ts[3] + 1.1e-19f);  // slack: 1 ulp + the flushed denormals
+            if (b < bound) {  // a NaN point never passes: keeps INFINITY / tile 0
+                bound = b;
+                nearest = ti;
+            }
+        }
+        unsigned long long* scratch = reinterpret_cast<unsigned long long*>(sh.tile);
+        scratch[wave * 64 + lane] = ((unsigned long long)(unsigned)__float_as_int(bound) << 32) | (unsigned)nearest;
+        if (wave == 0) {
+            sh.best[lane] = kBestInit;
+            sh.hits[lane] = 0;
+        }
+    }
+    __syncthreads();
+    V3 dn = s.p;
+    int first0, first1;
+    {
+        const unsigned long long* scratch = reinterpret_cast<const unsigned long long*>(sh.tile);
+        unsigned long long lo = scratch[lane];
+#pragma unroll
+        for (int w = 1; w < SLICES; ++w) {
+            const unsigned long long v = scratch[w * 64 + lane];
+            lo = v < lo ? v : lo;  // bound >= 0: bit order = float order; ties -> lowest tile index
+        }
+        s.reach = __int_as_float((int)(unsigned)(lo >> 32)) * 1.00001f;
+        s.reach2 = s.reach * s.reach;
+        first0 = __shfl((int)(unsigned)lo, 0, 64);
+        first1 = __shfl((int)(unsigned)lo, 63, 64);
+        if (WITH_RAY) dn = v3(sh.dn[3 * lane], sh.dn[3 * lane + 1], sh.dn[3 * lane + 2]);
+    }
+    __syncthreads();  // scratch consumed: the tile buffer may be overwritten
+    if (ntiles == 0) return;
+    visit_tile<SLICES, WITH_RAY>(m, sh, first0, wave, qc, qr, s, dn);
+    if (first1 != first0) visit_tile<SLICES, WITH_RAY>(m, sh, first1, wave, qc, qr, s, dn);
+    // ---- every other tile: vote, then visit the flagged ones ----
+    for (int base = 0; base < ntiles; base += kVoteTiles) {
+        const int nwords = (min(kVoteTiles, ntiles - base) + 31) / 32;
+        if (threadIdx.x < kVoteTiles / 32) sh.mask[threadIdx.x] = 0u;
+        __syncthreads();
+        for (int word = 0; word < nwords; ++word) {
+            unsigned bits = 0u;
+            for (int t = wave; t < 32; t += SLICES) {
+                const int ti = base + 32 * word + t;
+                if (ti >= ntiles || ti == first0 || ti == first1) continue;
+                STAT(0, 1);
+                if (wave_needs_tile<WITH_RAY>(m, ti, s, dn)) bits |= 1u << t;
+            }
+            if (bits != 0u && lane == 0) atomicOr(&sh.mask[word], bits);
+        }
+        __syncthreads();
+        for (int word = 0; word < nwords; ++word) {
+            unsigned todo = __builtin_amdgcn_readfirstlane(sh.mask[word]);
+            while (todo != 0u) {
+                const int t = __ffs(todo) - 1;
+                todo &= todo - 1u;
+                visit_tile<SLICES, WITH_RAY>(m, sh, base + 32 * word + t, wave, qc, qr, s, dn);
+            }
+        }
+        // visit_tile ends with a barrier (and so does the vote when nothing was flagged): the mask can be reused
     }
 }
 
 // the closest point on the winning face, recomputed from its corners (same operations as during the scan)
 PVAMD_DEV V3 closest_on_face(const MeshArgs& m, const float* __restrict__ tri_of_face, V3 p) {
     const float* o = tri_of_face;
-    return closest_point_prepared(p, v3(o[4], o[5], o[6]), v3(o[8], o[9], o[10]), v3(o[12], o[13], o[14]),
-                                  v3(o[16], o[17], o[18]), v3(o[20], o[21], o[22]));
+    return closest_point_triangle(p, v3(o[12], o[13], o[14]), v3(o[16], o[17], o[18]), v3(o[20], o[21], o[22]));
 }
 
-template <int PG, int SLICES>
-__global__ __launch_bounds__(64 * PG * SLICES) void mesh_query_kernel(MeshArgs m, const int* __restrict__ order,
+template <int SLICES>
+__global__ __launch_bounds__(64 * SLICES) void mesh_query_kernel(MeshArgs m, const int* __restrict__ order,
                                                                 const float* __restrict__ pts, int64_t P,
                                                                 uint64_t seed, int64_t index_base,
                                                                 float* __restrict__ out_closest,
@@ -313,29 +481,30 @@ __global__ __launch_bounds__(64 * PG * SLICES) void mesh_query_kernel(MeshArgs m
                                                                 float* __restrict__ out_grad,
                                                                 int* __restrict__ out_face,
                                                                 float* __restrict__ out_normal) {
-    __shared__ __attribute__((aligned(16))) float tile_lds[kTile * kRec];
-    __shared__ int ctl[4];
+    __shared__ __attribute__((aligned(16))) MeshShared sh;
+    __shared__ unsigned short queue_c[SLICES][kQueueCap], queue_r[SLICES][kQueueCap];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int64_t k = ((int64_t)blockIdx.x * PG + wave / SLICES) * 64 + lane;  // position in processing order
+    const int64_t k = (int64_t)blockIdx.x * 64 + lane;  // position in processing order
     const bool live = k < P;
     const int64_t kk = live ? k : (P - 1);
     const int64_t i = order ? (int64_t)order[kk] : kk;  // the point this lane owns (spatially sorted processing)
     const int64_t ii = i;
     LaneState s;
     s.p = v3(pts[3 * ii], pts[3 * ii + 1], pts[3 * ii + 2]);
-    s.best_f = -1;
-    s.best_d2 = INFINITY;
     s.reach = INFINITY;
     s.reach2 = INFINITY;
-    const V3 dir = jitter_dir(m.ray_dir, seed, index_base + ii);
-    const float inv_len = 1.f / sqrt_rn(dot(dir, dir));
-    const V3 dn = v3(dir.x * inv_len, dir.y * inv_len, dir.z * inv_len);
-    int hits = 0;
-    scan_mesh<PG, SLICES, true>(m, tile_lds, s, dir, dn, hits, ctl);
-    merge_slices<PG, SLICES>(tile_lds, s, hits);
-    if ((wave % SLICES) != 0 || !live) return;
-
-    const int f = s.best_f;
+    if (wave == 0) {  // the other waves read these from LDS
+        const V3 dir = jitter_dir(m.ray_dir, seed, index_base + ii);
+        const float inv_len = 1.f / sqrt_rn(dot(dir, dir));
+        sh.pt[3 * lane] = s.p.x; sh.pt[3 * lane + 1] = s.p.y; sh.pt[3 * lane + 2] = s.p.z;
+        sh.dir[3 * lane] = dir.x; sh.dir[3 * lane + 1] = dir.y; sh.dir[3 * lane + 2] = dir.z;
+        sh.dn[3 * lane] = dir.x * inv_len; sh.dn[3 * lane + 1] = dir.y * inv_len; sh.dn[3 * lane + 2] = dir.z * inv_len;
+    }
+    scan_mesh<SLICES, true>(m, sh, queue_c[wave], queue_r[wave], s);
+    if (wave != 0 || !live) return;
+    const unsigned long long found = sh.best[lane];
+    const int hits = sh.hits[lane];
+    const int f = (unsigned)(found >> 32) == 0x7F800000u ? -1 : (int)(unsigned)found;
     V3 q = v3(NAN, NAN, NAN);
     if (f >= 0) q = closest_on_face(m, m.rec + (int64_t)kRec * m.rec_of_face[f], s.p);
     V3 g = sub(q, s.p);                          // sdf.py:139
@@ -364,16 +533,16 @@ __global__ __launch_bounds__(64 * PG * SLICES) void mesh_query_kernel(MeshArgs m
 }
 
 // grid: x = tiles of 64 points, y = transform b
-template <int PG, int SLICES>
-__global__ __launch_bounds__(64 * PG * SLICES) void chamfer_mesh_kernel(MeshArgs m, const int* __restrict__ order,
+template <int SLICES>
+__global__ __launch_bounds__(64 * SLICES) void chamfer_mesh_kernel(MeshArgs m, const int* __restrict__ order,
                                                                   const float* __restrict__ W,
                                                                   const float* __restrict__ pts, int64_t N, float scale,
                                                                   double* __restrict__ out_sum) {
-    __shared__ __attribute__((aligned(16))) float tile_lds[kTile * kRec];
-    __shared__ int ctl[4];
+    __shared__ __attribute__((aligned(16))) MeshShared sh;
+    __shared__ unsigned short queue_c[SLICES][kQueueCap];
     const float* M = W + 16 * (int64_t)blockIdx.y;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int64_t k = ((int64_t)blockIdx.x * PG + wave / SLICES) * 64 + lane;
+    const int64_t k = (int64_t)blockIdx.x * 64 + lane;
     const bool live = k < N;
     const int64_t kk = live ? k : (N - 1);
     const int64_t ii = order ? (int64_t)order[kk] : kk;
@@ -383,17 +552,16 @@ __global__ __launch_bounds__(64 * PG * SLICES) void chamfer_mesh_kernel(MeshArgs
     s.p = v3(add_rn(fmaf(M[2], pz, fmaf(M[1], py, mul_rn(M[0], px))), M[3]),
              add_rn(fmaf(M[6], pz, fmaf(M[5], py, mul_rn(M[4], px))), M[7]),
              add_rn(fmaf(M[10], pz, fmaf(M[9], py, mul_rn(M[8], px))), M[11]));
-    s.best_f = -1;
-    s.best_d2 = INFINITY;
     s.reach = INFINITY;
     s.reach2 = INFINITY;
-    int hits = 0;
-    scan_mesh<PG, SLICES, false>(m, tile_lds, s, s.p, s.p, hits, ctl);
-    merge_slices<PG, SLICES>(tile_lds, s, hits);
-    if ((wave % SLICES) != 0) return;
+    if (wave == 0) { sh.pt[3 * lane] = s.p.x; sh.pt[3 * lane + 1] = s.p.y; sh.pt[3 * lane + 2] = s.p.z; }
+    scan_mesh<SLICES, false>(m, sh, queue_c[wave], queue_c[wave], s);
+    if (wave != 0) return;
+    const unsigned long long found = sh.best[lane];
+    const int best_f = (unsigned)(found >> 32) == 0x7F800000u ? -1 : (int)(unsigned)found;
     double acc = 0.0;
-    if (live && s.best_f >= 0) {
-        const V3 q = closest_on_face(m, m.rec + (int64_t)kRec * m.rec_of_face[s.best_f], s.p);
+    if (live && best_f >= 0) {
+        const V3 q = closest_on_face(m, m.rec + (int64_t)kRec * m.rec_of_face[best_f], s.p);
         const float sd = mul_rn(scale, norm3_unfused(sub(q, s.p)));  // chamfer.py:92
         acc = (double)mul_rn(sd, sd);
     }
@@ -432,7 +600,7 @@ __global__ void zero_f64_kernel(double* p, int n) {
 // rec_of_face[original id] = position of that face's record (records may be stored in any order)
 __global__ void invert_face_order_kernel(const float* __restrict__ rec, int F, int* __restrict__ rec_of_face) {
     const int k = blockIdx.x * blockDim.x + threadIdx.x;
-    if (k < F) rec_of_face[__float_as_int(rec[(int64_t)kRec * k + 7])] = k;
+    if (k < F) rec_of_face[__float_as_int(rec[(int64_t)kRec * k + 15])] = k;
 }
 
 static MeshArgs mesh_args(const pvamd_mesh_t& mesh) {
@@ -497,8 +665,8 @@ extern "C" int pvamd_mesh_query(const pvamd_mesh_t* mesh, const float* points, c
     if (ptiles > 0x7fffffff) return PVAMD_E_SHAPE;
     hipStream_t s = (hipStream_t)stream;
     switch (pick_slices(ptiles)) {
-        case 8: hipLaunchKernelGGL((mesh_query_kernel<1, 8>), dim3((unsigned)ptiles), dim3(512), 0, s, m, order, points, P, jitter_seed, index_base, out_closest, out_dist, out_grad, out_face, out_normal); break;
-        default: hipLaunchKernelGGL((mesh_query_kernel<1, 16>), dim3((unsigned)ptiles), dim3(1024), 0, s, m, order, points, P, jitter_seed, index_base, out_closest, out_dist, out_grad, out_face, out_normal); break;
+        case 8: hipLaunchKernelGGL((mesh_query_kernel<8>), dim3((unsigned)ptiles), dim3(512), 0, s, m, order, points, P, jitter_seed, index_base, out_closest, out_dist, out_grad, out_face, out_normal); break;
+        default: hipLaunchKernelGGL((mesh_query_kernel<16>), dim3((unsigned)ptiles), dim3(1024), 0, s, m, order, points, P, jitter_seed, index_base, out_closest, out_dist, out_grad, out_face, out_normal); break;
     }
     return (int)hipGetLastError();
 }
@@ -520,8 +688,8 @@ extern "C" int pvamd_chamfer_mesh(const pvamd_mesh_t* mesh, const float* W, int3
     for (int32_t b0 = 0; b0 < B; b0 += 65535) {
         const int32_t nb = (B - b0) < 65535 ? (B - b0) : 65535;
         switch (pick_slices(ptiles * nb)) {
-            case 8: hipLaunchKernelGGL((chamfer_mesh_kernel<1, 8>), dim3((unsigned)ptiles, nb), dim3(512), 0, s, m, order, W + 16 * (int64_t)b0, points, N, scale, out_sum + b0); break;
-            default: hipLaunchKernelGGL((chamfer_mesh_kernel<1, 16>), dim3((unsigned)ptiles, nb), dim3(1024), 0, s, m, order, W + 16 * (int64_t)b0, points, N, scale, out_sum + b0); break;
+            case 8: hipLaunchKernelGGL((chamfer_mesh_kernel<8>), dim3((unsigned)ptiles, nb), dim3(512), 0, s, m, order, W + 16 * (int64_t)b0, points, N, scale, out_sum + b0); break;
+            default: hipLaunchKernelGGL((chamfer_mesh_kernel<16>), dim3((unsigned)ptiles, nb), dim3(1024), 0, s, m, order, W + 16 * (int64_t)b0, points, N, scale, out_sum + b0); break;
         }
     }
     return (int)hipGetLastError();
