@@ -160,6 +160,10 @@ int pvamd_composed_query(const pvamd_grid_t* grids, int32_t S, const float* tf, 
 int pvamd_mesh_prepare(const float* tri, const int32_t* face_id, int32_t F, float abs_margin, float* rec_out,
                        float* tiles_out, int32_t* rec_of_face_out, void* stream);
 
+/* Axis-aligned bounds of the finite coordinates of a point set (the box pvamd_morton_keys wants).  points: device
+ * [P][3].  box_out: device [2][3] fp32 (lo xyz, hi xyz); (+inf, -inf) for a dimension without finite values.     */
+int pvamd_points_aabb(const float* points, int64_t P, float* box_out, void* stream);
+
 /* 30-bit Z-order (Morton) key of every point inside the box [lo, hi]: the sort key for a spatially coherent
  * processing order (`order` below).  points: device [P][3].  box: device [2][3] fp32 (lo xyz, hi xyz).
  * keys_out: device [P] int32.                                                                                  */

@@ -87,6 +87,7 @@ SIGNATURES = {
     "pvamd_composed_query": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int32, ctypes.c_void_p, ctypes.c_int32,
                                             ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p,
                                             ctypes.c_void_p, ctypes.c_void_p]),
+    "pvamd_points_aabb": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p]),
     "pvamd_morton_keys": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p,
                                          ctypes.c_void_p]),
     "pvamd_mesh_prepare": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int32, ctypes.c_float,
@@ -177,13 +178,12 @@ def as_query_points(points):
 def morton_order(points, min_points=2048):
     """int32 permutation that walks fp32 [P,3] device points along a Z-order curve (None below `min_points`, where
     sorting costs more than it saves).  Spatially coherent waves are what lets the mesh kernels skip far tiles.
-    One key kernel + one device sort; nothing comes back to the host."""
+    Bounds + key kernels + one device sort; nothing comes back to the host."""
     P = points.shape[0]
     if P < min_points:
         return None
-    finite = torch.nan_to_num(points, nan=0.0, posinf=0.0, neginf=0.0)  # (no host sync: always one cheap pass)
-    lo, hi = torch.aminmax(finite, dim=0)
-    box = torch.stack((lo, hi)).contiguous()
+    box = torch.empty((2, 3), dtype=torch.float32, device=points.device)
     keys = torch.empty((P,), dtype=torch.int32, device=points.device)
+    check(load().pvamd_points_aabb(ptr(points), P, ptr(box), stream_ptr()), "pvamd_points_aabb")
     check(load().pvamd_morton_keys(ptr(points), P, ptr(box), ptr(keys), stream_ptr()), "pvamd_morton_keys")
     return torch.argsort(keys).to(torch.int32)

@@ -592,6 +592,50 @@ __global__ __launch_bounds__(256) void morton_keys_kernel(const float* __restric
     keys[i] = (int)key;
 }
 
+// axis-aligned bounds of the finite coordinates of a point set, for the Morton keys.  Floats are folded through an
+// order-preserving map to uint32 so that atomicMin/atomicMax work; box holds the codes until aabb_decode_kernel.
+PVAMD_DEV unsigned order_code(float f) {
+    const unsigned b = (unsigned)__float_as_int(f);
+    return (b & 0x80000000u) ? ~b : (b | 0x80000000u);
+}
+PVAMD_DEV float order_decode(unsigned c) {
+    return __int_as_float((int)((c & 0x80000000u) ? (c & 0x7fffffffu) : ~c));
+}
+__global__ void aabb_init_kernel(unsigned* box) {
+    if (threadIdx.x < 3) box[threadIdx.x] = order_code(INFINITY);
+    else if (threadIdx.x < 6) box[threadIdx.x] = order_code(-INFINITY);
+}
+__global__ __launch_bounds__(256) void aabb_reduce_kernel(const float* __restrict__ pts, int64_t P, unsigned* box) {
+    float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < P; i += (int64_t)gridDim.x * blockDim.x) {
+#pragma unroll
+        for (int d = 0; d < 3; ++d) {
+            const float v = pts[3 * i + d];
+            if (fabsf(v) < INFINITY) {  // false for NaN and +-inf
+                lo[d] = fminf(lo[d], v);
+                hi[d] = fmaxf(hi[d], v);
+            }
+        }
+    }
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+        for (int off = 32; off > 0; off >>= 1) {
+            lo[d] = fminf(lo[d], __shfl_xor(lo[d], off, 64));
+            hi[d] = fmaxf(hi[d], __shfl_xor(hi[d], off, 64));
+        }
+    }
+    if ((threadIdx.x & 63) == 0) {
+#pragma unroll
+        for (int d = 0; d < 3; ++d) {
+            atomicMin(box + d, order_code(lo[d]));
+            atomicMax(box + 3 + d, order_code(hi[d]));
+        }
+    }
+}
+__global__ void aabb_decode_kernel(unsigned* box) {
+    if (threadIdx.x < 6) reinterpret_cast<float*>(box)[threadIdx.x] = order_decode(box[threadIdx.x]);
+}
+
 __global__ void zero_f64_kernel(double* p, int n) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) p[i] = 0.0;
@@ -628,6 +672,22 @@ static int pick_slices(int64_t point_tiles) {
 }  // namespace pvamd
 
 using namespace pvamd;
+
+extern "C" int pvamd_points_aabb(const float* points, int64_t P, float* box_out, void* stream) {
+    if (P < 0) return PVAMD_E_SHAPE;
+    if (!box_out) return PVAMD_E_NULL;
+    if (P > 0 && !points) return PVAMD_E_NULL;
+    hipStream_t s = (hipStream_t)stream;
+    unsigned* codes = reinterpret_cast<unsigned*>(box_out);
+    hipLaunchKernelGGL(aabb_init_kernel, dim3(1), dim3(64), 0, s, codes);
+    if (P > 0) {
+        const int64_t want = (P + 255) / 256;
+        const unsigned blocks = want < 2048 ? (unsigned)want : 2048u;
+        hipLaunchKernelGGL(aabb_reduce_kernel, dim3(blocks), dim3(256), 0, s, points, P, codes);
+    }
+    hipLaunchKernelGGL(aabb_decode_kernel, dim3(1), dim3(64), 0, s, codes);
+    return (int)hipGetLastError();
+}
 
 extern "C" int pvamd_morton_keys(const float* points, int64_t P, const float* box, int32_t* keys_out, void* stream) {
     if (P < 0) return PVAMD_E_SHAPE;

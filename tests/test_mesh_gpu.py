@@ -178,3 +178,55 @@ def test_reference_debug_assertions_hold_for_a_mesh_backed_cache():
     assert (v_gt - val[oob] > 0).all()                                   # sdf.py:576-578
     cos = torch.cosine_similarity(g_gt, grad[oob], dim=-1)               # sdf.py:580-582
     assert (cos > 0.7).all() and cos.mean() > 0.95
+
+
+def nasty_mesh(rng, offset):
+    """Triangles the broad-phase bounds must stay conservative for: needle slivers, zero-area (collinear and repeated
+    corners), duplicates, a few huge faces next to tiny ones, all far from the origin (large |coordinate| / size)."""
+    tris = []
+    for _ in range(150):  # needles: two corners ~1e-6 apart, third far along a random direction
+        a = rng.uniform(-1, 1, 3)
+        d = rng.normal(size=3)
+        tris.append([a, a + 1e-6 * rng.normal(size=3), a + d / np.linalg.norm(d) * rng.uniform(0.5, 3.0)])
+    for _ in range(60):  # collinear
+        a, d = rng.uniform(-1, 1, 3), rng.normal(size=3)
+        tris.append([a, a + 0.3 * d, a + 0.7 * d])
+    for _ in range(30):  # a point, three times
+        a = rng.uniform(-1, 1, 3)
+        tris.append([a, a, a])
+    for _ in range(200):  # tiny
+        a = rng.uniform(-1, 1, 3)
+        tris.append([a, a + 1e-3 * rng.normal(size=3), a + 1e-3 * rng.normal(size=3)])
+    for _ in range(8):  # huge
+        tris.append(list(rng.uniform(-4, 4, (3, 3))))
+    tris = tris + tris[:40]  # exact duplicates: ties must resolve to the lowest face id
+    soup = np.asarray(tris, dtype=np.float64) + np.asarray(offset)
+    verts = soup.reshape(-1, 3)
+    return mesh_io.TriMesh(verts, np.arange(len(verts)).reshape(-1, 3))
+
+
+@pytest.mark.parametrize("offset", [(0.0, 0.0, 0.0), (300.0, -200.0, 100.0)])
+def test_slivers_degenerate_and_duplicate_triangles_match_oracle(offset):
+    rng = np.random.default_rng(7)
+    obj = pv.MeshObjectFactory(mesh=nasty_mesh(rng, offset))
+    bb = obj.bounding_box(padding_ratio=0.1)
+    pts = H.uniform_points(6000, bb[:, 0], bb[:, 1], seed=5)
+    # plus points exactly on corners and straddling the needles
+    on = torch.from_numpy(obj._mesh.vertices[::7].astype(np.float32))
+    assert_query_matches(obj, torch.cat((pts, on, on + 1e-4)), seed=3)
+
+
+def test_points_aabb_ignores_non_finite_coordinates():
+    from pytorch_volumetric_amd import _lib
+    lib = _lib.load()
+    rng = np.random.default_rng(0)
+    pts = rng.normal(size=(100_000, 3)).astype(np.float32) * np.array([1.0, 50.0, 1e-3], dtype=np.float32)
+    pts[5] = [np.nan, np.inf, -np.inf]
+    pts[77, 1] = np.nan
+    d = torch.from_numpy(pts).cuda()
+    box = torch.empty((2, 3), dtype=torch.float32, device="cuda")
+    _lib.check(lib.pvamd_points_aabb(_lib.ptr(d), d.shape[0], _lib.ptr(box), _lib.stream_ptr()), "aabb")
+    fin = np.where(np.isfinite(pts), pts, np.nan)
+    assert np.array_equal(box.cpu().numpy(), np.stack((np.nanmin(fin, axis=0), np.nanmax(fin, axis=0))))
+    _lib.check(lib.pvamd_points_aabb(None, 0, _lib.ptr(box), _lib.stream_ptr()), "aabb empty")
+    assert np.array_equal(box.cpu().numpy(), np.array([[np.inf] * 3, [-np.inf] * 3], dtype=np.float32))

@@ -9,7 +9,7 @@ from tests import helpers as H
 
 lib = _lib.load()
 NAMES = ["tile_steps(block)", "tiles_loaded(block)", "tiles_scanned(wave)", "tri_sphere_tests(wave)", "closest_pairs",
-         "ray_pairs", "drains(wave)", "tris_any_closest(wave)", "tris_any_ray(wave)", "group_tests(wave)"]
+         "ray_pairs", "drains(wave)", "tris_any_closest(wave)", "tris_any_ray(wave)", "group_tests(wave)", "rect_tests(wave)"]
 
 
 def stats(reset=True):
@@ -45,6 +45,13 @@ stats()
 c = pv.CachedSDF("drill", 0.002, drill.bounding_box(padding=0.05), pv.MeshSDF(drill), clean_cache=True,
                  cache_path="/tmp/mesh_stats_cache.pkl")
 report("cache build drill 0.002 pad 0.05", int(np.prod(c.voxels.shape)), 15728)
+
+# cache build wrench
+wrench = pv.MeshObjectFactory(os.path.join("tests", "golden", "meshes", "offset_wrench_nogrip.obj"))
+stats()
+c = pv.CachedSDF("wrench", 0.002, wrench.bounding_box(padding=0.05), pv.MeshSDF(wrench), clean_cache=True,
+                 cache_path="/tmp/mesh_stats_cache.pkl")
+report("cache build wrench 0.002 pad 0.05", int(np.prod(c.voxels.shape)), 1263)
 
 # C1
 pts = H.uniform_points(10000, [-0.2] * 3, [0.2] * 3, seed=1).cuda()
