@@ -175,10 +175,14 @@ int pvamd_morton_keys(const float* points, int64_t P, const float* box, int32_t*
  * point order[k] (spatially sorted processing makes the tile culling effective; outputs stay in point order).  jitter_seed: counter-based replacement for the reference's unseeded
  * np.random.randn (sdf.py:149); index_base = global index of points[0], so that a query sharded across GPUs
  * draws the jitter an unsharded one would.  out_closest: device [P][3] or NULL.  out_dist: device [P].  out_grad: device
- * [P][3].  out_face: device [P] int32 or NULL.  out_normal: device [P][3] or NULL (compute_normal=True).     */
+ * [P][3].  out_face: device [P] int32 or NULL.  out_normal: device [P][3] or NULL (compute_normal=True).
+ * scratch: device, PVAMD_MESH_SCRATCH_BYTES(P) bytes, 8-byte aligned, or NULL.  With it, a query of few points
+ * against a mesh of many tiles spreads each 64-point group's tiles over several workgroups (three launches that meet
+ * in scratch); results are the same bits either way.  Contents on return are unspecified.                       */
+#define PVAMD_MESH_SCRATCH_BYTES(P) ((((P) + 63) / 64) * (64 * 12 + 8))
 int pvamd_mesh_query(const pvamd_mesh_t* mesh, const float* points, const int32_t* order, int64_t P,
                      uint64_t jitter_seed, int64_t index_base, float* out_closest, float* out_dist, float* out_grad, int32_t* out_face,
-                     float* out_normal, void* stream);
+                     float* out_normal, void* scratch, void* stream);
 
 /* batch_chamfer_dist (chamfer.py:79-94) against a mesh: for each of B world->object transforms, transform the
  * N points, unsigned distance to the mesh, accumulate sum_n (scale*d)^2.  The caller divides by the GLOBAL N

@@ -19,6 +19,14 @@ TRI_TILE = 256
 TRI_GROUP = 16
 
 
+def mesh_scratch_bytes(P):
+    """PVAMD_MESH_SCRATCH_BYTES(P)"""
+    return ((P + 63) // 64) * (64 * 12 + 8)
+
+
+MESH_SCRATCH_MAX_POINTS = 1 << 17  # above this the kernel never spreads a group's tiles: no scratch needed
+
+
 def tiles_floats(F):
     """PVAMD_TILES_FLOATS(F): tile spheres followed by group spheres."""
     return ((F + TRI_TILE - 1) // TRI_TILE) * (4 + 4 * (TRI_TILE // TRI_GROUP))
@@ -95,7 +103,7 @@ SIGNATURES = {
     "pvamd_mesh_query": (ctypes.c_int, [ctypes.POINTER(MeshDesc), ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64,
                                         ctypes.c_uint64,
                                         ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
-                                        ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]),
+                                        ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]),
     "pvamd_chamfer_mesh": (ctypes.c_int, [ctypes.POINTER(MeshDesc), ctypes.c_void_p, ctypes.c_int32, ctypes.c_void_p,
                                           ctypes.c_void_p, ctypes.c_int64, ctypes.c_float, ctypes.c_void_p, ctypes.c_void_p]),
     "pvamd_chamfer_grid": (ctypes.c_int, [ctypes.POINTER(GridDesc), ctypes.c_void_p, ctypes.c_int32, ctypes.c_void_p,

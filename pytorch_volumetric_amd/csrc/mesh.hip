@@ -390,14 +390,13 @@ PVAMD_DEV void visit_tile(const MeshArgs& m, MeshShared& sh, int ti, int wave, u
     __syncthreads();
 }
 
-// On entry: s.p set by every wave; wave 0 has filled sh.pt / sh.dir / sh.dn (no barrier needed yet).
-// On exit (after a barrier): sh.best[lane] / sh.hits[lane] hold the block's result for point `lane`.
+// seed (see above): sets s.reach, returns the two tiles to visit first.  On entry: s.p set by every wave; wave 0 has
+// filled sh.pt / sh.dir / sh.dn (no barrier needed yet).  Initialises sh.best / sh.hits; two barriers inside.
 template <int SLICES, bool WITH_RAY>
-PVAMD_DEV void scan_mesh(const MeshArgs& m, MeshShared& sh, unsigned short* qc, unsigned short* qr, LaneState& s) {
+PVAMD_DEV void scan_seed(const MeshArgs& m, MeshShared& sh, LaneState& s, V3& dn, int& first0, int& first1) {
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int ntiles = (m.F + kTile - 1) / kTile;
-    // ---- seed: this wave's share of the tile spheres ----
     {
         float bound = INFINITY;
         int nearest = 0;
@@ -418,8 +417,6 @@ PVAMD_DEV void scan_mesh(const MeshArgs& m, MeshShared& sh, unsigned short* qc, 
         }
     }
     __syncthreads();
-    V3 dn = s.p;
-    int first0, first1;
     {
         const unsigned long long* scratch = reinterpret_cast<const unsigned long long*>(sh.tile);
         unsigned long long lo = scratch[lane];
@@ -435,10 +432,15 @@ PVAMD_DEV void scan_mesh(const MeshArgs& m, MeshShared& sh, unsigned short* qc, 
         if (WITH_RAY) dn = v3(sh.dn[3 * lane], sh.dn[3 * lane + 1], sh.dn[3 * lane + 2]);
     }
     __syncthreads();  // scratch consumed: the tile buffer may be overwritten
-    if (ntiles == 0) return;
-    visit_tile<SLICES, WITH_RAY>(m, sh, first0, wave, qc, qr, s, dn);
-    if (first1 != first0) visit_tile<SLICES, WITH_RAY>(m, sh, first1, wave, qc, qr, s, dn);
-    // ---- every other tile: vote, then visit the flagged ones ----
+}
+
+// vote + visit over the tiles ti with ti % nparts == part, first0 / first1 excepted (they were visited before)
+template <int SLICES, bool WITH_RAY>
+PVAMD_DEV void scan_rest(const MeshArgs& m, MeshShared& sh, unsigned short* qc, unsigned short* qr, LaneState& s, V3 dn,
+                         int first0, int first1, int part, int nparts) {
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int ntiles = (m.F + kTile - 1) / kTile;
     for (int base = 0; base < ntiles; base += kVoteTiles) {
         const int nwords = (min(kVoteTiles, ntiles - base) + 31) / 32;
         if (threadIdx.x < kVoteTiles / 32) sh.mask[threadIdx.x] = 0u;
@@ -448,6 +450,7 @@ PVAMD_DEV void scan_mesh(const MeshArgs& m, MeshShared& sh, unsigned short* qc, 
             for (int t = wave; t < 32; t += SLICES) {
                 const int ti = base + 32 * word + t;
                 if (ti >= ntiles || ti == first0 || ti == first1) continue;
+                if (nparts > 1 && (ti % nparts) != part) continue;
                 STAT(0, 1);
                 if (wave_needs_tile<WITH_RAY>(m, ti, s, dn)) bits |= 1u << t;
             }
@@ -462,8 +465,21 @@ PVAMD_DEV void scan_mesh(const MeshArgs& m, MeshShared& sh, unsigned short* qc, 
                 visit_tile<SLICES, WITH_RAY>(m, sh, base + 32 * word + t, wave, qc, qr, s, dn);
             }
         }
-        // visit_tile ends with a barrier (and so does the vote when nothing was flagged): the mask can be reused
+        if (base + kVoteTiles < ntiles) __syncthreads();  // every wave has read the mask before it is cleared again
     }
+}
+
+// The whole scan in one block.  On exit (after a barrier): sh.best[lane] / sh.hits[lane] = result for point `lane`.
+template <int SLICES, bool WITH_RAY>
+PVAMD_DEV void scan_mesh(const MeshArgs& m, MeshShared& sh, unsigned short* qc, unsigned short* qr, LaneState& s) {
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    V3 dn = s.p;
+    int first0, first1;
+    scan_seed<SLICES, WITH_RAY>(m, sh, s, dn, first0, first1);
+    if (m.F <= 0) return;
+    visit_tile<SLICES, WITH_RAY>(m, sh, first0, wave, qc, qr, s, dn);
+    if (first1 != first0) visit_tile<SLICES, WITH_RAY>(m, sh, first1, wave, qc, qr, s, dn);
+    scan_rest<SLICES, WITH_RAY>(m, sh, qc, qr, s, dn, first0, first1, 0, 1);
 }
 
 // the closest point on the winning face, recomputed from its corners (same operations as during the scan)
@@ -472,42 +488,43 @@ PVAMD_DEV V3 closest_on_face(const MeshArgs& m, const float* __restrict__ tri_of
     return closest_point_triangle(p, v3(o[12], o[13], o[14]), v3(o[16], o[17], o[18]), v3(o[20], o[21], o[22]));
 }
 
-template <int SLICES>
-__global__ __launch_bounds__(64 * SLICES) void mesh_query_kernel(MeshArgs m, const int* __restrict__ order,
-                                                                const float* __restrict__ pts, int64_t P,
-                                                                uint64_t seed, int64_t index_base,
-                                                                float* __restrict__ out_closest,
-                                                                float* __restrict__ out_dist,
-                                                                float* __restrict__ out_grad,
-                                                                int* __restrict__ out_face,
-                                                                float* __restrict__ out_normal) {
-    __shared__ __attribute__((aligned(16))) MeshShared sh;
-    __shared__ unsigned short queue_c[SLICES][kQueueCap], queue_r[SLICES][kQueueCap];
+struct QueryOut {
+    float* closest;
+    float* dist;
+    float* grad;
+    int* face;
+    float* normal;
+};
+
+// the point this lane owns and (wave 0) the per-point LDS tables incl. the jittered ray
+PVAMD_DEV int64_t load_query_point(const MeshArgs& m, MeshShared& sh, const int* __restrict__ order,
+                                   const float* __restrict__ pts, int64_t P, uint64_t seed, int64_t index_base, bool with_ray,
+                                   LaneState& s) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int64_t k = (int64_t)blockIdx.x * 64 + lane;  // position in processing order
-    const bool live = k < P;
-    const int64_t kk = live ? k : (P - 1);
-    const int64_t i = order ? (int64_t)order[kk] : kk;  // the point this lane owns (spatially sorted processing)
-    const int64_t ii = i;
-    LaneState s;
-    s.p = v3(pts[3 * ii], pts[3 * ii + 1], pts[3 * ii + 2]);
+    const int64_t kk = k < P ? k : (P - 1);
+    const int64_t i = order ? (int64_t)order[kk] : kk;  // spatially sorted processing; outputs stay in caller order
+    s.p = v3(pts[3 * i], pts[3 * i + 1], pts[3 * i + 2]);
     s.reach = INFINITY;
     s.reach2 = INFINITY;
     if (wave == 0) {  // the other waves read these from LDS
-        const V3 dir = jitter_dir(m.ray_dir, seed, index_base + ii);
-        const float inv_len = 1.f / sqrt_rn(dot(dir, dir));
         sh.pt[3 * lane] = s.p.x; sh.pt[3 * lane + 1] = s.p.y; sh.pt[3 * lane + 2] = s.p.z;
-        sh.dir[3 * lane] = dir.x; sh.dir[3 * lane + 1] = dir.y; sh.dir[3 * lane + 2] = dir.z;
-        sh.dn[3 * lane] = dir.x * inv_len; sh.dn[3 * lane + 1] = dir.y * inv_len; sh.dn[3 * lane + 2] = dir.z * inv_len;
+        if (with_ray) {
+            const V3 dir = jitter_dir(m.ray_dir, seed, index_base + i);
+            const float inv_len = 1.f / sqrt_rn(dot(dir, dir));
+            sh.dir[3 * lane] = dir.x; sh.dir[3 * lane + 1] = dir.y; sh.dir[3 * lane + 2] = dir.z;
+            sh.dn[3 * lane] = dir.x * inv_len; sh.dn[3 * lane + 1] = dir.y * inv_len; sh.dn[3 * lane + 2] = dir.z * inv_len;
+        }
     }
-    scan_mesh<SLICES, true>(m, sh, queue_c[wave], queue_r[wave], s);
-    if (wave != 0 || !live) return;
-    const unsigned long long found = sh.best[lane];
-    const int hits = sh.hits[lane];
+    return i;
+}
+
+// sdf.py:139-171 from the winning (d2, face) and the hit count
+PVAMD_DEV void write_query(const MeshArgs& m, const QueryOut& out, int64_t i, V3 p, unsigned long long found, int hits) {
     const int f = (unsigned)(found >> 32) == 0x7F800000u ? -1 : (int)(unsigned)found;
     V3 q = v3(NAN, NAN, NAN);
-    if (f >= 0) q = closest_on_face(m, m.rec + (int64_t)kRec * m.rec_of_face[f], s.p);
-    V3 g = sub(q, s.p);                          // sdf.py:139
+    if (f >= 0) q = closest_on_face(m, m.rec + (int64_t)kRec * m.rec_of_face[f], p);
+    V3 g = sub(q, p);                            // sdf.py:139
     float d = norm3_unfused(g);                  // :141
     if (d > 0.f) g = v3(div_rn(g.x, d), div_rn(g.y, d), div_rn(g.z, d));  // :143-144
     if (hits & 1) d = -d;                        // :154-155 inside: negative distance
@@ -515,21 +532,122 @@ __global__ __launch_bounds__(64 * SLICES) void mesh_query_kernel(MeshArgs m, con
     if (fabsf(d) < 1e-3f && f >= 0) {            // :162-164 on the surface: use the face normal
         g = v3(m.normal[3 * f], m.normal[3 * f + 1], m.normal[3 * f + 2]);
     }
-    if (out_closest) {
-        out_closest[3 * i] = q.x;
-        out_closest[3 * i + 1] = q.y;
-        out_closest[3 * i + 2] = q.z;
+    if (out.closest) {
+        out.closest[3 * i] = q.x;
+        out.closest[3 * i + 1] = q.y;
+        out.closest[3 * i + 2] = q.z;
     }
-    out_dist[i] = d;
-    out_grad[3 * i] = g.x;
-    out_grad[3 * i + 1] = g.y;
-    out_grad[3 * i + 2] = g.z;
-    if (out_face) out_face[i] = f;
-    if (out_normal) {                            // :169-171
-        out_normal[3 * i] = f >= 0 ? m.normal[3 * f] : NAN;
-        out_normal[3 * i + 1] = f >= 0 ? m.normal[3 * f + 1] : NAN;
-        out_normal[3 * i + 2] = f >= 0 ? m.normal[3 * f + 2] : NAN;
+    out.dist[i] = d;
+    out.grad[3 * i] = g.x;
+    out.grad[3 * i + 1] = g.y;
+    out.grad[3 * i + 2] = g.z;
+    if (out.face) out.face[i] = f;
+    if (out.normal) {                            // :169-171
+        out.normal[3 * i] = f >= 0 ? m.normal[3 * f] : NAN;
+        out.normal[3 * i + 1] = f >= 0 ? m.normal[3 * f + 1] : NAN;
+        out.normal[3 * i + 2] = f >= 0 ? m.normal[3 * f + 2] : NAN;
     }
+}
+
+template <int SLICES>
+__global__ __launch_bounds__(64 * SLICES) void mesh_query_kernel(MeshArgs m, const int* __restrict__ order,
+                                                                const float* __restrict__ pts, int64_t P,
+                                                                uint64_t seed, int64_t index_base, QueryOut out) {
+    __shared__ __attribute__((aligned(16))) MeshShared sh;
+    __shared__ unsigned short queue_c[SLICES][kQueueCap], queue_r[SLICES][kQueueCap];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    LaneState s;
+    const int64_t i = load_query_point(m, sh, order, pts, P, seed, index_base, true, s);
+    scan_mesh<SLICES, true>(m, sh, queue_c[wave], queue_r[wave], s);
+    if (wave != 0 || (int64_t)blockIdx.x * 64 + lane >= P) return;
+    write_query(m, out, i, s.p, sh.best[lane], sh.hits[lane]);
+}
+
+// ---- few points: the tiles of one point group are spread over several blocks --------------------------------
+// A block of 64 points walks its flagged tiles one after the other; with only a few hundred blocks in flight that
+// serial walk, not throughput, sets the time.  Three launches instead:
+//   first   (one block per group)      seed + the two nearest tiles -> (d2, face), hit count, first0/first1 to scratch
+//   rest    (nparts blocks per group)  start from the scratch values, vote + visit the tiles ti % nparts == part,
+//                                      fold into scratch with global atomicMin / atomicAdd
+//   finish  (one wave per group)       outputs from the scratch values
+// scratch: u64 best[G*64], int hits[G*64], int firsts[G*2], G = ceil(P/64) groups, indexed by processing position.
+struct SplitScratch {
+    unsigned long long* best;
+    int* hits;
+    int* firsts;
+};
+PVAMD_DEV SplitScratch split_scratch(void* scratch, int64_t groups) {
+    SplitScratch r;
+    r.best = reinterpret_cast<unsigned long long*>(scratch);
+    r.hits = reinterpret_cast<int*>(r.best + groups * 64);
+    r.firsts = r.hits + groups * 64;
+    return r;
+}
+
+template <int SLICES>
+__global__ __launch_bounds__(64 * SLICES) void mesh_query_first_kernel(MeshArgs m, const int* __restrict__ order,
+                                                                      const float* __restrict__ pts, int64_t P,
+                                                                      uint64_t seed, int64_t index_base, void* scratch) {
+    __shared__ __attribute__((aligned(16))) MeshShared sh;
+    __shared__ unsigned short queue_c[SLICES][kQueueCap], queue_r[SLICES][kQueueCap];
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    LaneState s;
+    load_query_point(m, sh, order, pts, P, seed, index_base, true, s);
+    V3 dn = s.p;
+    int first0, first1;
+    scan_seed<SLICES, true>(m, sh, s, dn, first0, first1);
+    visit_tile<SLICES, true>(m, sh, first0, wave, queue_c[wave], queue_r[wave], s, dn);
+    if (first1 != first0) visit_tile<SLICES, true>(m, sh, first1, wave, queue_c[wave], queue_r[wave], s, dn);
+    if (wave != 0) return;
+    const SplitScratch sc = split_scratch(scratch, gridDim.x);
+    const int64_t k = (int64_t)blockIdx.x * 64 + lane;
+    sc.best[k] = sh.best[lane];
+    sc.hits[k] = sh.hits[lane];
+    if (lane == 0) {
+        sc.firsts[2 * blockIdx.x] = first0;
+        sc.firsts[2 * blockIdx.x + 1] = first1;
+    }
+}
+
+template <int SLICES>
+__global__ __launch_bounds__(64 * SLICES) void mesh_query_rest_kernel(MeshArgs m, const int* __restrict__ order,
+                                                                     const float* __restrict__ pts, int64_t P,
+                                                                     uint64_t seed, int64_t index_base, void* scratch) {
+    __shared__ __attribute__((aligned(16))) MeshShared sh;
+    __shared__ unsigned short queue_c[SLICES][kQueueCap], queue_r[SLICES][kQueueCap];
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    LaneState s;
+    load_query_point(m, sh, order, pts, P, seed, index_base, true, s);
+    const SplitScratch sc = split_scratch(scratch, gridDim.x);
+    const int64_t k = (int64_t)blockIdx.x * 64 + lane;
+    const unsigned long long start = sc.best[k];
+    if (wave == 0) {
+        sh.best[lane] = start;
+        sh.hits[lane] = 0;
+    }
+    {
+        const float reach = sqrt_rn(__int_as_float((int)(unsigned)(start >> 32))) * 1.00001f;  // inf while nothing found
+        s.reach = reach;
+        s.reach2 = reach * reach;
+    }
+    __syncthreads();
+    const V3 dn = v3(sh.dn[3 * lane], sh.dn[3 * lane + 1], sh.dn[3 * lane + 2]);
+    scan_rest<SLICES, true>(m, sh, queue_c[wave], queue_r[wave], s, dn, sc.firsts[2 * blockIdx.x], sc.firsts[2 * blockIdx.x + 1],
+                            (int)blockIdx.y, (int)gridDim.y);
+    __syncthreads();
+    if (wave != 0) return;
+    if (sh.best[lane] < start) atomicMin(&sc.best[k], sh.best[lane]);
+    if (sh.hits[lane] != 0) atomicAdd(&sc.hits[k], sh.hits[lane]);
+}
+
+__global__ __launch_bounds__(64) void mesh_query_finish_kernel(MeshArgs m, const int* __restrict__ order,
+                                                               const float* __restrict__ pts, int64_t P, const void* scratch,
+                                                               QueryOut out) {
+    const int64_t k = (int64_t)blockIdx.x * 64 + threadIdx.x;
+    if (k >= P) return;
+    const SplitScratch sc = split_scratch(const_cast<void*>(scratch), gridDim.x);
+    const int64_t i = order ? (int64_t)order[k] : k;
+    write_query(m, out, i, v3(pts[3 * i], pts[3 * i + 1], pts[3 * i + 2]), sc.best[k], sc.hits[k]);
 }
 
 // grid: x = tiles of 64 points, y = transform b
@@ -714,19 +832,32 @@ extern "C" int pvamd_mesh_prepare(const float* tri, const int32_t* face_id, int3
 
 extern "C" int pvamd_mesh_query(const pvamd_mesh_t* mesh, const float* points, const int32_t* order, int64_t P,
                                 uint64_t jitter_seed, int64_t index_base, float* out_closest, float* out_dist, float* out_grad,
-                                int32_t* out_face, float* out_normal, void* stream) {
+                                int32_t* out_face, float* out_normal, void* scratch, void* stream) {
     if (P < 0) return PVAMD_E_SHAPE;
     if (P == 0) return 0;
     if (!mesh || !out_dist || !out_grad) return PVAMD_E_NULL;
     if (mesh->F < 0) return PVAMD_E_SHAPE;
     if (!points || (mesh->F > 0 && (!mesh->rec || !mesh->tiles || !mesh->normal || !mesh->rec_of_face))) return PVAMD_E_NULL;
+    if (scratch && !aligned_to(scratch, 8)) return PVAMD_E_ALIGN;
     const MeshArgs m = mesh_args(*mesh);
     const int64_t ptiles = (P + 63) / 64;
     if (ptiles > 0x7fffffff) return PVAMD_E_SHAPE;
     hipStream_t s = (hipStream_t)stream;
+    const QueryOut out{out_closest, out_dist, out_grad, out_face, out_normal};
+    const int ntiles = (mesh->F + kTile - 1) / kTile;
+    // few point groups, many tiles: spread each group's tiles over `parts` blocks (see mesh_query_first_kernel)
+    int parts = (int)((int64_t)kNumCU * 8 / ptiles);
+    if (parts > 16) parts = 16;
+    if (parts > ntiles / 4) parts = ntiles / 4;
+    if (scratch && parts >= 2) {
+        hipLaunchKernelGGL((mesh_query_first_kernel<16>), dim3((unsigned)ptiles), dim3(1024), 0, s, m, order, points, P, jitter_seed, index_base, scratch);
+        hipLaunchKernelGGL((mesh_query_rest_kernel<16>), dim3((unsigned)ptiles, (unsigned)parts), dim3(1024), 0, s, m, order, points, P, jitter_seed, index_base, scratch);
+        hipLaunchKernelGGL(mesh_query_finish_kernel, dim3((unsigned)ptiles), dim3(64), 0, s, m, order, points, P, scratch, out);
+        return (int)hipGetLastError();
+    }
     switch (pick_slices(ptiles)) {
-        case 8: hipLaunchKernelGGL((mesh_query_kernel<8>), dim3((unsigned)ptiles), dim3(512), 0, s, m, order, points, P, jitter_seed, index_base, out_closest, out_dist, out_grad, out_face, out_normal); break;
-        default: hipLaunchKernelGGL((mesh_query_kernel<16>), dim3((unsigned)ptiles), dim3(1024), 0, s, m, order, points, P, jitter_seed, index_base, out_closest, out_dist, out_grad, out_face, out_normal); break;
+        case 8: hipLaunchKernelGGL((mesh_query_kernel<8>), dim3((unsigned)ptiles), dim3(512), 0, s, m, order, points, P, jitter_seed, index_base, out); break;
+        default: hipLaunchKernelGGL((mesh_query_kernel<16>), dim3((unsigned)ptiles), dim3(1024), 0, s, m, order, points, P, jitter_seed, index_base, out); break;
     }
     return (int)hipGetLastError();
 }

@@ -181,10 +181,15 @@ class ObjectFactory(abc.ABC):
         desc = self._mesh_desc()
         with torch.cuda.device(dev):
             order = _lib.morton_order(flat)
+            scratch = None
+            if 0 < P <= _lib.MESH_SCRATCH_MAX_POINTS and getattr(self, "tile_split", True):
+                # small query: let the kernel spread each group's tiles over several workgroups
+                scratch = torch.empty((_lib.mesh_scratch_bytes(P) // 8,), dtype=torch.int64, device=dev)
             _lib.check(lib.pvamd_mesh_query(ctypes.byref(desc), _lib.ptr(flat), _lib.ptr(order), P,
                                             ctypes.c_uint64(self.jitter_seed),
                                             int(index_base), _lib.ptr(closest), _lib.ptr(dist), _lib.ptr(grad),
-                                            _lib.ptr(face), _lib.ptr(normal), _lib.stream_ptr()), "pvamd_mesh_query")
+                                            _lib.ptr(face), _lib.ptr(normal), _lib.ptr(scratch), _lib.stream_ptr()),
+                       "pvamd_mesh_query")
         self._last_face_ids = face
         return SDFQuery(_restore(closest, lead, (3,), dtype, device), _restore(dist, lead, (), dtype, device),
                         _restore(grad, lead, (3,), dtype, device),

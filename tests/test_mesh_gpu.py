@@ -45,13 +45,26 @@ def test_mesh_query_matches_oracle_bitwise(mesh, n):
     assert (d < 0).any() and (d > 0).any()
 
 
-def test_c1_drill_10k_grid_points_match_oracle():
-    """BASELINE config C1: MeshSDF on the YCB power drill (15,728 triangles), 10k grid query points."""
+@pytest.mark.parametrize("tile_split", [True, False])
+def test_c1_drill_10k_grid_points_match_oracle(tile_split):
+    """BASELINE config C1: MeshSDF on the YCB power drill (15,728 triangles), 10k grid query points.  With few points
+    and many tiles the kernel spreads each point group's tiles over several workgroups (three launches meeting in a
+    scratch buffer); with the scratch withheld it is the single-launch scan.  Same bits either way."""
     obj = factory("ycb_power_drill.npz")
+    obj.tile_split = tile_split
     assert obj.num_faces == 15728
     pts = grid_sample(obj, 10_000, seed=0)
     d = assert_query_matches(obj, pts, seed=0)
     assert 0.05 < (d < 0).mean() < 0.9
+
+
+@pytest.mark.parametrize("n", [1, 63, 64, 65, 1000, 40_000])
+def test_tile_split_path_for_every_group_count(n):
+    """Partial last group, a single point, and the largest count that still splits (parts = 2..16)."""
+    obj = factory("ycb_power_drill.npz")
+    bb = obj.bounding_box(padding_ratio=0.3)
+    pts = H.uniform_points(n, bb[:, 0], bb[:, 1], seed=100 + n)
+    assert_query_matches(obj, pts, seed=n)
 
 
 def test_cube_closed_form():
