@@ -9,7 +9,7 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libpvamd.so")
+LIB_PATH = os.environ.get("PVAMD_LIB") or os.path.join(_HERE, "csrc", "libpvamd.so")  # PVAMD_LIB: A/B builds (tools/)
 
 ABI_VERSION = 3
 OOB_LOOKUP_GT_SDF = 0
@@ -19,6 +19,11 @@ TRI_TILE = 256
 TRI_GROUP = 16
 
 
+def tiles_floats(F):
+    """PVAMD_TILES_FLOATS(F): tile spheres followed by group spheres."""
+    return ((F + TRI_TILE - 1) // TRI_TILE) * (4 + 4 * (TRI_TILE // TRI_GROUP))
+
+
 def mesh_scratch_bytes(P):
     """PVAMD_MESH_SCRATCH_BYTES(P)"""
     return ((P + 63) // 64) * (64 * 12 + 8)
@@ -26,10 +31,6 @@ def mesh_scratch_bytes(P):
 
 MESH_SCRATCH_MAX_POINTS = 1 << 17  # above this the kernel never spreads a group's tiles: no scratch needed
 
-
-def tiles_floats(F):
-    """PVAMD_TILES_FLOATS(F): tile spheres followed by group spheres."""
-    return ((F + TRI_TILE - 1) // TRI_TILE) * (4 + 4 * (TRI_TILE // TRI_GROUP))
 
 _c_float_p = ctypes.POINTER(ctypes.c_float)
 

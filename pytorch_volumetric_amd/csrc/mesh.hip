@@ -175,13 +175,19 @@ PVAMD_DEV float norm3_unfused(V3 g) {
 
 struct LaneState {
     V3 p;
-    float reach, reach2;  // reach = inflated upper bound on the distance to the mesh: "closer than this could still win"
+    float reach;             // inflated upper bound on the distance to the mesh: "closer than this could still win"
+    float reach2m, reach2x;  // reach^2 * 1.00001 and 2 * reach * 1.00001: the reach terms of the sphere test
 };
 
-// sphere (ctr, r) cannot contain a point closer to p than the current best:  |p-ctr| > r + reach
+PVAMD_DEV void set_reach(LaneState& s, float reach) {
+    s.reach = reach;
+    s.reach2m = reach * reach * 1.00001f;
+    s.reach2x = 2.00002f * reach;
+}
+
+// sphere (ctr, r) cannot contain a point closer to p than the current best:  |p-ctr|^2 > (r + reach)^2 * 1.00001
 PVAMD_DEV bool sphere_may_improve(const LaneState& s, float dist2, float r) {
-    const float bound = fmaf(2.f * s.reach, r, fmaf(r, r, s.reach2));  // (r + reach)^2
-    return !(dist2 > bound * 1.00001f);
+    return !(dist2 > fmaf(r, fmaf(r, 1.00001f, s.reach2x), s.reach2m));
 }
 
 // sphere (ctr, r) may be crossed by the ray p + t*dn, t > 0 (dn unit):  distance from ctr to the line <= r, not behind p
@@ -202,7 +208,7 @@ PVAMD_DEV bool rect_may_improve(const LaneState& s, V3 w, float dist2, const flo
     const float h2 = fmaxf(fmaf(-v, v, fmaf(-u, u, dist2)), 0.f);
     const float du = fmaxf(fabsf(u) - o[7], 0.f), dv = fmaxf(fabsf(v) - o[11], 0.f);
     const float lb2 = fmaf(dv, dv, fmaf(du, du, h2));
-    return !(lb2 > fmaf(8e-6f, dist2, fmaf(s.reach2, 1.00001f, o[19])));
+    return !(lb2 > fmaf(8e-6f, dist2, s.reach2m + o[19]));
 }
 
 #ifdef PVAMD_MESH_STATS
@@ -299,10 +305,7 @@ PVAMD_DEV void drain_closest(MeshShared& sh, unsigned short* q, int& n, bool eve
     // tighten this lane's reach from the block-shared slot (other waves' finds included)
     const float d2 = __int_as_float((int)(unsigned)(sh.best[threadIdx.x & 63] >> 32));
     const float reach = sqrt_rn(d2) * 1.00001f;
-    if (reach < s.reach) {
-        s.reach = reach;
-        s.reach2 = reach * reach;
-    }
+    if (reach < s.reach) set_reach(s, reach);
 }
 
 PVAMD_DEV void drain_rays(MeshShared& sh, unsigned short* q, int& n, bool everything) {
@@ -425,8 +428,7 @@ PVAMD_DEV void scan_seed(const MeshArgs& m, MeshShared& sh, LaneState& s, V3& dn
             const unsigned long long v = scratch[w * 64 + lane];
             lo = v < lo ? v : lo;  // bound >= 0: bit order = float order; ties -> lowest tile index
         }
-        s.reach = __int_as_float((int)(unsigned)(lo >> 32)) * 1.00001f;
-        s.reach2 = s.reach * s.reach;
+        set_reach(s, __int_as_float((int)(unsigned)(lo >> 32)) * 1.00001f);
         first0 = __shfl((int)(unsigned)lo, 0, 64);
         first1 = __shfl((int)(unsigned)lo, 63, 64);
         if (WITH_RAY) dn = v3(sh.dn[3 * lane], sh.dn[3 * lane + 1], sh.dn[3 * lane + 2]);
@@ -505,8 +507,7 @@ PVAMD_DEV int64_t load_query_point(const MeshArgs& m, MeshShared& sh, const int*
     const int64_t kk = k < P ? k : (P - 1);
     const int64_t i = order ? (int64_t)order[kk] : kk;  // spatially sorted processing; outputs stay in caller order
     s.p = v3(pts[3 * i], pts[3 * i + 1], pts[3 * i + 2]);
-    s.reach = INFINITY;
-    s.reach2 = INFINITY;
+    set_reach(s, INFINITY);
     if (wave == 0) {  // the other waves read these from LDS
         sh.pt[3 * lane] = s.p.x; sh.pt[3 * lane + 1] = s.p.y; sh.pt[3 * lane + 2] = s.p.z;
         if (with_ray) {
@@ -627,8 +628,7 @@ __global__ __launch_bounds__(64 * SLICES) void mesh_query_rest_kernel(MeshArgs m
     }
     {
         const float reach = sqrt_rn(__int_as_float((int)(unsigned)(start >> 32))) * 1.00001f;  // inf while nothing found
-        s.reach = reach;
-        s.reach2 = reach * reach;
+        set_reach(s, reach);
     }
     __syncthreads();
     const V3 dn = v3(sh.dn[3 * lane], sh.dn[3 * lane + 1], sh.dn[3 * lane + 2]);
@@ -670,8 +670,7 @@ __global__ __launch_bounds__(64 * SLICES) void chamfer_mesh_kernel(MeshArgs m, c
     s.p = v3(add_rn(fmaf(M[2], pz, fmaf(M[1], py, mul_rn(M[0], px))), M[3]),
              add_rn(fmaf(M[6], pz, fmaf(M[5], py, mul_rn(M[4], px))), M[7]),
              add_rn(fmaf(M[10], pz, fmaf(M[9], py, mul_rn(M[8], px))), M[11]));
-    s.reach = INFINITY;
-    s.reach2 = INFINITY;
+    set_reach(s, INFINITY);
     if (wave == 0) { sh.pt[3 * lane] = s.p.x; sh.pt[3 * lane + 1] = s.p.y; sh.pt[3 * lane + 2] = s.p.z; }
     scan_mesh<SLICES, false>(m, sh, queue_c[wave], queue_c[wave], s);
     if (wave != 0) return;
