@@ -1,5 +1,6 @@
 #!/bin/bash
-# Build libpvamd with a different mesh.hip (and/or extra -D flags) for A/B timing:  tools/build_variant.sh NAME MESH_SRC [FLAGS...]
+# Build libpvamd with one source file swapped (and/or extra -D flags) for A/B timing:
+#   tools/build_variant.sh NAME SRC.hip [FLAGS...]     SRC's basename (mesh.hip, composed.hip, ...) says which object it replaces
 # -> tools/variants/libpvamd_NAME.so ; run a tool against it with PVAMD_LIB=tools/variants/libpvamd_NAME.so
 set -e
 name=$1; src=$2; shift 2
@@ -7,6 +8,11 @@ cd "$(dirname "$0")/.."
 make -s -C pytorch_volumetric_amd/csrc
 mkdir -p tools/variants
 C=pytorch_volumetric_amd/csrc
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -fno-fast-math -ffp-contract=off -Wno-unused-value -I$C -Iinclude "$@" -c "$src" -o tools/variants/mesh_$name.o
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -o tools/variants/libpvamd_$name.so $C/api.o $C/cached.o $C/composed.o tools/variants/mesh_$name.o $C/chamfer_grid.o $C/xform.o $C/fk.o
+which=$(basename "$src" .hip); which=${which%%_*}
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -fno-fast-math -ffp-contract=off -Wno-unused-value -I$C -Iinclude "$@" -c "$src" -o tools/variants/${which}_$name.o
+objs=""
+for o in api cached composed mesh chamfer_grid xform fk; do
+  if [ $o = $which ]; then objs="$objs tools/variants/${which}_$name.o"; else objs="$objs $C/$o.o"; fi
+done
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -o tools/variants/libpvamd_$name.so $objs
 echo tools/variants/libpvamd_$name.so
