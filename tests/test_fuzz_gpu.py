@@ -1,6 +1,8 @@
 """-m gpu: randomized differential tests, HIP path vs CPU oracle, over many small random configurations -- grid
 shapes and resolutions, ranges far from the origin (where the fp32 index estimate has to fall back to the exact
 division often), float32/float64 index arithmetic, random meshes and poses, awkward point counts."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -10,6 +12,7 @@ from oracle import oracle
 from pytorch_volumetric_amd import mesh_io
 from tests import helpers as H
 
+FUZZ_SCALE = int(os.environ.get("PVAMD_FUZZ_SCALE", "1"))  # PVAMD_FUZZ_SCALE=30 pytest ... for a long campaign
 pytestmark = pytest.mark.gpu
 
 
@@ -42,7 +45,7 @@ def random_cached(rng, f64, far=False):
     return c, rng_np
 
 
-@pytest.mark.parametrize("seed", range(12))
+@pytest.mark.parametrize("seed", range(12 * FUZZ_SCALE))
 def test_cached_query_fuzz(seed):
     rng = np.random.default_rng(seed)
     f64, far = bool(seed % 2), seed % 3 == 0
@@ -76,7 +79,7 @@ def test_cached_query_fuzz(seed):
     assert np.array_equal(c.outside_surface(t, 0.01).cpu().numpy(), oracle.cached_outside(og, pts, 0.01))
 
 
-@pytest.mark.parametrize("seed", range(8))
+@pytest.mark.parametrize("seed", range(8 * FUZZ_SCALE))
 def test_composed_query_fuzz(seed):
     rng = np.random.default_rng(100 + seed)
     S, A = int(rng.integers(1, 12)), int(rng.choice([1, 2, 5]))
@@ -107,7 +110,7 @@ def random_mesh(rng):
     return m
 
 
-@pytest.mark.parametrize("seed", range(10))
+@pytest.mark.parametrize("seed", range(10 * FUZZ_SCALE))
 def test_mesh_query_and_chamfer_fuzz(seed):
     rng = np.random.default_rng(200 + seed)
     obj = pv.MeshObjectFactory(mesh=random_mesh(rng))
