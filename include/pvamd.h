@@ -137,6 +137,22 @@ int pvamd_cached_outside(const pvamd_grid_t* grid, const float* points, int64_t 
 int pvamd_voxel_index(const pvamd_grid_t* grid, const float* points, int64_t P,
                       int64_t* out_key, int64_t* out_flat, uint8_t* out_valid, void* stream);
 
+/* Dense voxel containers addressed by points (VoxelGrid.__getitem__ / __setitem__, voxel.py:97-103, over the value-range
+ * view voxel.py:55): the same index arithmetic as above, reading or writing a caller-owned dense array in C order
+ * (float32, or bytes for torch.bool grids).  grid->vox is not used.
+ * gather:  out[i] = storage[flat(points[i])] where the point passes the range test, invalid_value elsewhere.
+ * scatter: storage[flat(points[i])] = values[i] (or `scalar` when values is NULL) for the points that pass the range test,
+ *          others are ignored.  When several points share a voxel the LAST one in input order wins, as in a sequential
+ *          loop; that needs owner_scratch: device int32 [shape0*shape1*shape2] (required iff values != NULL).      */
+int pvamd_voxel_gather_f32(const pvamd_grid_t* grid, const float* storage, const float* points, int64_t P,
+                           float invalid_value, float* out, void* stream);
+int pvamd_voxel_gather_u8(const pvamd_grid_t* grid, const uint8_t* storage, const float* points, int64_t P,
+                          uint8_t invalid_value, uint8_t* out, void* stream);
+int pvamd_voxel_scatter_f32(const pvamd_grid_t* grid, float* storage, const float* points, const float* values,
+                            float scalar, int64_t P, int32_t* owner_scratch, void* stream);
+int pvamd_voxel_scatter_u8(const pvamd_grid_t* grid, uint8_t* storage, const float* points, const uint8_t* values,
+                           uint8_t scalar, int64_t P, int32_t* owner_scratch, void* stream);
+
 /* ComposedSDF.__call__ over CachedSDF leaves (sdf.py:392-433 + 535-571 fused; also RobotSDF.__call__,
  * model_to_sdf.py:117-125): per configuration a and point p, x_s = T[s*A+a] p for every leaf s, look up leaf
  * s at x_s, rotate that gradient back with R^T, keep the first minimum over s.

@@ -109,6 +109,28 @@ def voxel_index(grid, pts):
     return key, flat, valid.astype(bool)
 
 
+def voxel_gather(grid, storage, pts, invalid_value=0):
+    """VoxelGrid.__getitem__ (voxel.py:97-98 over the value-range view): storage[flat] where the point is within the
+    range, invalid_value elsewhere.  storage: dense C-order array of the grid's shape."""
+    _, flat, valid = voxel_index(grid, pts)
+    store = np.asarray(storage).reshape(-1)
+    out = np.full((len(flat),), invalid_value, dtype=store.dtype)
+    out[valid] = store[flat[valid]]
+    return out
+
+
+def voxel_scatter(grid, storage, pts, value):
+    """VoxelGrid.__setitem__ (voxel.py:100-103): in-range points write, the rest are ignored; points sharing a voxel
+    are applied in input order (numpy index assignment: the last one wins, as in a sequential loop).  In place."""
+    _, flat, valid = voxel_index(grid, pts)
+    store = np.asarray(storage).reshape(-1)
+    if np.ndim(value) > 0:
+        store[flat[valid]] = np.asarray(value).reshape(-1)[valid]
+    else:
+        store[flat[valid]] = value
+    return storage
+
+
 def cached_query(grid, pts):
     pts = _f32(pts).reshape(-1, 3)
     P = len(pts)

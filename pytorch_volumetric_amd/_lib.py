@@ -96,6 +96,14 @@ SIGNATURES = {
     "pvamd_composed_query": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int32, ctypes.c_void_p, ctypes.c_int32,
                                             ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p,
                                             ctypes.c_void_p, ctypes.c_void_p]),
+    "pvamd_voxel_gather_f32": (ctypes.c_int, [ctypes.POINTER(GridDesc), ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64,
+                                              ctypes.c_float, ctypes.c_void_p, ctypes.c_void_p]),
+    "pvamd_voxel_gather_u8": (ctypes.c_int, [ctypes.POINTER(GridDesc), ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64,
+                                             ctypes.c_uint8, ctypes.c_void_p, ctypes.c_void_p]),
+    "pvamd_voxel_scatter_f32": (ctypes.c_int, [ctypes.POINTER(GridDesc), ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
+                                               ctypes.c_float, ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p]),
+    "pvamd_voxel_scatter_u8": (ctypes.c_int, [ctypes.POINTER(GridDesc), ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
+                                              ctypes.c_uint8, ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p]),
     "pvamd_points_aabb": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p]),
     "pvamd_morton_keys": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p,
                                          ctypes.c_void_p]),
