@@ -3,16 +3,16 @@
 //                 where it is a device->host copy, two Embree BVH traversals on CPU threads, ~12 numpy passes)
 //   chamfer_mesh: per-transform sum of (scale*d)^2 over the transformed points         (reference chamfer.py:79-94)
 //
-// fp32-VALU bound, not HBM bound.  Structure:
-//   * pvamd_mesh_prepare turns the soup into 112-byte records (corners, edge vectors, geometric normal, bounding
-//     sphere, original face id) + one bounding sphere per tile of 256 records.
+// fp32-VALU bound, not HBM bound.  Structure (details at "The scan" below):
+//   * pvamd_mesh_prepare turns the soup into 96-byte records (bounding sphere, in-plane bounding rectangle, corners,
+//     original face id) + one bounding sphere per group of 16 and per tile of 256 records.
 //   * a block owns 64 points (one per lane) and SLICES waves; a tile of records is staged into LDS once per block and
-//     its triangles are dealt round-robin to the waves (small P -> many slices so the 1024 SIMDs still fill).
-//   * two-level conservative culling: a tile is skipped when, for every lane of the block, its sphere is farther than
-//     the lane's current best distance AND misses the lane's ray; inside a live tile the same test per triangle,
-//     wave-uniform.  A skipped triangle provably cannot lower a lane's best d^2 nor be hit by its ray, and the exact
-//     tests run on every lane whenever any lane needs them, so results are bit-identical to the plain double loop of
-//     oracle/pvamd_oracle.c.  With spatially sorted triangles and points this is a flat two-level BVH.
+//     its groups are dealt round-robin to the waves (small P -> many slices so the 1024 SIMDs still fill; very small
+//     P -> the tiles of a point group are spread over several blocks as well).
+//   * conservative culling, tile -> group -> record sphere -> rectangle: a record is skipped when it provably cannot
+//     lower a lane's best d^2 nor be hit by its ray.  The survivors are queued as (record, point) pairs and the exact
+//     tests (the oracle's operation sequences) run densely over the queue.  Bit-identical to the plain double loop of
+//     oracle/pvamd_oracle.c; with spatially sorted triangles and points this is a flat three-level BVH.
 //   * ties in d^2 resolve to the lowest ORIGINAL face id (lexicographic min), independent of processing order.
 #include "common.h"
 #include "mesh_math.h"
@@ -778,7 +778,8 @@ static MeshArgs mesh_args(const pvamd_mesh_t& mesh) {
 // How many waves share one 64-point group.  The work per point is heavy-tailed once culling is on (a point near the
 // medial axis of the mesh is equidistant to much of the surface and must test most triangles exactly), so even when
 // there are plenty of points a group is split over 8 waves: it bounds the slowest group's time at 1/8 (measured on
-// C5: 45 ms with one wave per group -> see profiles/), at the price of repeating the per-tile bookkeeping per wave.
+// C5 with the first version of the scan: 45 ms with one wave per group, 18.5 ms with 8), at the price of repeating the
+// point-side bookkeeping per wave.
 #ifndef PVAMD_BIG_SLICES
 #define PVAMD_BIG_SLICES 8
 #endif
