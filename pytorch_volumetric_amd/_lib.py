@@ -161,16 +161,52 @@ def check(code, what):
     raise PvamdError(f"{what}: hipError_t {code}")
 
 
+_gpu_checked = False
+_devices = {}
+
+
 def require_gpu():
     """The compute device of this package.  No GPU -> loud failure (never a silent CPU path)."""
-    if not torch.cuda.is_available():
-        raise PvamdError("pytorch_volumetric_amd needs an AMD MI355X (gfx950) visible to PyTorch-ROCm; "
-                         "torch.cuda.is_available() is False and there is no CPU fallback")
-    return torch.device("cuda", torch.cuda.current_device())
+    global _gpu_checked
+    if not _gpu_checked:  # availability cannot change within a process; the check costs several us per call otherwise
+        if not torch.cuda.is_available():
+            raise PvamdError("pytorch_volumetric_amd needs an AMD MI355X (gfx950) visible to PyTorch-ROCm; "
+                             "torch.cuda.is_available() is False and there is no CPU fallback")
+        torch.cuda.current_device()  # torch's lazy CUDA/HIP initialisation, once
+        _gpu_checked = True
+    index = torch._C._cuda_getDevice()
+    dev = _devices.get(index)
+    if dev is None:
+        dev = _devices[index] = torch.device("cuda", index)
+    return dev
 
 
 def stream_ptr():
-    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    """hipStream_t of torch's current stream on the current device (the raw-handle call: torch.cuda.current_stream()
+    builds a Stream object and re-validates the device, ~8 us)."""
+    if not _gpu_checked:
+        require_gpu()
+    return ctypes.c_void_p(torch._C._cuda_getCurrentRawStream(torch._C._cuda_getDevice()))
+
+
+class on_device:
+    """`with on_device(dev):` = torch.cuda.device(dev) without its per-entry validation when dev is already current."""
+    __slots__ = ("index", "prev")
+
+    def __init__(self, dev):
+        self.index = dev.index if dev.index is not None else torch._C._cuda_getDevice()
+        self.prev = -1
+
+    def __enter__(self):
+        cur = torch._C._cuda_getDevice()
+        if cur != self.index:
+            self.prev = cur
+            torch.cuda.set_device(self.index)
+
+    def __exit__(self, *exc):
+        if self.prev >= 0:
+            torch.cuda.set_device(self.prev)
+        return False
 
 
 def ptr(t):

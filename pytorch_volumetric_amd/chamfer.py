@@ -53,7 +53,7 @@ def batch_chamfer_dist(world_to_object: torch.tensor, model_points_world_frame_e
     sums = torch.empty((B,), dtype=torch.float64, device=dev)
 
     fused_grid = isinstance(obj_sdf, CachedSDF) and obj_sdf.out_of_bounds_strategy == OutOfBoundsStrategy.BOUNDING_BOX
-    with torch.cuda.device(dev):
+    with _lib.on_device(dev):
         if fused_grid:
             desc = obj_sdf._grid_desc()
             _lib.check(lib.pvamd_chamfer_grid(ctypes.byref(desc), _lib.ptr(Wd), B, _lib.ptr(pts), N, float(scale),

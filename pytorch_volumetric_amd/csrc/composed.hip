@@ -232,7 +232,11 @@ extern "C" int pvamd_composed_query(const pvamd_grid_t* grids, int32_t S, const 
     const bool vec_ok = (P % 4 == 0) && aligned_to(points, 16) && aligned_to(out_val, 16) && aligned_to(out_grad, 16);
     // The leaf descriptors live in device memory; whether any of them asks for float64 index arithmetic is not
     // known host-side, so the kernels are built for the general case and test the (wave-uniform) flag per leaf.
-    const int64_t ntiles = vec_ok ? P / kTilePoints : 0;
+    // The wave-tile kernel walks 4 points per lane one after the other: it wins once there are enough 256-point tiles to
+    // fill the chip (1024 SIMDs x a few waves); below that the one-point-per-lane kernel has 4x the parallelism and a
+    // quarter of the latency (100k points x 8 leaves: 36 -> see profiles/ latency numbers).
+    const bool enough = vec_ok && (P / kTilePoints) * (int64_t)A >= 4096;
+    const int64_t ntiles = enough ? P / kTilePoints : 0;
     const int64_t cap = ((int64_t)4096 + A - 1) / A;  // ~4096 blocks in total, split over the A configurations
     if (ntiles > 0) {
         const int64_t need = (ntiles + kWavesPerBlock - 1) / kWavesPerBlock;

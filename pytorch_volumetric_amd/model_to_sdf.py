@@ -92,7 +92,7 @@ class RobotSDF(sdf.ObjectFrameSDF):
         lib = _lib.load()
         dev = _lib.require_gpu()
         offset_inv = self._offset_inv_dev(dev)
-        with torch.cuda.device(dev):
+        with _lib.on_device(dev):
             if hasattr(self.chain, "joint_table"):
                 # on-device FK (pvamd_chain_fk): no per-frame host-driven ops, nothing returns to the host
                 q = joint_config.reshape(-1, M).to(device=dev, dtype=torch.float32).contiguous()

@@ -134,7 +134,7 @@ class ObjectFactory(abc.ABC):
             self._rec_of_face_dev = torch.empty((max(F, 1),), dtype=torch.int32, device=dev)
             lo, hi = self._mesh.aabb()
             abs_margin = 1e-6 * float(np.abs(self._mesh.vertices).max() + np.linalg.norm(hi - lo)) if F else 0.0
-            with torch.cuda.device(dev):
+            with _lib.on_device(dev):
                 _lib.check(lib.pvamd_mesh_prepare(_lib.ptr(self._tri_dev), _lib.ptr(face_id), F, abs_margin,
                                                   _lib.ptr(self._rec_dev), _lib.ptr(self._tiles_dev),
                                                   _lib.ptr(self._rec_of_face_dev), _lib.stream_ptr()),
@@ -179,7 +179,7 @@ class ObjectFactory(abc.ABC):
         face = torch.empty((P,), dtype=torch.int32, device=dev)
         normal = torch.empty((P, 3), dtype=torch.float32, device=dev) if compute_normal else None
         desc = self._mesh_desc()
-        with torch.cuda.device(dev):
+        with _lib.on_device(dev):
             order = _lib.morton_order(flat)
             scratch = None
             if 0 < P <= _lib.MESH_SCRATCH_MAX_POINTS and getattr(self, "tile_split", True):
@@ -296,7 +296,7 @@ class VoxelView:
         ravel = torch.empty((P,), dtype=torch.int64, device=flat.device) if want_flat else None
         valid = torch.empty((P,), dtype=torch.uint8, device=flat.device) if want_valid else None
         desc = self._owner._grid_desc()
-        with torch.cuda.device(flat.device):
+        with _lib.on_device(flat.device):
             _lib.check(lib.pvamd_voxel_index(ctypes.byref(desc), _lib.ptr(flat), P, _lib.ptr(key), _lib.ptr(ravel),
                                              _lib.ptr(valid), _lib.stream_ptr()), "pvamd_voxel_index")
         return (key.reshape(*lead, 3) if want_key else None, ravel.reshape(*lead) if want_flat else None,
@@ -381,7 +381,7 @@ class CachedSDF(ObjectFrameSDF):
         val_d = val.to(device=dev, dtype=torch.float32).contiguous().reshape(-1)
         grad_d = grad.to(device=dev, dtype=torch.float32).contiguous().reshape(-1, 3)
         self._packed = torch.empty((val_d.shape[0], 4), dtype=torch.float32, device=dev)
-        with torch.cuda.device(dev):
+        with _lib.on_device(dev):
             _lib.check(lib.pvamd_pack_grid(_lib.ptr(val_d), _lib.ptr(grad_d), val_d.shape[0], _lib.ptr(self._packed),
                                            _lib.stream_ptr()), "pvamd_pack_grid")
         self.voxels = VoxelView(self)
@@ -427,7 +427,7 @@ class CachedSDF(ObjectFrameSDF):
         lookup_gt = self.out_of_bounds_strategy == OutOfBoundsStrategy.LOOKUP_GT_SDF
         oob = torch.empty((P,), dtype=torch.uint8, device=dev) if lookup_gt else None
         desc = self._grid_desc()
-        with torch.cuda.device(dev):
+        with _lib.on_device(dev):
             _lib.check(lib.pvamd_cached_query(ctypes.byref(desc), _lib.ptr(flat), P, _lib.ptr(val), _lib.ptr(grad),
                                               _lib.ptr(oob), _lib.stream_ptr()), "pvamd_cached_query")
         if lookup_gt:
@@ -468,7 +468,7 @@ class CachedSDF(ObjectFrameSDF):
         flat, lead, _, _ = _lib.as_query_points(points_in_object_frame)
         out = torch.empty((flat.shape[0],), dtype=torch.uint8, device=flat.device)
         desc = self._grid_desc()
-        with torch.cuda.device(flat.device):
+        with _lib.on_device(flat.device):
             _lib.check(lib.pvamd_cached_outside(ctypes.byref(desc), _lib.ptr(flat), flat.shape[0],
                                                 float(surface_level), _lib.ptr(out), _lib.stream_ptr()),
                        "pvamd_cached_outside")
@@ -580,7 +580,7 @@ class ComposedSDF(ObjectFrameSDF):
             out_device = self.sdfs[0].device  # leaves return on their own device (sdf.py:546)
             val = torch.empty((A, P), dtype=torch.float32, device=dev)
             grad = torch.empty((A, P, 3), dtype=torch.float32, device=dev)
-            with torch.cuda.device(dev):
+            with _lib.on_device(dev):
                 _lib.check(lib.pvamd_composed_query(_lib.ptr(self._leaf_grids(dev)), S, _lib.ptr(self._tf_device(dev)),
                                                     A, _lib.ptr(flat), P, _lib.ptr(val), _lib.ptr(grad), None,
                                                     _lib.stream_ptr()), "pvamd_composed_query")

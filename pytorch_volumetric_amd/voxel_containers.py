@@ -57,7 +57,7 @@ class ValueRangeView:
         out = torch.empty((P,), dtype=store.dtype, device=flat.device)
         invalid = self.invalid_value
         fn = lib.pvamd_voxel_gather_u8 if as_bytes else lib.pvamd_voxel_gather_f32
-        with torch.cuda.device(flat.device):
+        with _lib.on_device(flat.device):
             _lib.check(fn(ctypes.byref(self._grid_desc()), _lib.ptr(store), _lib.ptr(flat), P,
                           int(bool(invalid)) if as_bytes else float(invalid), _lib.ptr(out), _lib.stream_ptr()),
                        "pvamd_voxel_gather")
@@ -81,7 +81,7 @@ class ValueRangeView:
         else:
             scalar = value.item() if torch.is_tensor(value) else value
         fn = lib.pvamd_voxel_scatter_u8 if as_bytes else lib.pvamd_voxel_scatter_f32
-        with torch.cuda.device(flat.device):
+        with _lib.on_device(flat.device):
             _lib.check(fn(ctypes.byref(self._grid_desc()), _lib.ptr(store), _lib.ptr(flat), _lib.ptr(values),
                           int(bool(scalar)) if as_bytes else float(scalar), P, _lib.ptr(owner), _lib.stream_ptr()),
                        "pvamd_voxel_scatter")
@@ -225,7 +225,7 @@ def _point_bounds(points):
     if points.is_cuda and points.dtype == torch.float32 and points.dim() == 2 and points.shape[1] == 3:
         flat = points.contiguous()
         box = torch.empty((2, 3), dtype=torch.float32, device=points.device)
-        with torch.cuda.device(points.device):
+        with _lib.on_device(points.device):
             _lib.check(_lib.load().pvamd_points_aabb(_lib.ptr(flat), flat.shape[0], _lib.ptr(box), _lib.stream_ptr()),
                        "pvamd_points_aabb")
         box = box.cpu().numpy()

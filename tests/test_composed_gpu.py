@@ -123,8 +123,9 @@ def test_full_size_c3_properties():
 
 def test_leaf_culling_is_exact_on_coherent_and_far_queries():
     """Grid-ordered points (whole waves far from most leaves -> leaves skipped) and points far outside every leaf must
-    still match the oracle bit for bit; so must a scene where a leaf's grid range is SMALLER than its bounding box."""
-    S, A = 8, 3
+    still match the oracle bit for bit; so must a scene where a leaf's grid range is SMALLER than its bounding box.
+    Sizes are chosen so that the wave-tile kernel (the one that culls; used once tiles x configurations >= 4096) runs."""
+    S, A = 8, 10
     leaves = [make_leaf(f64=(s % 2 == 0), padding=0.05) for s in range(S)]
     tfm = H.random_rigid(S * A, seed=77, trans=1.5)
     comp = pv.ComposedSDF(leaves, None)
@@ -141,7 +142,7 @@ def test_leaf_culling_is_exact_on_coherent_and_far_queries():
     gt = H.drill_like_gt()
     tight = pv.CachedSDF("tight", 0.01, H.padded_range(H.DRILL_BB, -0.02), gt, device="cuda", cache_path=None)
     comp2 = pv.ComposedSDF([tight, leaves[0]], pv.Transform3d(matrix=tfm[:2]))
-    q = H.uniform_points(65_536, [-2.0] * 3, [2.0] * 3, seed=5)
+    q = H.uniform_points(1 << 20, [-2.0] * 3, [2.0] * 3, seed=5)
     v2, g2 = comp2(q.cuda())
     ov, og, _ = oracle.composed_query([H.oracle_grid_from_cached(tight), H.oracle_grid_from_cached(leaves[0])],
                                       tfm[:2].numpy(), 1, q.numpy())
@@ -150,17 +151,19 @@ def test_leaf_culling_is_exact_on_coherent_and_far_queries():
 
 
 def test_more_leaves_than_the_culling_table_holds():
-    """S = 70 > 64: leaves beyond the LDS culling table take the un-culled branch of the same loop."""
-    S = 70
+    """S = 70 > 64: leaves beyond the LDS culling table take the un-culled branch of the same loop (wave-tile kernel:
+    256 tiles x 16 configurations; the 4 leftover points go through the one-point-per-lane kernel)."""
+    S, A = 70, 16
     leaf = make_leaf(res=0.02)
-    tfm = H.random_rigid(S, seed=9, trans=0.8)
-    comp = pv.ComposedSDF([leaf] * S, pv.Transform3d(matrix=tfm))
-    pts = scene_points(4096 + 3, seed=4, extent=1.0)
+    tfm = H.random_rigid(S * A, seed=9, trans=0.8)
+    comp = pv.ComposedSDF([leaf] * S, None)
+    comp.set_transforms(pv.Transform3d(matrix=tfm), batch_dim=(A,))
+    pts = scene_points(65_536 + 4, seed=4, extent=1.0)
     val, grad = comp(pts.cuda())
     og = H.oracle_grid_from_cached(leaf)
-    oval, ograd, oleaf = oracle.composed_query([og] * S, tfm.numpy(), 1, pts.numpy())
-    assert np.array_equal(val.cpu().numpy(), oval[0], equal_nan=True)
-    assert np.array_equal(grad.cpu().numpy(), ograd[0], equal_nan=True)
+    oval, ograd, oleaf = oracle.composed_query([og] * S, tfm.numpy(), A, pts.numpy())
+    assert np.array_equal(val.cpu().numpy(), oval, equal_nan=True)
+    assert np.array_equal(grad.cpu().numpy(), ograd, equal_nan=True)
     assert oleaf.max() >= 64  # the late leaves do win somewhere
 
 
