@@ -784,16 +784,17 @@ static MeshArgs mesh_args(const pvamd_mesh_t& mesh) {
     return m;
 }
 
-// How many waves share one 64-point group.  The work per point is heavy-tailed once culling is on (a point near the
-// medial axis of the mesh is equidistant to much of the surface and must test most triangles exactly), so even when
-// there are plenty of points a group is split over 8 waves: it bounds the slowest group's time at 1/8 (measured on
-// C5 with the first version of the scan: 45 ms with one wave per group, 18.5 ms with 8), at the price of repeating the
-// point-side bookkeeping per wave.
-#ifndef PVAMD_BIG_SLICES
-#define PVAMD_BIG_SLICES 8
-#endif
-static int pick_slices(int64_t point_tiles) {
-    return point_tiles >= (int64_t)kNumCU * 16 ? PVAMD_BIG_SLICES : 16;
+// How many waves share one 64-point group.
+//   few point groups      -> 16, so that the 1024 SIMDs still fill;
+//   many groups           -> 4: the least replicated point-side work (A/B at 2 M points on the 62-tile drill: grid 5.4 ->
+//                            3.3 ms, random box 2.7 -> 1.9 ms, near-surface chamfer 2.0 -> 1.6 ms against 8; 2 is slower);
+//   many groups AND tiles -> 8: the work per group is heavy-tailed (a point near the medial axis is equidistant to much
+//                            of the surface and walks most tiles), and on a mesh of hundreds of tiles the slowest
+//                            groups, not the throughput, set the kernel time (C5, 389 tiles: 8.2 ms with 8, 9.5 with 4,
+//                            16 with 2; 45 ms with one wave per group in the first version of the scan).
+static int pick_slices(int64_t point_tiles, int mesh_tiles) {
+    if (point_tiles < (int64_t)kNumCU * 16) return 16;
+    return mesh_tiles > 128 ? 8 : 4;
 }
 
 }  // namespace pvamd
@@ -864,8 +865,9 @@ extern "C" int pvamd_mesh_query(const pvamd_mesh_t* mesh, const float* points, c
         hipLaunchKernelGGL(mesh_query_finish_kernel, dim3((unsigned)ptiles), dim3(64), 0, s, m, order, points, P, scratch, out);
         return (int)hipGetLastError();
     }
-    switch (pick_slices(ptiles)) {
+    switch (pick_slices(ptiles, ntiles)) {
         case 8: hipLaunchKernelGGL((mesh_query_kernel<8>), dim3((unsigned)ptiles), dim3(512), 0, s, m, order, points, P, jitter_seed, index_base, out); break;
+        case 4: hipLaunchKernelGGL((mesh_query_kernel<4>), dim3((unsigned)ptiles), dim3(256), 0, s, m, order, points, P, jitter_seed, index_base, out); break;
         default: hipLaunchKernelGGL((mesh_query_kernel<16>), dim3((unsigned)ptiles), dim3(1024), 0, s, m, order, points, P, jitter_seed, index_base, out); break;
     }
     return (int)hipGetLastError();
@@ -887,8 +889,9 @@ extern "C" int pvamd_chamfer_mesh(const pvamd_mesh_t* mesh, const float* W, int3
     // y-dimension of a HIP grid is limited to 65535: walk B in slabs
     for (int32_t b0 = 0; b0 < B; b0 += 65535) {
         const int32_t nb = (B - b0) < 65535 ? (B - b0) : 65535;
-        switch (pick_slices(ptiles * nb)) {
+        switch (pick_slices(ptiles * nb, (mesh->F + kTile - 1) / kTile)) {
             case 8: hipLaunchKernelGGL((chamfer_mesh_kernel<8>), dim3((unsigned)ptiles, nb), dim3(512), 0, s, m, order, W + 16 * (int64_t)b0, points, N, scale, out_sum + b0); break;
+            case 4: hipLaunchKernelGGL((chamfer_mesh_kernel<4>), dim3((unsigned)ptiles, nb), dim3(256), 0, s, m, order, W + 16 * (int64_t)b0, points, N, scale, out_sum + b0); break;
             default: hipLaunchKernelGGL((chamfer_mesh_kernel<16>), dim3((unsigned)ptiles, nb), dim3(1024), 0, s, m, order, W + 16 * (int64_t)b0, points, N, scale, out_sum + b0); break;
         }
     }

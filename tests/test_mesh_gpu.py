@@ -152,14 +152,31 @@ def test_large_sphere_mesh_distance_close_to_analytic():
     assert ((val.cpu() < 0) == (ref < -1e-3))[ref.abs() > 1e-3].all()
 
 
-@pytest.mark.parametrize("n,slices", [(300, 16), (70_000, 16), (300_000, 8)])
+@pytest.mark.parametrize("n,slices", [(300, 16), (70_000, 16), (300_000, 4)])
 def test_every_slice_configuration_matches_oracle(n, slices):
-    """The kernel picks 16 or 8 triangle slices per 64-point group from the point count; unsorted (n < 2048) and
-    Morton-sorted processing orders are both covered.  All must reproduce the plain double loop bit for bit."""
+    """The kernel picks 16, 8 or 4 waves per 64-point group from the point count and the mesh size (8: many points AND
+    more than 128 tiles, covered by the sphere / chamfer tests); unsorted (n < 2048) and Morton-sorted processing
+    orders are both covered.  All must reproduce the plain double loop bit for bit."""
     obj = factory("probe.obj")
     bb = obj.bounding_box(padding_ratio=0.5)
     pts = H.uniform_points(n, bb[:, 0], bb[:, 1], seed=n)
     assert_query_matches(obj, pts, seed=n)
+
+
+def test_eight_wave_configuration_on_a_mesh_of_many_tiles():
+    """Many points AND more than 128 tiles (> 32,768 triangles) -> 8 waves per point group.  The oracle checks a prefix
+    of the batch (points are independent; the jitter is indexed by global point id)."""
+    obj = pv.MeshObjectFactory(mesh=mesh_io.uv_sphere_mesh(0.1, 150, 120, scale=(1.0, 0.7, 1.3)))
+    assert obj.num_faces > 128 * 256
+    pts = H.uniform_points(1 << 18, [-0.16] * 3, [0.16] * 3, seed=8)
+    obj.jitter_seed = 5
+    res = obj.object_frame_closest_point(pts.cuda(), compute_normal=True)
+    n = 12_000
+    oc, od, og, of, on = oracle.mesh_query(H.oracle_mesh_from_factory(obj), pts[:n].numpy(), seed=5)
+    assert np.array_equal(obj._last_face_ids[:n].cpu().numpy(), of)
+    assert np.array_equal(res.closest[:n].cpu().numpy(), oc)
+    assert np.array_equal(res.distance[:n].cpu().numpy(), od)
+    assert np.array_equal(res.gradient[:n].cpu().numpy(), og)
 
 
 def test_culling_is_exact_for_far_and_degenerate_queries():

@@ -29,4 +29,9 @@ grid = grid.cuda()
 out.append("drill grid %d pts %.2f ms" % (grid.shape[0], timed(lambda: gt(grid), 4)))
 pts = H.uniform_points(10000, [-0.2] * 3, [0.2] * 3, seed=1).cuda()
 out.append("C1-like 10k random %.3f ms" % timed(lambda: gt(pts), 10))
+big = H.uniform_points(1 << 20, [-0.2] * 3, [0.3] * 3, seed=3).cuda()
+out.append("1M random box %.2f ms" % timed(lambda: gt(big), 3))
+surf, _, _ = pv.sample_mesh_points(drill, num_points=1 << 21, seed=0, dbpath=None, device="cuda")
+surf = (surf + 0.001 * torch.randn_like(surf)).float()
+out.append("2M near-surface chamfer %.2f ms" % timed(lambda: pv.batch_chamfer_dist(W, surf, drill), 3))
 print(os.environ.get("PVAMD_LIB", "default"), " | ".join(out))
