@@ -785,7 +785,7 @@ static MeshArgs mesh_args(const pvamd_mesh_t& mesh) {
 }
 
 // How many waves share one 64-point group.
-//   few point groups      -> 16, so that the 1024 SIMDs still fill;
+//   few point groups      -> 16 (then 8), so that the 1024 SIMDs still fill;
 //   many groups           -> 4: the least replicated point-side work (A/B at 2 M points on the 62-tile drill: grid 5.4 ->
 //                            3.3 ms, random box 2.7 -> 1.9 ms, near-surface chamfer 2.0 -> 1.6 ms against 8; 2 is slower);
 //   many groups AND tiles -> 8: the work per group is heavy-tailed (a point near the medial axis is equidistant to much
@@ -793,7 +793,8 @@ static MeshArgs mesh_args(const pvamd_mesh_t& mesh) {
 //                            groups, not the throughput, set the kernel time (C5, 389 tiles: 8.2 ms with 8, 9.5 with 4,
 //                            16 with 2; 45 ms with one wave per group in the first version of the scan).
 static int pick_slices(int64_t point_tiles, int mesh_tiles) {
-    if (point_tiles < (int64_t)kNumCU * 16) return 16;
+    if (point_tiles < (int64_t)kNumCU * 4) return 16;
+    if (point_tiles < (int64_t)kNumCU * 16) return 8;  // 100k random points on the drill: 0.65 (16) / 0.56 (8) / 0.60 ms (4)
     return mesh_tiles > 128 ? 8 : 4;
 }
 
