@@ -34,7 +34,7 @@ out.append("1M random box %.2f ms" % timed(lambda: gt(big), 3))
 surf, _, _ = pv.sample_mesh_points(drill, num_points=1 << 21, seed=0, dbpath=None, device="cuda")
 surf = (surf + 0.001 * torch.randn_like(surf)).float()
 out.append("2M near-surface chamfer %.2f ms" % timed(lambda: pv.batch_chamfer_dist(W, surf, drill), 3))
-for n in (30_000, 100_000, 300_000):
+for n in (3_000, 10_000, 30_000, 60_000, 100_000, 200_000):
     q = H.uniform_points(n, [-0.2] * 3, [0.3] * 3, seed=n).cuda()
     out.append("%dk random %.3f ms" % (n // 1000, timed(lambda: gt(q), 6)))
 print(os.environ.get("PVAMD_LIB", "default"), " | ".join(out))
