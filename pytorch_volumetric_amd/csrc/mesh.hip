@@ -859,14 +859,15 @@ extern "C" int pvamd_mesh_query(const pvamd_mesh_t* mesh, const float* points, c
     // few point groups, many tiles: spread each group's tiles over `parts` blocks (see mesh_query_first_kernel)
     // (A/B on the drill, 3k..60k random points: 16 waves x <=16 parts 0.175 / 0.222 / 0.391 / 0.539 ms; 8 waves x <=31 parts
     // 0.164 / 0.183 / 0.331 / 0.405; 4 waves x <=31 parts 0.227 / 0.214 / 0.281 / 0.394)
-    const int split_waves = ptiles >= 256 ? 4 : 8;
+    const int split_waves = ptiles >= 256 ? 4 : (ptiles >= 32 ? 8 : 16);  // (1k points: 69 us with 16 waves, 87 with 8)
     int parts = (int)((int64_t)kNumCU * (split_waves == 4 ? 32 : 16) / ptiles);
     if (parts > 31) parts = 31;
     if (parts > ntiles / 4) parts = ntiles / 4;
     if (scratch && parts >= 2 && ptiles <= (int64_t)kNumCU * 8) {  // beyond ~130k points the single launch wins
         hipLaunchKernelGGL((mesh_query_first_kernel<16>), dim3((unsigned)ptiles), dim3(1024), 0, s, m, order, points, P, jitter_seed, index_base, scratch);
         if (split_waves == 4) hipLaunchKernelGGL((mesh_query_rest_kernel<4>), dim3((unsigned)ptiles, (unsigned)parts), dim3(256), 0, s, m, order, points, P, jitter_seed, index_base, scratch);
-        else hipLaunchKernelGGL((mesh_query_rest_kernel<8>), dim3((unsigned)ptiles, (unsigned)parts), dim3(512), 0, s, m, order, points, P, jitter_seed, index_base, scratch);
+        else if (split_waves == 8) hipLaunchKernelGGL((mesh_query_rest_kernel<8>), dim3((unsigned)ptiles, (unsigned)parts), dim3(512), 0, s, m, order, points, P, jitter_seed, index_base, scratch);
+        else hipLaunchKernelGGL((mesh_query_rest_kernel<16>), dim3((unsigned)ptiles, (unsigned)parts), dim3(1024), 0, s, m, order, points, P, jitter_seed, index_base, scratch);
         hipLaunchKernelGGL(mesh_query_finish_kernel, dim3((unsigned)ptiles), dim3(64), 0, s, m, order, points, P, scratch, out);
         return (int)hipGetLastError();
     }
