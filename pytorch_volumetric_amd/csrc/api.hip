@@ -39,10 +39,11 @@ extern "C" int pvamd_grid_finalize(pvamd_grid_t* g) {
         g->vlo[d] = flo;
         g->vhi[d] = fhi;
         g->inv32[d] = (float)(1.0 / res);
-        // |t32 - exact| <= (|p| + 2|min|) * 2^-24 / res + |t| * 2^-23 (+ float64 round-off, negligible): fold the
-        // constant parts into one per-dimension coefficient applied to (|p| + 1), with a 2x safety margin
-        const double amin = std::fabs(lo);
-        g->err32[d] = (float)(2.0 * 5.97e-8 / res * (1.0 + 2.0 * amin));
+        // |t32 - exact| <= (|p| + 2|min|) * 2^-24 / res + |t| * 2^-23 (+ float64 round-off, negligible).  The estimate is
+        // only ever used for in-range p, where |p| <= max(|lo|, |hi|) and |t| <= shape: one constant per dimension, with
+        // a 2x safety margin on the first term
+        const double amin = std::fabs(lo), pmax = std::fmax(std::fabs(lo), std::fabs(hi));
+        g->err32[d] = (float)((2.0 * 5.97e-8 / res * (1.0 + 2.0 * amin)) * (pmax + 1.0) + 2.5e-7 * (double)g->shape[d]);
     }
     g->finalized = 1;
     return 0;

@@ -68,8 +68,7 @@ PVAMD_DEV int voxel_index_fast(const pvamd_grid_t& g, int d, float p) {
     const float t = mul_rn(sub_rn(p, g.fmin[d]), g.inv32[d]);
     const float kc = __builtin_rintf(t);
     const float half_dist = sub_rn(0.5f, fabsf(sub_rn(t, kc)));
-    const float bound = fmaf(g.err32[d], add_rn(fabsf(p), 1.f), mul_rn(2.5e-7f, fabsf(t)));
-    if (half_dist > bound) return (int)kc;  // NaN-safe: any NaN fails the comparison and takes the exact path
+    if (half_dist > g.err32[d]) return (int)kc;  // NaN-safe: any NaN fails the comparison and takes the exact path
     long long k;
     voxel_index_1d<F64>(g, d, p, k);
     return (int)k;
