@@ -236,15 +236,20 @@ def nasty_mesh(rng, offset):
     return mesh_io.TriMesh(verts, np.arange(len(verts)).reshape(-1, 3))
 
 
-@pytest.mark.parametrize("offset", [(0.0, 0.0, 0.0), (300.0, -200.0, 100.0)])
-def test_slivers_degenerate_and_duplicate_triangles_match_oracle(offset):
+@pytest.mark.parametrize("offset,scale", [((0.0, 0.0, 0.0), 1.0), ((300.0, -200.0, 100.0), 1.0),
+                                          ((0.0, 0.0, 0.0), 1e-3), ((2.0, 1.0, -3.0), 1e3), ((5e3, 5e3, 5e3), 1.0)])
+def test_slivers_degenerate_and_duplicate_triangles_match_oracle(offset, scale):
+    """also at mm and km scale, and 5 km from the origin (fp32 cancellation in every bound)"""
     rng = np.random.default_rng(7)
-    obj = pv.MeshObjectFactory(mesh=nasty_mesh(rng, offset))
+    obj = pv.MeshObjectFactory(mesh=nasty_mesh(rng, offset).scaled(scale))
     bb = obj.bounding_box(padding_ratio=0.1)
     pts = H.uniform_points(6000, bb[:, 0], bb[:, 1], seed=5)
-    # plus points exactly on corners and straddling the needles
+    # plus points exactly on corners, straddling the needles, and in the planes of the huge faces
     on = torch.from_numpy(obj._mesh.vertices[::7].astype(np.float32))
-    assert_query_matches(obj, torch.cat((pts, on, on + 1e-4)), seed=3)
+    soup = obj._mesh.triangle_soup()[-48:-40].astype(np.float32)  # the huge faces
+    w = np.random.default_rng(11).dirichlet((0.3, 0.3, 0.3), size=(8, 60)).astype(np.float32)
+    in_plane = torch.from_numpy(np.einsum("fsk,fkd->fsd", w * 1.6 - 0.2, soup).reshape(-1, 3))
+    assert_query_matches(obj, torch.cat((pts, on, on + 1e-4 * float(scale), in_plane)), seed=3)
 
 
 def test_points_aabb_ignores_non_finite_coordinates():
