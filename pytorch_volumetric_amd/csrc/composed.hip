@@ -237,7 +237,10 @@ extern "C" int pvamd_composed_query(const pvamd_grid_t* grids, int32_t S, const 
     // quarter of the latency (100k points x 8 leaves: 36 -> see profiles/ latency numbers).
     const bool enough = vec_ok && (P / kTilePoints) * (int64_t)A >= 4096;
     const int64_t ntiles = enough ? P / kTilePoints : 0;
-    const int64_t cap = ((int64_t)4096 + A - 1) / A;  // ~4096 blocks in total, split over the A configurations
+    // up to ~65536 blocks in total, split over the A configurations: about one 256-point tile per wave.  (Sweep on C4,
+    // 200 x 262,144: 1024 blocks 1.40 ms, 4096 1.17, 8192 1.13, 32768 1.09, 65536 1.08 -- the hardware dispatcher
+    // balances better than a grid-stride loop over unequal tiles.)
+    const int64_t cap = ((int64_t)65536 + A - 1) / A;
     if (ntiles > 0) {
         const int64_t need = (ntiles + kWavesPerBlock - 1) / kWavesPerBlock;
         const unsigned gx = (unsigned)(need < cap ? need : (cap < 1 ? 1 : cap));
