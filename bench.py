@@ -2,17 +2,25 @@
 """Headline benchmark: SDF (value + gradient) queries/sec -- BASELINE.json configs[1] ("C2"):
 CachedSDF at 0.01 m voxels on the YCB power drill, 1M query points per GPU per step.
 
+    python bench.py --gpus N --steps K --warmup W
+
 One "step" = one pass of the hot path over one batch: a single `pvamd_cached_query` C-ABI call (one kernel launch)
 over the rank's 1,048,576 resident query points, writing sdf_val [P] and sdf_grad [P,3].  Inputs are in HBM before
-the timed region.  N > 1: one process per GPU, each with its own batch (weak scaling), no data-path collective
-(pass --gather to time the RCCL all-gather of (val, grad) as well).
+the timed region.  `--gpus N` with N > 1 and no torchrun environment re-launches itself as N ranks (one process per
+GPU, RCCL); under torchrun it uses the ranks it was given.  The headline line is weak scaling (every rank its own
+1M-point batch, no data-path collective); the `legs` object carries the configs BASELINE.json names for multi-GPU:
+C4 (RobotSDF, 200 configurations x 262,144 points) strong-scaled over points with the results left sharded and with
+the RCCL all-gather in the timed step, and C5 (chamfer, 2M points -> 99,500 triangles) with its B-float all-reduce.
 
-Prints ONE JSON line (rank 0) with `roofline` (HBM, algorithmic 28 B/query over the per-launch duration measured with
-HIP events on the launch stream) and `cpu_baseline` (the C oracle on the host cores, bounded sample).
+Prints ONE JSON line (rank 0).  `value`/`ms_per_step` are the wall time of exactly the K steps asked for.
+`roofline` is the dominant kernel (pvamd::cached_query_wave): algorithmic 28 B/query over the kernel's per-launch
+duration, which is measured live but SEPARATELY from the K timed steps (HIP events around a >=2000-launch hipGraph of
+the same call on the same buffers), so that it does not depend on K.  `cpu_baseline` = the C oracle on the host cores.
 """
 import argparse
 import json
 import os
+import socket
 import sys
 import time
 
@@ -20,12 +28,10 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-import numpy as np
-import torch
-import torch.distributed as dist
-
-HBM_PEAK_GBS = 8000.0  # MI355X datasheet (MI355X_MICROARCH.md); ~6290 GB/s is the measured float4-copy ceiling
+HBM_PEAK_GBS = 8000.0  # MI355X datasheet (MI355X_MICROARCH.md); 6.3-6.5 TB/s is what a float4 copy reaches (profiles/)
 BYTES_PER_QUERY = 28   # 12 B point read + 4 B value + 12 B gradient written
+BYTES_PER_PAIR_C4 = 16  # C4: 4 B value + 12 B gradient written per (configuration, point); points are re-read from L2
+KERNEL_GRAPH_LAUNCHES = 2000
 
 
 def parse_args():
@@ -34,45 +40,125 @@ def parse_args():
     ap.add_argument("--steps", type=int, default=2000)
     ap.add_argument("--warmup", type=int, default=200)
     ap.add_argument("--points", type=int, default=1 << 20, help="query points per GPU per step")
-    ap.add_argument("--gather", action="store_true", help="all-gather (val, grad) across ranks inside each step")
     ap.add_argument("--no-graph", action="store_true", help="time eager launches instead of one hipGraph of K steps")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-large", action="store_true", help="skip the secondary 64M-point (cache-exceeding) run")
+    ap.add_argument("--no-legs", action="store_true", help="skip the C4 / C5 legs")
+    ap.add_argument("--small-legs", action="store_true", help="functional test: C4 with 8 x 16,384 and C5 with 65,536 points")
     ap.add_argument("--cpu-seconds", type=float, default=4.0, help="wall budget of the CPU baseline sample")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL over xGMI)")
+    ap.add_argument("--share-gpu", action="store_true",
+                    help="functional test on a 1-GPU box: every rank uses cuda:0 and collectives go through gloo")
+    ap.add_argument("--launch-check", action="store_true",
+                    help="no GPU work: start the ranks, all-reduce over gloo, print the rank count (CPU test of --gpus N)")
     return ap.parse_args()
 
 
-def build_workload(points_per_gpu, rank):
-    import pytorch_volumetric_amd as pv
-    from tests import helpers as H
-    obj = pv.MeshObjectFactory(H.mesh_path("ycb_power_drill.npz"))
-    # the cache is filled on-device by the brute-force mesh kernel (48,840 voxel centres x 15,728 triangles)
-    cached = pv.CachedSDF("YcbPowerDrill", 0.01, obj.bounding_box(padding=0.1), pv.MeshSDF(obj), device="cuda",
-                          cache_path=None)
-    lo = np.array([r[0] for r in cached.ranges]) - 0.05
-    hi = np.array([r[1] for r in cached.ranges]) + 0.05
-    g = torch.Generator(device="cuda").manual_seed(1234 + rank)
-    lo_t = torch.tensor(lo, dtype=torch.float32, device="cuda")
-    hi_t = torch.tensor(hi, dtype=torch.float32, device="cuda")
-    pts = torch.rand((points_per_gpu, 3), generator=g, device="cuda") * (hi_t - lo_t) + lo_t
-    return cached, pts.contiguous()
+def free_port():
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
 
 
-def time_eager_kernel(cached, pts, val, grad, reps):
-    """Average duration of ONE launch, HIP events recorded on the launch stream around each launch."""
+def spawn_ranks_if_needed(args):
+    """`python bench.py --gpus N` outside torchrun: become `torch.distributed.run --nproc-per-node N bench.py ...`."""
+    if args.gpus <= 1 or "WORLD_SIZE" in os.environ:
+        return
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC: RCCL between processes needs it on this driver
+    sys.stdout.flush()
+    os.execv(sys.executable, cmd)
+
+
+def launch_check(args, rank, world):
+    import torch
+    import torch.distributed as dist
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("gloo")
+        t = torch.ones(1)
+        dist.all_reduce(t)
+        ranks = int(t.item())
+        dist.destroy_process_group()
+    else:
+        ranks = 1
+    if rank == 0:
+        print(json.dumps({"launch_check": True, "n_gpus": world, "ranks_seen_by_all_reduce": ranks,
+                          "gpus_requested": args.gpus}))
+
+
+class Timer:
+    """barrier + synchronize on both sides of the timed call; MAX over ranks; the device wait is an event-query spin
+    followed by the synchronize (hipDeviceSynchronize alone adds tens of us of host wake-up to a ~0.1 ms region)."""
+
+    def __init__(self, torch, dist, world):
+        self.torch, self.dist, self.world = torch, dist, world
+
+    def barrier(self):
+        if self.world > 1:
+            self.dist.barrier()
+
+    def __call__(self, fn):
+        torch = self.torch
+        done = torch.cuda.Event()
+        self.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        fn()
+        done.record()
+        while not done.query():
+            pass
+        torch.cuda.synchronize()
+        elapsed = time.perf_counter() - t0
+        self.barrier()
+        if self.world > 1:
+            t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+            self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
+            elapsed = t.item()
+        return elapsed
+
+
+def capture_graph(torch, fn, n):
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph, stream=side):
+            for _ in range(n):
+                fn()
+    torch.cuda.current_stream().wait_stream(side)
+    return graph
+
+
+def graph_ms_per_launch(torch, graph, n, reps=3):
+    """HIP events on the launch stream around one replay of an n-launch graph, / n; best of `reps`."""
+    best = float("inf")
+    for _ in range(reps):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        graph.replay()
+        e1.record()
+        torch.cuda.synchronize()
+        best = min(best, e0.elapsed_time(e1) / n)
+    return best
+
+
+def time_eager_kernel(torch, np, fn, reps):
     starts = [torch.cuda.Event(enable_timing=True) for _ in range(reps)]
     ends = [torch.cuda.Event(enable_timing=True) for _ in range(reps)]
     torch.cuda.synchronize()
     for i in range(reps):
         starts[i].record()
-        cached.query_into(pts, val, grad)
+        fn()
         ends[i].record()
     torch.cuda.synchronize()
     ms = [s.elapsed_time(e) for s, e in zip(starts, ends)]
     return float(np.mean(ms)), float(np.median(ms)), float(np.min(ms))
 
 
-def cpu_baseline(cached, pts, seconds):
+def cpu_baseline(torch, np, cached, pts, seconds):
+    """The oracle (CPU restatement) on the host cores, bounded sample.  Only reached after every GPU timing is done."""
     from oracle import oracle
     from tests import helpers as H
     og = H.oracle_grid_from_cached(cached)
@@ -112,172 +198,247 @@ def cpu_baseline(cached, pts, seconds):
     return out
 
 
+def read_traffic(P):
+    """HBM-side bytes per launch from the committed PMC passes (NOT measured in this run: rocprofv3 --pmc cannot run
+    inside the benchmark)."""
+    for name in ("r02_traffic.json", "traffic.json"):
+        path = os.path.join(ROOT, "profiles", name)
+        if os.path.exists(path):
+            try:
+                tj = json.load(open(path))
+                if tj.get("points") == P:
+                    return tj.get("hbm_bytes_per_launch"), (
+                        f"profiles/{name}: rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE passes of this workload "
+                        "(FETCH_SIZE x2, the gfx950 correction of MI355X_MICROARCH.md); read from the committed file, "
+                        "not measured in this run")
+            except Exception:
+                pass
+    return None, "no committed PMC pass for this point count"
+
+
+# ------------------------------------------------------------------------------------------------ legs: C4 and C5
+def leg_c4(torch, dist, Wk, pv, timer, rank, world, steps, padding, with_gather, small=False):
+    """BASELINE configs[3]: RobotSDF (7-DOF, 8 links), A=200 joint configurations x P=262,144 points, the POINTS
+    sharded over the ranks (strong scaling: the total work is fixed).  Leg 1 leaves (val, grad) sharded -- no
+    collective; leg 2 times ShardedSDF.__call__: query + RCCL all-gather of val and grad + the strided copy back to
+    (A, P[, 3]) order (model_to_sdf.py:117-125 on every rank's slice)."""
+    A, P = (8, 1 << 14) if small else (200, 1 << 18)
+    robot = Wk.build_c4(resolution=0.02, padding=padding)
+    robot.set_joint_configuration(Wk.c4_joint_configs(A))
+    pts = Wk.c4_points(P)
+    start, stop, chunk = pv.shard_range(P, world, rank)
+    mine = pts[start:stop].contiguous()
+    n = mine.shape[0]
+    val = torch.empty((A, n), dtype=torch.float32, device="cuda")
+    grad = torch.empty((A, n, 3), dtype=torch.float32, device="cuda")
+
+    def sharded_steps():
+        for _ in range(steps):
+            robot.query_into(mine, val, grad)
+
+    for _ in range(3):
+        robot.query_into(mine, val, grad)
+    t = timer(sharded_steps)
+    pairs = A * P * steps
+    out = {"config": f"C4: RobotSDF 8 links, link grids res 0.02 padding {padding}, A={A} x P={P}, points sharded x{world}",
+           "scaling": "strong", "n_gpus": world, "steps": steps, "unit": "(configuration, point) pairs/s",
+           "link_grid_voxels": [int(s._packed.shape[0]) for s in robot.sdf.sdfs],
+           "sharded": {"gather": False, "value": pairs / t, "ms_per_step": t / steps * 1e3,
+                       "roofline": {"bound": "hbm", "achieved": BYTES_PER_PAIR_C4 * pairs / t / 1e9, "peak": HBM_PEAK_GBS * world,
+                                    "unit": "GB/s", "frac": BYTES_PER_PAIR_C4 * pairs / t / 1e9 / (HBM_PEAK_GBS * world),
+                                    "note": "16 B written per pair; the kernel itself is VALU-bound (DESIGN.md 3.2)"}}}
+    if with_gather and world > 1:
+        sharded = pv.ShardedSDF(robot, gather=True, compute_device=torch.device("cuda"))
+        gsteps = max(2, steps // 4)
+        full = None
+
+        def gather_steps():
+            nonlocal full
+            for _ in range(gsteps):
+                full = sharded(pts)
+
+        sharded(pts)
+        tg = timer(gather_steps)
+        out["gathered"] = {"gather": True, "value": A * P * gsteps / tg, "ms_per_step": tg / gsteps * 1e3, "steps": gsteps,
+                           "collective": f"all_gather_into_tensor x2 ({dist.get_backend()}), "
+                                         f"{A * P * 16 * (world - 1) // world} B received per rank per step",
+                           "output_shape": [list(full[0].shape), list(full[1].shape)]}
+    else:
+        out["gathered"] = None if world > 1 else {"gather": True, "note": "single rank: nothing to gather, same as `sharded`"}
+    return out
+
+
+def leg_c5(torch, dist, Wk, pv, timer, rank, world, steps, small=False):
+    """BASELINE configs[4]: unidirectional chamfer, 2,097,152 source points -> 99,500-triangle mesh, the source
+    points sharded over the ranks; each rank reduces its slice, then ONE all-reduce of B float64 partial sums (+ the
+    count) -- chamfer.py:79-94 with the mean taken over the global N."""
+    N = (1 << 16) if small else (1 << 21)
+    mesh = Wk.build_c5_mesh()
+    pts = Wk.c5_points(N)
+    W = torch.eye(4).unsqueeze(0).cuda()
+    err = None
+
+    def run():
+        nonlocal err
+        for _ in range(steps):
+            if world > 1:
+                err = pv.sharded_chamfer(W, pts, obj_factory=mesh, scale=1000.0)
+            else:
+                err = pv.batch_chamfer_dist(W, pts, obj_factory=mesh, scale=1000.0)
+
+    run()
+    t = timer(run)
+    F = mesh.num_faces
+    analytic = float((((pts.norm(dim=-1) - 0.1) * 1000.0) ** 2).mean())
+    return {"config": f"C5: chamfer, {N} points -> {F}-triangle sphere mesh, points sharded x{world}, B=1",
+            "scaling": "strong", "n_gpus": world, "steps": steps, "unit": "points/s", "value": N * steps / t,
+            "ms_per_step": t / steps * 1e3, "brute_force_equivalent_pairs_per_s": N * F * steps / t,
+            "collective": None if world == 1 else f"all_reduce of B=1 float64 sums + count ({dist.get_backend()})",
+            "chamfer_mm2": float(err[0]), "analytic_sphere_mm2": analytic,
+            "rel_err_vs_analytic": abs(float(err[0]) - analytic) / analytic}
+
+
 def main():
     args = parse_args()
+    spawn_ranks_if_needed(args)
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.launch_check:
+        launch_check(args, rank, world)
+        return
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X visible to PyTorch-ROCm (no CPU path exists)")
+    if args.share_gpu:
+        local_rank, backend = 0, "gloo"
+    else:
+        backend = args.backend
+        if world > torch.cuda.device_count():
+            raise SystemExit(f"bench.py: {world} ranks but only {torch.cuda.device_count()} GPU(s) visible "
+                             "(one process per GPU; --share-gpu is the 1-GPU functional test)")
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-    cached, pts = build_workload(args.points, rank)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend)
+    import pytorch_volumetric_amd as pv
+    import workloads as Wk
+    timer = Timer(torch, dist, world)
+
+    cached = Wk.build_c2_cache()
+    pts = Wk.c2_points(cached, args.points, seed=1234 + rank)
     P = pts.shape[0]
     val = torch.empty((P,), dtype=torch.float32, device="cuda")
     grad = torch.empty((P, 3), dtype=torch.float32, device="cuda")
-    gathered = None
-    if args.gather and world > 1:
-        packed = torch.empty((P, 4), dtype=torch.float32, device="cuda")
-        gathered = torch.empty((world, P, 4), dtype=torch.float32, device="cuda")
 
     def step():
         cached.query_into(pts, val, grad)
-        if gathered is not None:
-            packed[:, 0] = val
-            packed[:, 1:] = grad
-            dist.all_gather_into_tensor(gathered, packed)
-
-    def barrier():
-        if world > 1:
-            dist.barrier()
 
     for _ in range(args.warmup):
         step()
     torch.cuda.synchronize()
 
-    use_graph = not args.no_graph and gathered is None
     graph = None
-    if use_graph:
-        # the launch-bound inner loop (a ~5 us kernel) captured once: K launches, one replay
-        side = torch.cuda.Stream()
-        side.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(side):
-            graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(graph, stream=side):
-                for _ in range(args.steps):
-                    cached.query_into(pts, val, grad)
-        torch.cuda.current_stream().wait_stream(side)
+    if not args.no_graph:
+        # the launch-bound inner loop (a ~6 us kernel) captured once: K launches, one replay
+        graph = capture_graph(torch, step, args.steps)
         # untimed: the first replay uploads the graph; the rest let the clocks settle (MI355X DVFS needs a few thousand
-        # of these ~6 us launches, MI355X_MICROARCH.md) when the caller asks for a short K / W.  The timed region below is
-        # still exactly K steps.
-        settle = max(1, -(-3000 // max(args.steps, 1)))
-        for _ in range(settle):
+        # of these ~6 us launches, MI355X_MICROARCH.md) when the caller asks for a short K / W.  Each replay is
+        # synchronised: a burst of un-synchronised replays leaves the HIP runtime with housekeeping that the NEXT launch
+        # call pays for (measured, tools/k20_probe.py: the launch call returns after ~200 us instead of ~15 us).  The
+        # timed region below is still exactly K steps.
+        for _ in range(max(3, -(-3000 // max(args.steps, 1)))):
             graph.replay()
-        torch.cuda.synchronize()
+            torch.cuda.synchronize()
 
-    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    barrier()
+    def k_steps():
+        if graph is not None:
+            graph.replay()
+        else:
+            for _ in range(args.steps):
+                step()
+
+    elapsed = timer(k_steps)
+
+    # ---- the dominant kernel's per-launch duration, independent of K: events around a separate >=2000-launch graph ----
+    kg_n = max(KERNEL_GRAPH_LAUNCHES, args.steps)
+    kgraph = capture_graph(torch, step, kg_n)
+    kgraph.replay()
     torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    ev0.record()  # HIP events on the launch stream, bracketing exactly the K timed steps
-    if graph is not None:
-        graph.replay()
-    else:
-        for _ in range(args.steps):
-            step()
-    ev1.record()
-    torch.cuda.synchronize()
-    barrier()
-    elapsed = time.perf_counter() - t0
-    region_ms = ev0.elapsed_time(ev1)
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = t.item()
-
-    # per-launch duration for the roofline: the HIP-event time of the timed region / K (back-to-back launches of the
-    # one kernel); eager launches individually bracketed by events are reported next to it (they carry ~2 us of
-    # event/launch overhead each on a ~10 us kernel)
-    k_mean = region_ms / args.steps
-    e_mean, e_med, e_min = time_eager_kernel(cached, pts, val, grad, min(args.steps, 200))
-
-    # parity spot check inside the bench: GPU result of the timed workload vs the oracle on a slice
-    from oracle import oracle
-    from tests import helpers as H
-    n_chk = min(P, 50_000)
-    oval, ograd, ooob = oracle.cached_query(H.oracle_grid_from_cached(cached), pts[:n_chk].cpu().numpy())
-    max_err = float(np.nanmax(np.abs(val[:n_chk].cpu().numpy() - oval)))
-    grad_mismatch = int((~np.isclose(grad[:n_chk].cpu().numpy(), ograd, rtol=0, atol=0, equal_nan=True)).sum())
+    k_ms = graph_ms_per_launch(torch, kgraph, kg_n)
+    del kgraph
+    e_mean, e_med, e_min = time_eager_kernel(torch, np, step, 200)
 
     out = None
     if rank == 0:
         qps = world * P * args.steps / elapsed
-        achieved = BYTES_PER_QUERY * P / (k_mean * 1e-3) / 1e9
-        traffic = None
-        tpath = os.path.join(ROOT, "profiles", "traffic.json")
-        if os.path.exists(tpath):
-            try:
-                tj = json.load(open(tpath))
-                if tj.get("points") == P:
-                    traffic = tj.get("hbm_bytes_per_launch")
-            except Exception:
-                traffic = None
+        achieved = BYTES_PER_QUERY * P / (k_ms * 1e-3) / 1e9
+        traffic, traffic_source = read_traffic(P)
         out = {
             "metric": "SDF (val+grad) queries/sec", "value": qps, "unit": "queries/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "C2: CachedSDF 0.01 m voxels (37x33x40, packed 16 B/voxel) on YcbPowerDrill, "
                                    f"{P} uniform query points per GPU per step, BOUNDING_BOX out-of-range fallback",
-                       "points_per_gpu": P, "oob_fraction": float(ooob.mean()),
-                       "index_dtype": "f64" if cached._view.index_f64 else "f32",
-                       "launch": "hipGraph of K steps" if graph is not None else "eager",
-                       "gather": bool(gathered is not None), "parallelism": f"points x{world}"},
+                       "points_per_gpu": P, "index_dtype": "f64" if cached._view.index_f64 else "f32",
+                       "launch": "one hipGraph of the K steps" if graph is not None else "eager",
+                       "timed_region": "barrier + synchronize | K steps | event-query spin + synchronize | barrier; "
+                                       "max over ranks",
+                       "gather": False, "parallelism": f"points x{world}", "ranks": world,
+                       "backend": (dist.get_backend() if world > 1 else None), "gpus_requested": args.gpus},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "kernel": "pvamd::cached_query_wave", "launch_ms_mean": k_mean,
-                         "timing": "HIP events on the launch stream around the K timed steps, / K",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
+                         "kernel": "pvamd::cached_query_wave", "launch_ms_mean": k_ms,
+                         "timing": f"HIP events on the launch stream around a SEPARATE hipGraph of {kg_n} launches of the "
+                                   f"same call on the same buffers, / {kg_n} (best of 3 replays); NOT the K timed steps, "
+                                   "so it does not change with --steps",
                          "eager_launch_ms": {"mean": e_mean, "median": e_med, "min": e_min},
                          "algorithmic_bytes_per_launch": BYTES_PER_QUERY * P,
-                         "copy_kernel_ceiling_GBs_r01": 5200.0},
-            "parity": {"checked_points": n_chk, "max_abs_val_err_vs_oracle": max_err,
-                       "grad_mismatches_vs_oracle": grad_mismatch},
+                         "frac_of_wall_ms_per_step": BYTES_PER_QUERY * P / (elapsed / args.steps) / 1e9 / HBM_PEAK_GBS},
         }
-        if not args.no_cpu_baseline and world == 1:  # the CPU baseline is timed on rank 0 of the 1-GPU run only
-            out["cpu_baseline"] = cpu_baseline(cached, pts, args.cpu_seconds)
+
+    legs = {}
+    if not args.no_legs:
+        leg_steps = 20
+        sm = args.small_legs
+        for name, fn in (("c4", lambda: leg_c4(torch, dist, Wk, pv, timer, rank, world, leg_steps, 0.1, True, sm)),
+                         ("c4_readme_grid", lambda: leg_c4(torch, dist, Wk, pv, timer, rank, world, leg_steps, 1.0, False, sm)),
+                         ("c5", lambda: leg_c5(torch, dist, Wk, pv, timer, rank, world, 5, sm))):
+            try:
+                legs[name] = fn()
+            except Exception as exc:  # a failing leg must not take the headline line with it
+                legs[name] = {"error": repr(exc)}
+            torch.cuda.empty_cache()
+    if rank == 0:
+        out["legs"] = legs
 
     if not args.no_large and rank == 0 and world == 1:
         # secondary: the same batch size with EVERY point inside the cached range (every query gathers a 16-B record)
-        lo_in = torch.tensor([r[0] for r in cached.ranges], dtype=torch.float32, device="cuda") + 1e-4
-        hi_in = torch.tensor([r[1] for r in cached.ranges], dtype=torch.float32, device="cuda") - 1e-4
-        g_in = torch.Generator(device="cuda").manual_seed(7)
-        pin = (torch.rand((P, 3), generator=g_in, device="cuda") * (hi_in - lo_in) + lo_in).contiguous()
+        pin = Wk.c2_points(cached, P, seed=7, margin=-1e-4)
         for _ in range(50):
             cached.query_into(pin, val, grad)
-        reps = 1000
-        side2 = torch.cuda.Stream()
-        side2.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(side2):
-            g2 = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g2, stream=side2):
-                for _ in range(reps):
-                    cached.query_into(pin, val, grad)
-        torch.cuda.current_stream().wait_stream(side2)
+        g2 = capture_graph(torch, lambda: cached.query_into(pin, val, grad), 1000)
         g2.replay()
         torch.cuda.synchronize()
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        g2.replay()
-        e1.record()
-        torch.cuda.synchronize()
-        t_in = e0.elapsed_time(e1) / reps
+        t_in = graph_ms_per_launch(torch, g2, 1000)
         out["all_in_range_batch"] = {"points": P, "ms_per_launch": t_in, "queries_per_s": P / (t_in * 1e-3),
                                      "achieved_GBs": BYTES_PER_QUERY * P / (t_in * 1e-3) / 1e9,
                                      "frac_of_8TBs": BYTES_PER_QUERY * P / (t_in * 1e-3) / 1e9 / HBM_PEAK_GBS}
-        del g2
-
+        del g2, pin
         # secondary: a batch far beyond the 256 MB Infinity Cache, where the kernel is HBM- rather than launch-bound
         PL = 1 << 26
-        g = torch.Generator(device="cuda").manual_seed(99)
-        lo = torch.tensor([r[0] for r in cached.ranges], dtype=torch.float32, device="cuda") - 0.05
-        hi = torch.tensor([r[1] for r in cached.ranges], dtype=torch.float32, device="cuda") + 0.05
-        big = (torch.rand((PL, 3), generator=g, device="cuda") * (hi - lo) + lo).contiguous()
+        big = Wk.c2_points(cached, PL, seed=99)
         bval = torch.empty((PL,), dtype=torch.float32, device="cuda")
         bgrad = torch.empty((PL, 3), dtype=torch.float32, device="cuda")
-        for _ in range(60):  # the chip needs ~20 launches of this size to settle its clocks (DVFS ramp: 0.50 -> 0.41 ms)
+        for _ in range(60):  # the chip needs ~20 launches of this size to settle its clocks (DVFS ramp)
             cached.query_into(big, bval, bgrad)
-        _, m, mn = time_eager_kernel(cached, big, bval, bgrad, 40)
+        _, m, mn = time_eager_kernel(torch, np, lambda: cached.query_into(big, bval, bgrad), 40)
         out["large_batch"] = {"points": PL, "kernel_ms_median": m, "kernel_ms_min": mn,
                               "queries_per_s": PL / (m * 1e-3),
                               "achieved_GBs": BYTES_PER_QUERY * PL / (m * 1e-3) / 1e9,
@@ -285,6 +446,21 @@ def main():
         del big, bval, bgrad
 
     if rank == 0:
+        # ---- everything below uses the oracle: only after all GPU timing ----
+        from oracle import oracle
+        from tests import helpers as H
+        n_chk = min(P, 50_000)
+        step()
+        torch.cuda.synchronize()
+        oval, ograd, ooob = oracle.cached_query(H.oracle_grid_from_cached(cached), pts[:n_chk].cpu().numpy())
+        max_err = float(np.nanmax(np.abs(val[:n_chk].cpu().numpy() - oval)))
+        grad_mismatch = int((~np.isclose(grad[:n_chk].cpu().numpy(), ograd, rtol=0, atol=0, equal_nan=True)).sum())
+        out["config"]["oob_fraction"] = float(ooob.mean())
+        out["parity"] = {"checked_points": n_chk, "max_abs_val_err_vs_oracle": max_err,
+                         "grad_mismatches_vs_oracle": grad_mismatch,
+                         "oracle": "oracle/pvamd_oracle.c (in-repo CPU restatement; third-party arithmetic UNPINNED)"}
+        if not args.no_cpu_baseline and world == 1:  # the CPU baseline is timed on rank 0 of the 1-GPU run only
+            out["cpu_baseline"] = cpu_baseline(torch, np, cached, pts, args.cpu_seconds)
         print(json.dumps(out))
     if world > 1:
         dist.barrier()

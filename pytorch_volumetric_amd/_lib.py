@@ -216,13 +216,16 @@ def ptr(t):
     return ctypes.c_void_p(t.data_ptr())
 
 
-def as_query_points(points):
-    """[..., 3] any float dtype / device  ->  (contiguous fp32 [P,3] on the GPU, leading shape, dtype, device)."""
+def as_query_points(points, device=None):
+    """[..., 3] any float dtype / device  ->  (contiguous fp32 [P,3] on the GPU, leading shape, dtype, device).
+
+    `device`: the GPU that owns the grid / mesh the points will be looked up in (the kernel dereferences raw pointers
+    of that device, so the points and the launch must be there too); None = the current device."""
     if not torch.is_tensor(points):
         points = torch.as_tensor(points)
     if points.shape[-1] != 3:
         raise ValueError(f"query points must have last dimension 3, got {tuple(points.shape)}")
-    dev = require_gpu()
+    dev = require_gpu() if device is None else device
     lead = points.shape[:-1]
     flat = points.detach().reshape(-1, 3).to(device=dev, dtype=torch.float32).contiguous()
     return flat, lead, points.dtype if points.dtype.is_floating_point else torch.float32, points.device

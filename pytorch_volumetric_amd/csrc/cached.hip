@@ -176,7 +176,10 @@ extern "C" int pvamd_cached_query(const pvamd_grid_t* grid, const float* points,
     const int64_t ntiles = vec_ok ? P / kTilePoints : 0;
     if (ntiles > 0) {
         const int64_t need = (ntiles + kWavesPerBlock - 1) / kWavesPerBlock;
-        const dim3 grid_dim((unsigned)(need < 1024 ? need : 1024)), block(kWavesPerBlock * 64);  // 4 waves/SIMD
+#ifndef PVAMD_CQ_BLOCKS
+#define PVAMD_CQ_BLOCKS 1024
+#endif
+        const dim3 grid_dim((unsigned)(need < PVAMD_CQ_BLOCKS ? need : PVAMD_CQ_BLOCKS)), block(kWavesPerBlock * 64);
         const f32x4* p4 = reinterpret_cast<const f32x4*>(points);
         f32x4* v4 = reinterpret_cast<f32x4*>(out_val);
         f32x4* g4 = reinterpret_cast<f32x4*>(out_grad);

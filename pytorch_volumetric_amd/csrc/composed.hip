@@ -123,14 +123,14 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void composed_query_wave(const
                                                                            int64_t ntiles, int64_t P,
                                                                            float* __restrict__ val,
                                                                            float* __restrict__ grad,
-                                                                           int* __restrict__ leaf) {
+                                                                           int* __restrict__ leaf, int a0) {
     __shared__ __attribute__((aligned(16))) float lds[kWavesPerBlock][1024];
     __shared__ float cull[kMaxCullLeaves][8];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     float* spf = lds[wave];
     f32x4_alias* sp = reinterpret_cast<f32x4_alias*>(spf);
     float* svf = spf + 768;
-    const int a = blockIdx.y;
+    const int a = a0 + blockIdx.y;
     build_cull_spheres(grids, S, tf, A, a, cull);
     __syncthreads();
     const int64_t wstride = (int64_t)gridDim.x * kWavesPerBlock;
@@ -197,8 +197,8 @@ __global__ __launch_bounds__(256) void composed_query_scalar(const pvamd_grid_t*
                                                               const float* __restrict__ tf, int A,
                                                               const float* __restrict__ pts, int64_t first,
                                                               int64_t P, float* __restrict__ val,
-                                                              float* __restrict__ grad, int* __restrict__ leaf) {
-    const int a = blockIdx.y;
+                                                              float* __restrict__ grad, int* __restrict__ leaf, int a0) {
+    const int a = a0 + blockIdx.y;
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     for (int64_t i = first + (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < P; i += stride) {
         const float px = pts[3 * i], py = pts[3 * i + 1], pz = pts[3 * i + 2];
@@ -224,7 +224,7 @@ using namespace pvamd;
 extern "C" int pvamd_composed_query(const pvamd_grid_t* grids, int32_t S, const float* tf, int32_t A,
                                     const float* points, int64_t P, float* out_val, float* out_grad,
                                     int32_t* out_leaf, void* stream) {
-    if (S < 1 || A < 1 || A > 65535 || P < 0) return PVAMD_E_SHAPE;
+    if (S < 1 || A < 1 || P < 0) return PVAMD_E_SHAPE;
     if (P == 0) return 0;
     if (!grids || !tf || !out_val || !out_grad || !points) return PVAMD_E_NULL;
     if (!aligned_to(grids, 8) || !aligned_to(tf, 4) || !aligned_to(points, 4)) return PVAMD_E_ALIGN;
@@ -240,19 +240,25 @@ extern "C" int pvamd_composed_query(const pvamd_grid_t* grids, int32_t S, const 
     // up to ~65536 blocks in total, split over the A configurations: about one 256-point tile per wave.  (Sweep on C4,
     // 200 x 262,144: 1024 blocks 1.40 ms, 4096 1.17, 8192 1.13, 32768 1.09, 65536 1.08 -- the hardware dispatcher
     // balances better than a grid-stride loop over unequal tiles.)
-    const int64_t cap = ((int64_t)65536 + A - 1) / A;
-    if (ntiles > 0) {
-        const int64_t need = (ntiles + kWavesPerBlock - 1) / kWavesPerBlock;
-        const unsigned gx = (unsigned)(need < cap ? need : (cap < 1 ? 1 : cap));
-        hipLaunchKernelGGL((composed_query_wave<true, PVAMD_COMPOSED_PPP>), dim3(gx, A), dim3(kWavesPerBlock * 64), 0, s, grids, S, tf, A,
-                           reinterpret_cast<const f32x4*>(points), ntiles, P, out_val, out_grad, out_leaf);
-    }
-    const int64_t first = ntiles * kTilePoints;
-    if (first < P) {
-        const int64_t need = (P - first + 255) / 256;
-        const unsigned gx = (unsigned)(need < cap ? need : (cap < 1 ? 1 : cap));
-        hipLaunchKernelGGL((composed_query_scalar<true>), dim3(gx, A), dim3(256), 0, s, grids, S, tf, A, points, first,
-                           P, out_val, out_grad, out_leaf);
+    // gridDim.y carries the configuration: at most 65535 per launch, so larger batches go out in slabs (the kernels
+    // take the slab's first configuration and index transforms / outputs with the global one)
+    constexpr int kSlab = 65535;
+    for (int a0 = 0; a0 < A; a0 += kSlab) {
+        const int An = A - a0 < kSlab ? A - a0 : kSlab;
+        const int64_t cap = ((int64_t)65536 + An - 1) / An;
+        if (ntiles > 0) {
+            const int64_t need = (ntiles + kWavesPerBlock - 1) / kWavesPerBlock;
+            const unsigned gx = (unsigned)(need < cap ? need : (cap < 1 ? 1 : cap));
+            hipLaunchKernelGGL((composed_query_wave<true, PVAMD_COMPOSED_PPP>), dim3(gx, An), dim3(kWavesPerBlock * 64), 0, s, grids, S, tf, A,
+                               reinterpret_cast<const f32x4*>(points), ntiles, P, out_val, out_grad, out_leaf, a0);
+        }
+        const int64_t first = ntiles * kTilePoints;
+        if (first < P) {
+            const int64_t need = (P - first + 255) / 256;
+            const unsigned gx = (unsigned)(need < cap ? need : (cap < 1 ? 1 : cap));
+            hipLaunchKernelGGL((composed_query_scalar<true>), dim3(gx, An), dim3(256), 0, s, grids, S, tf, A, points, first,
+                               P, out_val, out_grad, out_leaf, a0);
+        }
     }
     return (int)hipGetLastError();
 }

@@ -72,7 +72,15 @@ class ShardedSDF:
         val = _all_gather_cat(val, -1, self.group)[..., :P]
         grad = _all_gather_cat(grad, -2, self.group)[..., :P, :]
         batch = tuple(val.shape[:-1])
+        if self._returns_flat():
+            return val.reshape(*batch, -1), grad.reshape(*batch, -1, 3)
         return val.reshape(*batch, *lead), grad.reshape(*batch, *lead, 3)
+
+    def _returns_flat(self):
+        """A ComposedSDF (or RobotSDF) WITHOUT a transform batch returns flat (P,) / (P,3) even for batched points
+        (reference sdf.py:418-426,433); the wrapper keeps the wrapped SDF's own convention."""
+        inner = getattr(self.sdf, "sdf", self.sdf)  # RobotSDF -> its ComposedSDF
+        return hasattr(inner, "tsf_batch") and hasattr(inner, "sdfs") and inner.tsf_batch is None
 
     def _query(self, pts, index_base):
         # MeshSDF's sign jitter is indexed by the global point number so sharding does not change the result

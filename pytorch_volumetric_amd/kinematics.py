@@ -193,7 +193,9 @@ def build_chain_from_urdf(urdf_text: str, end_link_name: Optional[str] = None, r
     child_names = set()
     for je in root.findall("joint"):
         axis_e = je.find("axis")
-        axis = [float(v) for v in axis_e.get("xyz").split()] if axis_e is not None else (1.0, 0.0, 0.0)
+        # a joint without <axis>: pytorch_kinematics, which the reference drives (model_to_sdf.py:99), falls back to
+        # z = (0, 0, 1) (frame.Joint's default), not the URDF specification's (1, 0, 0); drop-in parity follows pk
+        axis = [float(v) for v in axis_e.get("xyz").split()] if axis_e is not None else (0.0, 0.0, 1.0)
         joint = Joint(je.get("name"), je.get("type"), axis, _origin_matrix(je.find("origin")))
         parent, child = je.find("parent").get("link"), je.find("child").get("link")
         children.setdefault(parent, []).append((joint, child))

@@ -99,17 +99,98 @@ def _parse_stl(data):
     return v, np.arange(len(v), dtype=np.int64).reshape(-1, 3)
 
 
+def _parse_ply(data):
+    """PLY, ascii or binary_little_endian: vertex x/y/z (float/double) and a face list property of vertex indices."""
+    end = data.index(b"end_header")
+    end = data.index(b"\n", end) + 1
+    header = data[:end].decode("ascii", "ignore").splitlines()
+    fmt, elements, cur = None, [], None
+    for line in header:
+        tok = line.split()
+        if not tok:
+            continue
+        if tok[0] == "format":
+            fmt = tok[1]
+        elif tok[0] == "element":
+            cur = {"name": tok[1], "count": int(tok[2]), "props": []}
+            elements.append(cur)
+        elif tok[0] == "property" and cur is not None:
+            cur["props"].append(tok[1:])
+    np_types = {"char": "i1", "int8": "i1", "uchar": "u1", "uint8": "u1", "short": "i2", "int16": "i2", "ushort": "u2",
+                "uint16": "u2", "int": "i4", "int32": "i4", "uint": "u4", "uint32": "u4", "float": "f4", "float32": "f4",
+                "double": "f8", "float64": "f8"}
+    verts, faces = None, []
+    if fmt == "ascii":
+        lines = data[end:].decode("ascii", "ignore").split("\n")
+        at = 0
+        for el in elements:
+            rows = [ln.split() for ln in lines[at:at + el["count"]]]
+            at += el["count"]
+            if el["name"] == "vertex":
+                names = [pr[-1] for pr in el["props"]]
+                ix = [names.index(c) for c in "xyz"]
+                verts = np.array([[float(r[i]) for i in ix] for r in rows], dtype=np.float64).reshape(-1, 3)
+            elif el["name"] == "face":
+                for r in rows:
+                    idx = [int(t) for t in r[1:1 + int(r[0])]]
+                    faces.extend((idx[0], idx[k], idx[k + 1]) for k in range(1, len(idx) - 1))
+    elif fmt == "binary_little_endian":
+        at = end
+        for el in elements:
+            if el["name"] == "vertex":
+                dt = np.dtype([(pr[-1], "<" + np_types[pr[0]]) for pr in el["props"]])
+                rec = np.frombuffer(data, dtype=dt, count=el["count"], offset=at)
+                verts = np.stack([rec[c].astype(np.float64) for c in "xyz"], axis=1)
+                at += dt.itemsize * el["count"]
+            elif el["name"] == "face":
+                lists = [pr for pr in el["props"] if pr[0] == "list"]
+                if len(lists) != 1 or len(el["props"]) != 1:
+                    raise ValueError("PLY faces with extra per-face properties are not supported")
+                ct, it = np.dtype("<" + np_types[lists[0][1]]), np.dtype("<" + np_types[lists[0][2]])
+                for _ in range(el["count"]):
+                    n = int(np.frombuffer(data, dtype=ct, count=1, offset=at)[0])
+                    at += ct.itemsize
+                    idx = np.frombuffer(data, dtype=it, count=n, offset=at)
+                    at += it.itemsize * n
+                    faces.extend((int(idx[0]), int(idx[k]), int(idx[k + 1])) for k in range(1, n - 1))
+            else:
+                raise ValueError(f"PLY element {el['name']} before the faces is not supported")
+    else:
+        raise ValueError(f"unsupported PLY format {fmt}")
+    if verts is None:
+        raise ValueError("PLY file has no vertex element")
+    return verts, np.array(faces, dtype=np.int64).reshape(-1, 3)
+
+
+SUPPORTED_MESH_EXTENSIONS = (".obj", ".stl", ".ply", ".npz")
+
+
 def load_mesh(path):
-    """.obj (text), .stl (ascii/binary) or .npz with arrays `vertices` [V,3] and `faces` [F,3]."""
+    """.obj (text), .stl (ascii/binary), .ply (ascii/binary little endian) or .npz with arrays `vertices` [V,3] and
+    `faces` [F,3].  STL repeats every vertex per triangle; identical positions are merged (as open3d does when it
+    reads an STL) so that center() and the vertex count match the reference loader.  Anything else -- .dae in
+    particular, which needs the scene transforms assimp applies -- raises instead of yielding an empty mesh."""
     ext = os.path.splitext(path)[1].lower()
+    if ext not in SUPPORTED_MESH_EXTENSIONS:
+        raise ValueError(f"unsupported mesh format '{ext}' ({path}); supported: {', '.join(SUPPORTED_MESH_EXTENSIONS)}. "
+                         "Convert the mesh (e.g. to .obj) or pass a TriMesh through `mesh=`.")
     if ext == ".npz":
         with np.load(path) as z:
-            return TriMesh(z["vertices"], z["faces"])
-    if ext == ".stl":
+            mesh = TriMesh(z["vertices"], z["faces"])
+    elif ext == ".stl":
         with open(path, "rb") as f:
-            return TriMesh(*_parse_stl(f.read()))
-    with open(path, "r") as f:
-        return TriMesh(*_parse_obj(f.read()))
+            v, faces = _parse_stl(f.read())
+        uniq, inverse = np.unique(v, axis=0, return_inverse=True)
+        mesh = TriMesh(uniq, inverse.reshape(-1)[faces])
+    elif ext == ".ply":
+        with open(path, "rb") as f:
+            mesh = TriMesh(*_parse_ply(f.read()))
+    else:
+        with open(path, "r") as f:
+            mesh = TriMesh(*_parse_obj(f.read()))
+    if len(mesh.faces) == 0 or len(mesh.vertices) == 0:
+        raise ValueError(f"mesh file {path} has {len(mesh.vertices)} vertices and {len(mesh.faces)} triangles")
+    return mesh
 
 
 def save_obj(path, mesh):

@@ -3,6 +3,7 @@
 configuration; `pvamd_transform_stack` (f32 MFMA) contracts them with the visual offsets into the leaf-major
 object->leaf stack that the fused ComposedSDF kernel consumes."""
 import logging
+import math
 import typing
 
 import numpy as np
@@ -84,7 +85,8 @@ class RobotSDF(sdf.ObjectFrameSDF):
         joint_config = torch.as_tensor(joint_config)
         if len(joint_config.shape) > 1:
             self.configuration_batch = tuple(joint_config.shape[:-1])
-            joint_config = joint_config.reshape(-1, M)
+            # a chain of fixed joints only has M == 0: reshape(-1, 0) cannot infer the batch
+            joint_config = joint_config.reshape(math.prod(self.configuration_batch), M)
         else:
             self.configuration_batch = None
         self.q = joint_config
@@ -95,7 +97,8 @@ class RobotSDF(sdf.ObjectFrameSDF):
         with _lib.on_device(dev):
             if hasattr(self.chain, "joint_table"):
                 # on-device FK (pvamd_chain_fk): no per-frame host-driven ops, nothing returns to the host
-                q = joint_config.reshape(-1, M).to(device=dev, dtype=torch.float32).contiguous()
+                q = joint_config.reshape(1 if joint_config.dim() == 1 else joint_config.shape[0], M).to(
+                    device=dev, dtype=torch.float32).contiguous()
                 A = q.shape[0]
                 joints, F = self._joint_table_dev(dev)
                 sin_q, cos_q = torch.sin(q), torch.cos(q)

@@ -290,7 +290,7 @@ class VoxelView:
 
     def _index(self, points, want_key=False, want_flat=False, want_valid=False):
         lib = _lib.load()
-        flat, lead, _, device = _lib.as_query_points(points)
+        flat, lead, _, device = _lib.as_query_points(points, self._owner._packed.device)
         P = flat.shape[0]
         key = torch.empty((P, 3), dtype=torch.int64, device=flat.device) if want_key else None
         ravel = torch.empty((P,), dtype=torch.int64, device=flat.device) if want_flat else None
@@ -419,7 +419,8 @@ class CachedSDF(ObjectFrameSDF):
     def __call__(self, points_in_object_frame):
         """sdf.py:535-591"""
         lib = _lib.load()
-        flat, lead, dtype, _ = _lib.as_query_points(points_in_object_frame)
+        # the launch happens on the GPU that holds the grid, whatever device is current in the calling code
+        flat, lead, dtype, _ = _lib.as_query_points(points_in_object_frame, self._packed.device)
         P = flat.shape[0]
         dev = flat.device
         val = torch.empty((P,), dtype=torch.float32, device=dev)
@@ -452,20 +453,24 @@ class CachedSDF(ObjectFrameSDF):
             raise ValueError("query_into needs the fused BOUNDING_BOX strategy")
         if not (points.is_cuda and points.dtype == torch.float32 and points.is_contiguous()):
             raise ValueError("query_into needs contiguous fp32 points on the GPU")
+        if not (points.device == self._packed.device == out_val.device == out_grad.device):
+            raise _lib.PvamdError(f"query_into: the grid lives on {self._packed.device}; points / outputs are on "
+                                  f"{points.device} / {out_val.device} / {out_grad.device}")
         P = points.shape[0]
         if out_val.shape != (P,) or out_grad.shape != (P, 3) or out_val.dtype != torch.float32 or \
                 out_grad.dtype != torch.float32 or not (out_val.is_contiguous() and out_grad.is_contiguous()):
             raise ValueError("query_into needs contiguous fp32 outputs of shape (P,) and (P,3)")
         if getattr(self, "_desc_cache", None) is None:
             self._desc_cache = self._grid_desc()
-        _lib.check(_lib.load().pvamd_cached_query(ctypes.byref(self._desc_cache), _lib.ptr(points), P,
-                                                  _lib.ptr(out_val), _lib.ptr(out_grad), None, _lib.stream_ptr()),
-                   "pvamd_cached_query")
+        with _lib.on_device(points.device):
+            _lib.check(_lib.load().pvamd_cached_query(ctypes.byref(self._desc_cache), _lib.ptr(points), P,
+                                                      _lib.ptr(out_val), _lib.ptr(out_grad), None, _lib.stream_ptr()),
+                       "pvamd_cached_query")
 
     def outside_surface(self, points_in_object_frame, surface_level=0):
         """sdf.py:593-602"""
         lib = _lib.load()
-        flat, lead, _, _ = _lib.as_query_points(points_in_object_frame)
+        flat, lead, _, _ = _lib.as_query_points(points_in_object_frame, self._packed.device)
         out = torch.empty((flat.shape[0],), dtype=torch.uint8, device=flat.device)
         desc = self._grid_desc()
         with _lib.on_device(flat.device):
@@ -508,7 +513,7 @@ class ComposedSDF(ObjectFrameSDF):
         (sdf.py:379) and cannot slice with it; only its explicit batch_dim path works."""
         if tsf is None:
             self.obj_frame_to_link_frame, self.link_frame_to_obj_frame = None, []
-            self.tsf_batch, self._tf_dev = batch_dim, None
+            self.tsf_batch, self._tf_dev, self._rigid = batch_dim, None, True
             return
         m = tf.as_matrix(tsf)
         S, S_tsf = len(self.sdfs), m.shape[0]
@@ -523,7 +528,12 @@ class ComposedSDF(ObjectFrameSDF):
         # validated: now commit
         self.tsf_batch, self._tf_dev = batch_dim, None
         self.obj_frame_to_link_frame = tsf if hasattr(tsf, "get_matrix") else tf.Transform3d(matrix=m)
-        inv = tf.rigid_inverse(m)
+        # The reference inverts with a general matrix inverse (sdf.py:380).  Rigid stacks (every RobotSDF stack, and
+        # what the fused kernel's leaf-culling spheres and R^T gradient rotation assume) use the exact R^T form;
+        # anything else -- scale, shear, a drifted rotation -- takes the general inverse and the unfused path, whose
+        # x = L p + t and g_obj = L^T g_leaf are valid for any affine transform.
+        self._rigid = tf.is_rigid(m)
+        inv = tf.rigid_inverse(m) if self._rigid else torch.linalg.inv(m)
         self.link_frame_to_obj_frame = [tf.Transform3d(matrix=inv[self.ith_transform_slice(i)]) for i in range(S)]
 
     def surface_bounding_box(self, **kwargs):
@@ -545,9 +555,16 @@ class ComposedSDF(ObjectFrameSDF):
 
     # ---- fused path ----
     def _fusable(self):
-        return len(self.sdfs) > 0 and all(
+        return len(self.sdfs) > 0 and getattr(self, "_rigid", True) and all(
             isinstance(s, CachedSDF) and s.out_of_bounds_strategy == OutOfBoundsStrategy.BOUNDING_BOX
             for s in self.sdfs)
+
+    def _owner_device(self):
+        """The one GPU every leaf grid lives on (the fused kernel reads all of them through raw pointers)."""
+        devs = {s._packed.device for s in self.sdfs}
+        if len(devs) != 1:
+            raise _lib.PvamdError(f"ComposedSDF: leaf grids live on different devices {sorted(map(str, devs))}")
+        return next(iter(devs))
 
     def _leaf_grids(self, dev):
         key = tuple((id(s), s._packed.data_ptr()) for s in self.sdfs) + (str(dev),)
@@ -572,10 +589,11 @@ class ComposedSDF(ObjectFrameSDF):
             points_in_object_frame = torch.as_tensor(points_in_object_frame)
         pts_shape = points_in_object_frame.shape
         out_device = points_in_object_frame.device
-        flat, _, dtype, _ = _lib.as_query_points(points_in_object_frame)
+        fused = self._fusable()
+        flat, _, dtype, _ = _lib.as_query_points(points_in_object_frame, self._owner_device() if fused else None)
         P = flat.shape[0]
         dev = flat.device
-        if self._fusable():
+        if fused:
             lib = _lib.load()
             out_device = self.sdfs[0].device  # leaves return on their own device (sdf.py:546)
             val = torch.empty((A, P), dtype=torch.float32, device=dev)
@@ -607,10 +625,14 @@ class ComposedSDF(ObjectFrameSDF):
                 out_grad.dtype != torch.float32 or not (out_val.is_contiguous() and out_grad.is_contiguous()):
             raise ValueError("query_into needs contiguous fp32 outputs with A*P and A*P*3 elements")
         dev = points.device
-        _lib.check(_lib.load().pvamd_composed_query(_lib.ptr(self._leaf_grids(dev)), len(self.sdfs),
-                                                    _lib.ptr(self._tf_device(dev)), A, _lib.ptr(points), P,
-                                                    _lib.ptr(out_val), _lib.ptr(out_grad), None, _lib.stream_ptr()),
-                   "pvamd_composed_query")
+        if not (dev == self._owner_device() == out_val.device == out_grad.device):
+            raise _lib.PvamdError(f"query_into: the leaf grids live on {self._owner_device()}; points / outputs are on "
+                                  f"{dev} / {out_val.device} / {out_grad.device}")
+        with _lib.on_device(dev):
+            _lib.check(_lib.load().pvamd_composed_query(_lib.ptr(self._leaf_grids(dev)), len(self.sdfs),
+                                                        _lib.ptr(self._tf_device(dev)), A, _lib.ptr(points), P,
+                                                        _lib.ptr(out_val), _lib.ptr(out_grad), None, _lib.stream_ptr()),
+                       "pvamd_composed_query")
 
     def _generic(self, flat, S, A):
         """Leaves that are not cached grids (MeshSDF, SphereSDF, nested compositions): per-leaf query kernels with

@@ -69,6 +69,21 @@ def rigid_inverse(m):
     return out
 
 
+def is_rigid(m, tol=1e-4):
+    """True when every (...,4,4) matrix is a rigid transform: last row 0 0 0 1 and R R^T = I, det R = +1, to `tol`
+    (absolute; rotation matrices built in float32 are orthonormal to ~1e-6)."""
+    m = torch.as_tensor(m)
+    if m.numel() == 0:
+        return True
+    r = m[..., :3, :3].double()
+    last = m[..., 3, :].double()
+    eye = torch.eye(3, dtype=torch.float64, device=m.device)
+    bottom = torch.tensor([0.0, 0.0, 0.0, 1.0], dtype=torch.float64, device=m.device)
+    ok_last = bool(((last - bottom).abs() <= tol).all())
+    ok_rot = bool(((r @ r.transpose(-1, -2) - eye).abs() <= tol).all()) and bool((torch.linalg.det(r) > 0).all())
+    return ok_last and ok_rot
+
+
 class Transform3d:
     def __init__(self, matrix=None, pos=None, rot=None, dtype=torch.float32, device="cpu"):
         """matrix: (B,4,4) or (4,4); or pos (.., 3) and/or rot: (..,3,3) matrix or (..,4) wxyz quaternion."""

@@ -4,17 +4,17 @@ import os
 import numpy as np
 import torch
 
+import workloads
 from oracle import oracle
 from pytorch_volumetric_amd import mesh_io
 
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
-MESHES = os.path.join(GOLDEN, "meshes")
+MESHES = workloads.MESHES
 
 DRILL_BB = np.array([[-0.067981, 0.095006], [-0.041332, 0.081863], [-0.003716, 0.183718]])
 
 
-def mesh_path(name):
-    return os.path.join(MESHES, name)
+mesh_path = workloads.mesh_path
 
 
 class AnalyticEllipsoidSDF:
@@ -78,16 +78,5 @@ def oracle_mesh_from_factory(obj):
                        obj.bounding_box(padding=1.0)[:, 1])
 
 
-def random_rigid(n, seed, trans=0.3):
-    g = torch.Generator().manual_seed(seed)
-    from pytorch_volumetric_amd import transforms as tf
-    m = torch.eye(4).repeat(n, 1, 1)
-    m[:, :3, :3] = tf.random_rotations(n, generator=g)
-    m[:, :3, 3] = (torch.rand(n, 3, generator=g) * 2 - 1) * trans
-    return m
-
-
-def uniform_points(n, lo, hi, seed):
-    g = torch.Generator().manual_seed(seed)
-    lo, hi = torch.as_tensor(lo, dtype=torch.float32), torch.as_tensor(hi, dtype=torch.float32)
-    return torch.rand(n, 3, generator=g) * (hi - lo) + lo
+random_rigid = workloads.random_rigid
+uniform_points = workloads.uniform_points

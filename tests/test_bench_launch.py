@@ -1,0 +1,66 @@
+"""bench.py's launcher: `--gpus N` must really start N ranks (the flag used to be parsed and ignored).
+
+The CPU test drives the same spawn path the driver's `python bench.py --gpus N` takes, with `--launch-check` standing in
+for the GPU work (ranks rendezvous over gloo on 127.0.0.1 and all-reduce a 1).  The GPU test runs the whole benchmark
+with two ranks sharing the one GPU of the test box (collectives through gloo): every leg, rank-0 JSON, n_gpus == 2.
+"""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def run_bench(*flags, timeout=600):
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), *flags], capture_output=True, text=True,
+                         timeout=timeout, env=env, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-2000:]
+    return json.loads(out.stdout.strip().splitlines()[-1])
+
+
+@pytest.mark.parametrize("n", [1, 2, 3])
+def test_gpus_flag_spawns_that_many_ranks(n):
+    line = run_bench("--gpus", str(n), "--launch-check")
+    assert line["n_gpus"] == n and line["ranks_seen_by_all_reduce"] == n and line["gpus_requested"] == n
+
+
+def test_under_torchrun_the_given_world_is_used():
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                          "--master-addr", "127.0.0.1", "--master-port", "29741", os.path.join(ROOT, "bench.py"),
+                          "--gpus", "2", "--launch-check"], capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-2000:]
+    line = json.loads(out.stdout.strip().splitlines()[-1])
+    assert line["n_gpus"] == 2 and line["ranks_seen_by_all_reduce"] == 2
+
+
+@pytest.mark.gpu
+def test_two_ranks_share_the_gpu_and_every_leg_reports():
+    line = run_bench("--gpus", "2", "--share-gpu", "--steps", "5", "--warmup", "2", "--points", "65536", "--small-legs",
+                     "--no-large", "--no-cpu-baseline")
+    assert line["n_gpus"] == 2 and line["config"]["ranks"] == 2 and line["scaling"] == "weak"
+    assert line["parity"]["max_abs_val_err_vs_oracle"] == 0.0 and line["parity"]["grad_mismatches_vs_oracle"] == 0
+    legs = line["legs"]
+    for name in ("c4", "c4_readme_grid", "c5"):
+        assert "error" not in legs[name], legs[name]
+        assert legs[name]["scaling"] == "strong" and legs[name]["n_gpus"] == 2
+    assert legs["c4"]["sharded"]["gather"] is False and legs["c4"]["gathered"]["gather"] is True
+    assert legs["c4"]["gathered"]["output_shape"] == [[8, 16384], [8, 16384, 3]]
+    assert legs["c5"]["rel_err_vs_analytic"] < 1e-3
+
+
+@pytest.mark.gpu
+def test_single_rank_line_has_the_contract_fields():
+    line = run_bench("--steps", "20", "--warmup", "5", "--small-legs", "--no-large", "--cpu-seconds", "0.5")
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert key in line, key
+    roof = line["roofline"]
+    assert roof["bound"] == "hbm" and roof["unit"] == "GB/s" and abs(roof["frac"] - roof["achieved"] / roof["peak"]) < 1e-9
+    assert "SEPARATE" in roof["timing"] and "traffic_source" in roof
+    assert line["steps"] == 20 and line["warmup"] == 5 and line["n_gpus"] == 1
+    assert line["cpu_baseline"]["kind"] == "port" and line["cpu_baseline"]["cores"] >= 1
