@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define PVAMD_ABI_VERSION 3
+#define PVAMD_ABI_VERSION 4
 
 #define PVAMD_E_NULL      (-1)  /* a required pointer is NULL            */
 #define PVAMD_E_SHAPE     (-2)  /* a size/shape argument is out of range */
@@ -67,6 +67,9 @@ typedef struct pvamd_grid {
     float        vhi[3];     /* largest  float32 p with p <= max                                             */
     float        inv32[3];   /* float32(1/res): the multiply-first index estimate, checked against a rounding */
     float        err32[3];   /* bound and redone with the exact IEEE division when it is within it            */
+    /* ---- float64 query points (the *_f64 entry points) ---- */
+    double       dbb_min[3]; /* surface bounding box in float64: sdf.py:556-557 casts self.bb to the query dtype   */
+    double       dbb_max[3];
 } pvamd_grid_t;
 
 /*
@@ -130,6 +133,18 @@ int pvamd_cached_query(const pvamd_grid_t* grid, const float* points, int64_t P,
 /* CachedSDF.outside_surface (sdf.py:593-602): OOB -> 1, else vox.val > level.  out: device [P] bytes. */
 int pvamd_cached_outside(const pvamd_grid_t* grid, const float* points, int64_t P, float level,
                          uint8_t* out, void* stream);
+
+/* The same three queries for FLOAT64 query points.  The reference returns the query dtype (sdf.py:545-547) and torch
+ * promotion makes every operation on the points float64: (points - min) / resolution and the range test (sdf.py:537,
+ * 540) whatever dtype the range had (dmin / dmax / dres above), the BOUNDING_BOX branch on self.bb.to(float64)
+ * (sdf.py:556-571, dbb_min / dbb_max).  Cached values are float32 and are widened exactly.
+ * points: device [P][3] float64.  out_val: device [P] float64.  out_grad: device [P][3] float64.                 */
+int pvamd_cached_query_f64(const pvamd_grid_t* grid, const double* points, int64_t P,
+                           double* out_val, double* out_grad, uint8_t* out_oob, void* stream);
+int pvamd_cached_outside_f64(const pvamd_grid_t* grid, const double* points, int64_t P, double level,
+                             uint8_t* out, void* stream);
+int pvamd_voxel_index_f64(const pvamd_grid_t* grid, const double* points, int64_t P,
+                          int64_t* out_key, int64_t* out_flat, uint8_t* out_valid, void* stream);
 
 /* Voxel index arithmetic alone (TorchMultidimView.ensure_index_key / ravel_multi_index / get_valid_values as
  * used at sdf.py:537-540): out_key device [P][3] int64, out_flat device [P] int64, out_valid device [P] bytes.

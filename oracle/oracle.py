@@ -22,6 +22,7 @@ class OracleGrid(ctypes.Structure):
         ("bb_min", ctypes.c_float * 3), ("bb_max", ctypes.c_float * 3),
         ("shape", ctypes.c_int32 * 3), ("index_f64", ctypes.c_int32), ("oob_mode", ctypes.c_int32),
         ("reserved", ctypes.c_int32),
+        ("dbb_min", ctypes.c_double * 3), ("dbb_max", ctypes.c_double * 3),
     ]
 
 
@@ -88,8 +89,10 @@ class Grid:
             fmin, fmax = rmin.astype(np.float32), rmax.astype(np.float32)
             fres = ((fmax - fmin) / cells.astype(np.float32)).astype(np.float32)
             dmin, dmax, dres = fmin.astype(np.float64), fmax.astype(np.float64), fres.astype(np.float64)
-        bb = np.asarray(bb, dtype=np.float32).reshape(3, 2)
+        bb64 = np.asarray(bb, dtype=np.float64).reshape(3, 2)  # float64 queries see the un-rounded box (sdf.py:556-557)
+        bb = bb64.astype(np.float32)
         for d in range(3):
+            g.dbb_min[d], g.dbb_max[d] = bb64[d, 0], bb64[d, 1]
             g.dmin[d], g.dmax[d], g.dres[d] = dmin[d], dmax[d], dres[d]
             g.fmin[d], g.fmax[d], g.fres[d] = fmin[d], fmax[d], fres[d]
             g.bb_min[d], g.bb_max[d] = bb[d, 0], bb[d, 1]
@@ -139,6 +142,36 @@ def cached_query(grid, pts):
     oob = np.empty((P,), np.uint8)
     load().oracle_cached_query(ctypes.byref(grid.c), _p(pts), ctypes.c_int64(P), _p(val), _p(grad), _p(oob))
     return val, grad, oob.astype(bool)
+
+
+def _f64(a):
+    return np.ascontiguousarray(a, dtype=np.float64)
+
+
+def voxel_index_f64(grid, pts):
+    """float64 query points: index arithmetic and range test in float64 (torch promotion, sdf.py:537-540)."""
+    pts = _f64(pts).reshape(-1, 3)
+    P = len(pts)
+    key, flat, valid = np.empty((P, 3), np.int64), np.empty((P,), np.int64), np.empty((P,), np.uint8)
+    load().oracle_voxel_index_f64(ctypes.byref(grid.c), _p(pts), ctypes.c_int64(P), _p(key), _p(flat), _p(valid))
+    return key, flat, valid.astype(bool)
+
+
+def cached_query_f64(grid, pts):
+    """CachedSDF.__call__ for float64 query points: float64 outputs (sdf.py:545-547)."""
+    pts = _f64(pts).reshape(-1, 3)
+    P = len(pts)
+    val, grad, oob = np.empty((P,), np.float64), np.empty((P, 3), np.float64), np.empty((P,), np.uint8)
+    load().oracle_cached_query_f64(ctypes.byref(grid.c), _p(pts), ctypes.c_int64(P), _p(val), _p(grad), _p(oob))
+    return val, grad, oob.astype(bool)
+
+
+def cached_outside_f64(grid, pts, level=0.0):
+    pts = _f64(pts).reshape(-1, 3)
+    out = np.empty((len(pts),), np.uint8)
+    load().oracle_cached_outside_f64(ctypes.byref(grid.c), _p(pts), ctypes.c_int64(len(pts)), ctypes.c_double(level),
+                                     _p(out))
+    return out.astype(bool)
 
 
 def cached_outside(grid, pts, level=0.0):

@@ -47,6 +47,7 @@ typedef struct oracle_grid {
     int32_t index_f64;
     int32_t oob_mode; /* 0 LOOKUP_GT_SDF (zeros + mask), 1 BOUNDING_BOX */
     int32_t reserved;
+    double dbb_min[3], dbb_max[3]; /* the bounding box as float64: what sdf.py:556-557 casts self.bb to for float64 queries */
 } oracle_grid_t;
 
 int oracle_num_threads(void) {
@@ -141,6 +142,88 @@ void oracle_cached_query(const oracle_grid_t* g, const float* pts, int64_t P, fl
     for (int64_t i = 0; i < P; ++i) {
         const int valid = cached_lookup(g, pts + 3 * i, out_val + i, out_grad + 3 * i);
         if (out_oob) out_oob[i] = (uint8_t)!valid;
+    }
+}
+
+/* ---- float64 query points ----
+ * The reference's output dtype is the query dtype (sdf.py:545-547) and every tensor op on the points promotes to it:
+ * (points - min) / resolution (sdf.py:537 via the view) is float64 whatever dtype the range had, the range test
+ * (sdf.py:540) compares in float64, and the BOUNDING_BOX branch runs on self.bb.to(float64) (sdf.py:556-557). */
+static int index_1d_f64(const oracle_grid_t* g, int d, double p, int64_t* k) {
+    *k = (int64_t)rint((p - g->dmin[d]) / g->dres[d]); /* dmin / dres = the view's tensors promoted to float64 */
+    return (g->dmin[d] <= p) && (p <= g->dmax[d]);
+}
+
+void oracle_voxel_index_f64(const oracle_grid_t* g, const double* pts, int64_t P, int64_t* out_key, int64_t* out_flat,
+                            uint8_t* out_valid) {
+#pragma omp parallel for schedule(static)
+    for (int64_t i = 0; i < P; ++i) {
+        int64_t k[3];
+        int valid = 1;
+        for (int d = 0; d < 3; ++d) valid &= index_1d_f64(g, d, pts[3 * i + d], &k[d]);
+        if (out_key) {
+            out_key[3 * i] = k[0];
+            out_key[3 * i + 1] = k[1];
+            out_key[3 * i + 2] = k[2];
+        }
+        if (out_flat) out_flat[i] = (k[0] * g->shape[1] + k[1]) * g->shape[2] + k[2];
+        if (out_valid) out_valid[i] = (uint8_t)valid;
+    }
+}
+
+void oracle_cached_query_f64(const oracle_grid_t* g, const double* pts, int64_t P, double* out_val, double* out_grad,
+                             uint8_t* out_oob) {
+#pragma omp parallel for schedule(static)
+    for (int64_t i = 0; i < P; ++i) {
+        const double* p = pts + 3 * i;
+        int64_t k[3];
+        int valid = 1;
+        for (int d = 0; d < 3; ++d) valid &= index_1d_f64(g, d, p[d], &k[d]);
+        double* val = out_val + i;
+        double* grad = out_grad + 3 * i;
+        if (valid) {
+            const int64_t flat = (k[0] * g->shape[1] + k[1]) * g->shape[2] + k[2];
+            *val = (double)g->val[flat];           /* :549 float32 cache assigned into a float64 tensor */
+            grad[0] = (double)g->grad[3 * flat];   /* :550 */
+            grad[1] = (double)g->grad[3 * flat + 1];
+            grad[2] = (double)g->grad[3 * flat + 2];
+        } else if (g->oob_mode == 1) {
+            double t[3];
+            for (int d = 0; d < 3; ++d) {
+                double dmin = g->dbb_min[d] - p[d];  /* :559 */
+                const int dmin_active = dmin > 0.0;  /* :560 */
+                if (!dmin_active) dmin = 0.0;        /* :561 */
+                double dmax = p[d] - g->dbb_max[d];  /* :562 */
+                if (!(dmax > 0.0)) dmax = 0.0;       /* :563-564 */
+                double dtotal = dmin + dmax;         /* :565 */
+                if (dmin_active) dtotal = -dtotal;   /* :567 */
+                t[d] = dtotal;
+            }
+            const double n = sqrt(fma(t[2], t[2], fma(t[1], t[1], t[0] * t[0]))); /* :568 */
+            grad[0] = t[0] / n; /* :570 */
+            grad[1] = t[1] / n;
+            grad[2] = t[2] / n;
+            *val = n; /* :571 */
+        } else {
+            *val = 0.0;
+            grad[0] = grad[1] = grad[2] = 0.0;
+        }
+        if (out_oob) out_oob[i] = (uint8_t)!valid;
+    }
+}
+
+void oracle_cached_outside_f64(const oracle_grid_t* g, const double* pts, int64_t P, double level, uint8_t* out) {
+#pragma omp parallel for schedule(static)
+    for (int64_t i = 0; i < P; ++i) {
+        int64_t k[3];
+        int valid = 1;
+        for (int d = 0; d < 3; ++d) valid &= index_1d_f64(g, d, pts[3 * i + d], &k[d]);
+        if (valid) {
+            const int64_t flat = (k[0] * g->shape[1] + k[1]) * g->shape[2] + k[2];
+            out[i] = (uint8_t)((double)g->val[flat] > level);
+        } else {
+            out[i] = 1;
+        }
     }
 }
 

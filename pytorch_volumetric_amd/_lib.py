@@ -11,7 +11,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("PVAMD_LIB") or os.path.join(_HERE, "csrc", "libpvamd.so")  # PVAMD_LIB: A/B builds (tools/)
 
-ABI_VERSION = 3
+ABI_VERSION = 4
 OOB_LOOKUP_GT_SDF = 0
 OOB_BOUNDING_BOX = 1
 TRI_REC = 24
@@ -55,6 +55,8 @@ class GridDesc(ctypes.Structure):
         ("vhi", ctypes.c_float * 3),
         ("inv32", ctypes.c_float * 3),
         ("err32", ctypes.c_float * 3),
+        ("dbb_min", ctypes.c_double * 3),
+        ("dbb_max", ctypes.c_double * 3),
     ]
 
 
@@ -93,6 +95,12 @@ SIGNATURES = {
                                             ctypes.c_float, ctypes.c_void_p, ctypes.c_void_p]),
     "pvamd_voxel_index": (ctypes.c_int, [ctypes.POINTER(GridDesc), ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p,
                                          ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]),
+    "pvamd_cached_query_f64": (ctypes.c_int, [ctypes.POINTER(GridDesc), ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p,
+                                              ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]),
+    "pvamd_cached_outside_f64": (ctypes.c_int, [ctypes.POINTER(GridDesc), ctypes.c_void_p, ctypes.c_int64,
+                                                ctypes.c_double, ctypes.c_void_p, ctypes.c_void_p]),
+    "pvamd_voxel_index_f64": (ctypes.c_int, [ctypes.POINTER(GridDesc), ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p,
+                                             ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]),
     "pvamd_composed_query": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int32, ctypes.c_void_p, ctypes.c_int32,
                                             ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p,
                                             ctypes.c_void_p, ctypes.c_void_p]),
@@ -216,18 +224,21 @@ def ptr(t):
     return ctypes.c_void_p(t.data_ptr())
 
 
-def as_query_points(points, device=None):
+def as_query_points(points, device=None, keep_f64=False):
     """[..., 3] any float dtype / device  ->  (contiguous fp32 [P,3] on the GPU, leading shape, dtype, device).
 
     `device`: the GPU that owns the grid / mesh the points will be looked up in (the kernel dereferences raw pointers
-    of that device, so the points and the launch must be there too); None = the current device."""
+    of that device, so the points and the launch must be there too); None = the current device.
+    `keep_f64`: float64 points stay float64 (the grid lookups have float64 entry points; the mesh query computes in
+    float32 like the reference, sdf.py:132)."""
     if not torch.is_tensor(points):
         points = torch.as_tensor(points)
     if points.shape[-1] != 3:
         raise ValueError(f"query points must have last dimension 3, got {tuple(points.shape)}")
     dev = require_gpu() if device is None else device
     lead = points.shape[:-1]
-    flat = points.detach().reshape(-1, 3).to(device=dev, dtype=torch.float32).contiguous()
+    flat = points.detach().reshape(-1, 3).to(device=dev, dtype=torch.float64 if keep_f64 and points.dtype == torch.float64
+                                              else torch.float32).contiguous()
     return flat, lead, points.dtype if points.dtype.is_floating_point else torch.float32, points.device
 
 

@@ -141,6 +141,90 @@ __global__ __launch_bounds__(256) void voxel_index_kernel(const pvamd_grid_t g, 
     }
 }
 
+// ---- float64 query points (sdf.py:545-547: output dtype = query dtype; torch promotion makes the index arithmetic,
+// the range test and the BOUNDING_BOX branch float64).  One point per lane; 24 B read + 32 B written per point. ----
+PVAMD_DEV bool voxel_key_f64(const pvamd_grid_t& g, const double p[3], long long key[3]) {
+    bool valid = true;
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+        valid &= (g.dmin[d] <= p[d]) && (p[d] <= g.dmax[d]);
+        key[d] = (long long)__builtin_rint((p[d] - g.dmin[d]) / g.dres[d]);
+    }
+    return valid;
+}
+
+PVAMD_DEV int clamped_flat(const pvamd_grid_t& g, const long long key[3]) {
+    const int kx = min(max((int)key[0], 0), g.shape[0] - 1);
+    const int ky = min(max((int)key[1], 0), g.shape[1] - 1);
+    const int kz = min(max((int)key[2], 0), g.shape[2] - 1);
+    return (kx * g.shape[1] + ky) * g.shape[2] + kz;
+}
+
+__global__ __launch_bounds__(256) void cached_query_f64_kernel(const pvamd_grid_t g, const double* __restrict__ pts,
+                                                                int64_t P, double* __restrict__ val,
+                                                                double* __restrict__ grad, uint8_t* __restrict__ oob) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < P; i += stride) {
+        const double p[3] = {pts[3 * i], pts[3 * i + 1], pts[3 * i + 2]};
+        long long key[3];
+        const bool valid = voxel_key_f64(g, p, key);
+        double v = 0.0, gx = 0.0, gy = 0.0, gz = 0.0;
+        if (valid) {
+            const float4 r = reinterpret_cast<const float4*>(g.vox)[clamped_flat(g, key)];
+            v = (double)r.x; gx = (double)r.y; gy = (double)r.z; gz = (double)r.w;
+        } else if (g.oob_mode == PVAMD_OOB_BOUNDING_BOX) {
+            double t[3];
+#pragma unroll
+            for (int d = 0; d < 3; ++d) {
+                double lo = g.dbb_min[d] - p[d];
+                const bool lo_active = lo > 0.0;
+                lo = lo_active ? lo : 0.0;
+                double hi = p[d] - g.dbb_max[d];
+                hi = (hi > 0.0) ? hi : 0.0;
+                const double s = lo + hi;
+                t[d] = lo_active ? -s : s;
+            }
+            v = __builtin_sqrt(__builtin_fma(t[2], t[2], __builtin_fma(t[1], t[1], t[0] * t[0])));
+            gx = t[0] / v; gy = t[1] / v; gz = t[2] / v;
+        }
+        val[i] = v;
+        grad[3 * i] = gx;
+        grad[3 * i + 1] = gy;
+        grad[3 * i + 2] = gz;
+        if (oob) oob[i] = valid ? 0 : 1;
+    }
+}
+
+__global__ __launch_bounds__(256) void cached_outside_f64_kernel(const pvamd_grid_t g, const double* __restrict__ pts,
+                                                                  int64_t P, double level, uint8_t* __restrict__ out) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < P; i += stride) {
+        const double p[3] = {pts[3 * i], pts[3 * i + 1], pts[3 * i + 2]};
+        long long key[3];
+        const bool valid = voxel_key_f64(g, p, key);
+        out[i] = valid ? (uint8_t)((double)g.vox[4 * (int64_t)clamped_flat(g, key)] > level) : (uint8_t)1;
+    }
+}
+
+__global__ __launch_bounds__(256) void voxel_index_f64_kernel(const pvamd_grid_t g, const double* __restrict__ pts,
+                                                               int64_t P, int64_t* __restrict__ out_key,
+                                                               int64_t* __restrict__ out_flat,
+                                                               uint8_t* __restrict__ out_valid) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < P; i += stride) {
+        const double p[3] = {pts[3 * i], pts[3 * i + 1], pts[3 * i + 2]};
+        long long key[3];
+        const bool valid = voxel_key_f64(g, p, key);
+        if (out_key) {
+            out_key[3 * i] = key[0];
+            out_key[3 * i + 1] = key[1];
+            out_key[3 * i + 2] = key[2];
+        }
+        if (out_flat) out_flat[i] = (key[0] * g.shape[1] + key[1]) * g.shape[2] + key[2];
+        if (out_valid) out_valid[i] = valid ? 1 : 0;
+    }
+}
+
 __global__ __launch_bounds__(256) void pack_grid_kernel(const float* __restrict__ val, const float* __restrict__ grad,
                                                          int64_t n, float4* __restrict__ out) {
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
@@ -228,5 +312,41 @@ extern "C" int pvamd_voxel_index(const pvamd_grid_t* grid, const float* points, 
     const dim3 grid_dim(stream_grid(P, 256)), block(256);
     if (grid->index_f64) hipLaunchKernelGGL((voxel_index_kernel<true>), grid_dim, block, 0, (hipStream_t)stream, *grid, points, P, out_key, out_flat, out_valid);
     else hipLaunchKernelGGL((voxel_index_kernel<false>), grid_dim, block, 0, (hipStream_t)stream, *grid, points, P, out_key, out_flat, out_valid);
+    return (int)hipGetLastError();
+}
+
+extern "C" int pvamd_cached_query_f64(const pvamd_grid_t* grid, const double* points, int64_t P, double* out_val,
+                                      double* out_grad, uint8_t* out_oob, void* stream) {
+    if (P < 0) return PVAMD_E_SHAPE;
+    if (P == 0) return 0;
+    if (!grid || !out_val || !out_grad || !points) return PVAMD_E_NULL;
+    if (int e = check_grid(*grid)) return e;
+    if (!aligned_to(points, 8) || !aligned_to(out_val, 8) || !aligned_to(out_grad, 8)) return PVAMD_E_ALIGN;
+    hipLaunchKernelGGL(cached_query_f64_kernel, dim3(stream_grid(P, 256)), dim3(256), 0, (hipStream_t)stream, *grid, points,
+                       P, out_val, out_grad, out_oob);
+    return (int)hipGetLastError();
+}
+
+extern "C" int pvamd_cached_outside_f64(const pvamd_grid_t* grid, const double* points, int64_t P, double level,
+                                        uint8_t* out, void* stream) {
+    if (P < 0) return PVAMD_E_SHAPE;
+    if (P == 0) return 0;
+    if (!grid || !out || !points) return PVAMD_E_NULL;
+    if (int e = check_grid(*grid)) return e;
+    if (!aligned_to(points, 8)) return PVAMD_E_ALIGN;
+    hipLaunchKernelGGL(cached_outside_f64_kernel, dim3(stream_grid(P, 256)), dim3(256), 0, (hipStream_t)stream, *grid,
+                       points, P, level, out);
+    return (int)hipGetLastError();
+}
+
+extern "C" int pvamd_voxel_index_f64(const pvamd_grid_t* grid, const double* points, int64_t P, int64_t* out_key,
+                                     int64_t* out_flat, uint8_t* out_valid, void* stream) {
+    if (P < 0) return PVAMD_E_SHAPE;
+    if (P == 0) return 0;
+    if (!grid || !points) return PVAMD_E_NULL;
+    if (int e = check_grid(*grid, /*need_vox=*/false)) return e;
+    if (!aligned_to(points, 8)) return PVAMD_E_ALIGN;
+    hipLaunchKernelGGL(voxel_index_f64_kernel, dim3(stream_grid(P, 256)), dim3(256), 0, (hipStream_t)stream, *grid, points,
+                       P, out_key, out_flat, out_valid);
     return (int)hipGetLastError();
 }

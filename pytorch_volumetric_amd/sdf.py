@@ -290,15 +290,16 @@ class VoxelView:
 
     def _index(self, points, want_key=False, want_flat=False, want_valid=False):
         lib = _lib.load()
-        flat, lead, _, device = _lib.as_query_points(points, self._owner._packed.device)
+        flat, lead, _, device = _lib.as_query_points(points, self._owner._packed.device, keep_f64=True)
         P = flat.shape[0]
         key = torch.empty((P, 3), dtype=torch.int64, device=flat.device) if want_key else None
         ravel = torch.empty((P,), dtype=torch.int64, device=flat.device) if want_flat else None
         valid = torch.empty((P,), dtype=torch.uint8, device=flat.device) if want_valid else None
         desc = self._owner._grid_desc()
+        entry = lib.pvamd_voxel_index_f64 if flat.dtype == torch.float64 else lib.pvamd_voxel_index
         with _lib.on_device(flat.device):
-            _lib.check(lib.pvamd_voxel_index(ctypes.byref(desc), _lib.ptr(flat), P, _lib.ptr(key), _lib.ptr(ravel),
-                                             _lib.ptr(valid), _lib.stream_ptr()), "pvamd_voxel_index")
+            _lib.check(entry(ctypes.byref(desc), _lib.ptr(flat), P, _lib.ptr(key), _lib.ptr(ravel),
+                             _lib.ptr(valid), _lib.stream_ptr()), "pvamd_voxel_index")
         return (key.reshape(*lead, 3) if want_key else None, ravel.reshape(*lead) if want_flat else None,
                 valid.reshape(*lead).bool() if want_valid else None)
 
@@ -408,8 +409,10 @@ class CachedSDF(ObjectFrameSDF):
         desc.vox = self._packed.data_ptr()
         self._view.fill(desc)
         bb = self.bb.to(dtype=torch.float32, device="cpu")
+        bb64 = self.bb.to(dtype=torch.float64, device="cpu")  # float64 queries: sdf.py:556-557 casts bb to the query dtype
         for d in range(3):
             desc.bb_min[d], desc.bb_max[d] = bb[d, 0].item(), bb[d, 1].item()
+            desc.dbb_min[d], desc.dbb_max[d] = bb64[d, 0].item(), bb64[d, 1].item()
         mode = self.out_of_bounds_strategy if oob_mode is None else oob_mode
         desc.oob_mode = _lib.OOB_BOUNDING_BOX if mode == OutOfBoundsStrategy.BOUNDING_BOX else _lib.OOB_LOOKUP_GT_SDF
         _lib.check(_lib.load().pvamd_grid_finalize(ctypes.byref(desc)), "pvamd_grid_finalize")
@@ -420,23 +423,26 @@ class CachedSDF(ObjectFrameSDF):
         """sdf.py:535-591"""
         lib = _lib.load()
         # the launch happens on the GPU that holds the grid, whatever device is current in the calling code
-        flat, lead, dtype, _ = _lib.as_query_points(points_in_object_frame, self._packed.device)
+        # float64 points are looked up in float64 (index arithmetic, range test and bounding-box branch all promote to
+        # the query dtype in the reference: sdf.py:537-540,545-547,556-571); everything else is computed in float32
+        flat, lead, dtype, _ = _lib.as_query_points(points_in_object_frame, self._packed.device, keep_f64=True)
         P = flat.shape[0]
         dev = flat.device
-        val = torch.empty((P,), dtype=torch.float32, device=dev)
-        grad = torch.empty((P, 3), dtype=torch.float32, device=dev)
+        val = torch.empty((P,), dtype=flat.dtype, device=dev)
+        grad = torch.empty((P, 3), dtype=flat.dtype, device=dev)
         lookup_gt = self.out_of_bounds_strategy == OutOfBoundsStrategy.LOOKUP_GT_SDF
         oob = torch.empty((P,), dtype=torch.uint8, device=dev) if lookup_gt else None
         desc = self._grid_desc()
+        entry = lib.pvamd_cached_query_f64 if flat.dtype == torch.float64 else lib.pvamd_cached_query
         with _lib.on_device(dev):
-            _lib.check(lib.pvamd_cached_query(ctypes.byref(desc), _lib.ptr(flat), P, _lib.ptr(val), _lib.ptr(grad),
-                                              _lib.ptr(oob), _lib.stream_ptr()), "pvamd_cached_query")
+            _lib.check(entry(ctypes.byref(desc), _lib.ptr(flat), P, _lib.ptr(val), _lib.ptr(grad),
+                             _lib.ptr(oob), _lib.stream_ptr()), "pvamd_cached_query")
         if lookup_gt:
             idx = oob.nonzero().squeeze(-1)  # sdf.py:552-554: ground truth on the out-of-range subset only
             if idx.numel() > 0:
                 v_gt, g_gt = self.gt_sdf(flat[idx])
-                val[idx] = v_gt.to(device=dev, dtype=torch.float32)
-                grad[idx] = g_gt.to(device=dev, dtype=torch.float32)
+                val[idx] = v_gt.to(device=dev, dtype=flat.dtype)
+                grad[idx] = g_gt.to(device=dev, dtype=flat.dtype)
         val = _restore(val, lead, (), dtype, self.device)
         grad = _restore(grad, lead, (3,), dtype, self.device)
         if self.debug_check_sdf:
@@ -470,12 +476,13 @@ class CachedSDF(ObjectFrameSDF):
     def outside_surface(self, points_in_object_frame, surface_level=0):
         """sdf.py:593-602"""
         lib = _lib.load()
-        flat, lead, _, _ = _lib.as_query_points(points_in_object_frame, self._packed.device)
+        flat, lead, _, _ = _lib.as_query_points(points_in_object_frame, self._packed.device, keep_f64=True)
         out = torch.empty((flat.shape[0],), dtype=torch.uint8, device=flat.device)
         desc = self._grid_desc()
+        entry = lib.pvamd_cached_outside_f64 if flat.dtype == torch.float64 else lib.pvamd_cached_outside
         with _lib.on_device(flat.device):
-            _lib.check(lib.pvamd_cached_outside(ctypes.byref(desc), _lib.ptr(flat), flat.shape[0],
-                                                float(surface_level), _lib.ptr(out), _lib.stream_ptr()),
+            _lib.check(entry(ctypes.byref(desc), _lib.ptr(flat), flat.shape[0],
+                             float(surface_level), _lib.ptr(out), _lib.stream_ptr()),
                        "pvamd_cached_outside")
         return out.reshape(*lead).bool().to(device=self.device)
 

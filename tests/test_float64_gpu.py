@@ -1,0 +1,126 @@
+"""-m gpu: float64 query points are looked up in float64.
+
+Reference behaviour (sdf.py:535-571): the output dtype is the query dtype (:545-547); `(points - min) / resolution` and the
+range test promote to float64 whatever dtype the range had (:537,540); the BOUNDING_BOX branch runs on
+self.bb.to(float64) (:556-571).  The HIP path: pvamd_cached_query_f64 / _outside_f64 / pvamd_voxel_index_f64; the oracle
+twins: oracle.cached_query_f64 & co.  Everything bit-exact (float64 equality), including at half-voxel planes and range
+edges that only float64 can resolve.
+"""
+import numpy as np
+import pytest
+import torch
+
+import pytorch_volumetric_amd as pv
+from oracle import oracle
+from tests import helpers as H
+from tests.test_cached_gpu import make_cached, query_points
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("f64_range", [True, False])
+@pytest.mark.parametrize("n", [0, 1, 5, 1023, 200_003])
+def test_float64_query_matches_oracle_bitwise(f64_range, n):
+    c = make_cached(f64=f64_range)
+    og = H.oracle_grid_from_cached(c)
+    pts = query_points(c, n, seed=n + 3).double() + 1e-9  # not representable in float32
+    val, grad = c(pts.cuda())
+    assert val.dtype == torch.float64 and grad.dtype == torch.float64 and val.shape == (n,) and grad.shape == (n, 3)
+    oval, ograd, ooob = oracle.cached_query_f64(og, pts.numpy())
+    assert np.array_equal(val.cpu().numpy(), oval, equal_nan=True)
+    assert np.array_equal(grad.cpu().numpy(), ograd, equal_nan=True)
+    if n > 1000:
+        assert 0.05 < ooob.mean() < 0.95  # both branches
+
+
+@pytest.mark.parametrize("f64_range", [True, False])
+def test_half_voxel_planes_only_float64_resolves(f64_range):
+    """Points 1e-12 m either side of every half-voxel plane: as float32 the two collapse onto one value (one index), in
+    float64 they are different voxels -- and the product must say so, bit for bit with the oracle."""
+    c = make_cached(f64=f64_range)
+    og = H.oracle_grid_from_cached(c)
+    v = c._view
+    mn, res = v.dmin.numpy(), v.dres.numpy()
+    shape = np.array(v.shape)
+    rng = np.random.default_rng(0)
+    n = 20_000
+    k = rng.integers(0, shape - 1, size=(n, 3))
+    centre = mn + (k + rng.random((n, 3)) * 0.6 + 0.2) * res  # somewhere inside cell k..k+1, away from the planes
+    d = rng.integers(0, 3, size=n)
+    plane = mn[d] + (k[np.arange(n), d] + 0.5) * res[d]
+    below, above = centre.copy(), centre.copy()
+    below[np.arange(n), d] = plane - 1e-12
+    above[np.arange(n), d] = plane + 1e-12
+    pts = np.concatenate((below, above))
+    key = c.voxels.ensure_index_key(torch.from_numpy(pts).cuda()).cpu().numpy()
+    okey, oflat, ovalid = oracle.voxel_index_f64(og, pts)
+    assert np.array_equal(key, okey)
+    assert ovalid.all()
+    kd_below, kd_above = key[:n][np.arange(n), d], key[n:][np.arange(n), d]
+    assert np.array_equal(kd_above, kd_below + 1)  # float64 separates the two sides of every plane ...
+    key32 = c.voxels.ensure_index_key(torch.from_numpy(pts.astype(np.float32)).cuda()).cpu().numpy()
+    # ... float32 cannot (2e-12 m apart: the two sides round to the same float32 except where the plane itself is a float32
+    # rounding midpoint: fmin + (k + 0.5) * fres has about one bit more than a float32)
+    assert (key32[:n] == key32[n:]).all(axis=1).mean() > 0.98
+    val, grad = c(torch.from_numpy(pts).cuda())
+    oval, ograd, _ = oracle.cached_query_f64(og, pts)
+    assert np.array_equal(val.cpu().numpy(), oval) and np.array_equal(grad.cpu().numpy(), ograd)
+    # what casting the query to float32 first (round 1's behaviour) would have cost: a wrong voxel for about half the points
+    val32, _ = c(torch.from_numpy(pts.astype(np.float32)).cuda())
+    wrong = (val32.double().cpu().numpy() != oval).mean()
+    assert wrong > 0.2
+
+
+@pytest.mark.parametrize("f64_range", [True, False])
+def test_range_edges_and_outside_surface_in_float64(f64_range):
+    c = make_cached(f64=f64_range)
+    og = H.oracle_grid_from_cached(c)
+    v = c._view
+    mn, mx = v.dmin.numpy(), v.dmax.numpy()
+    mid = 0.5 * (mn + mx)
+    rows = []
+    for d in range(3):
+        for edge in (mn[d], mx[d]):
+            for delta in (0.0, -1e-13, 1e-13, -1e-9, 1e-9):
+                p = mid.copy()
+                p[d] = edge + delta
+                rows.append(p)
+    pts = np.array(rows)
+    valid = c.voxels.get_valid_values(torch.from_numpy(pts).cuda()).cpu().numpy()
+    _, _, ovalid = oracle.voxel_index_f64(og, pts)
+    assert np.array_equal(valid, ovalid) and ovalid.any() and (~ovalid).any()
+    val, grad = c(torch.from_numpy(pts).cuda())
+    oval, ograd, _ = oracle.cached_query_f64(og, pts)
+    assert np.array_equal(val.cpu().numpy(), oval, equal_nan=True)
+    assert np.array_equal(grad.cpu().numpy(), ograd, equal_nan=True)
+    big = query_points(c, 50_000, seed=11).double() * (1 + 1e-12)
+    out = c.outside_surface(big.cuda(), surface_level=0.003)
+    assert np.array_equal(out.cpu().numpy(), oracle.cached_outside_f64(og, big.numpy(), 0.003))
+
+
+def test_bounding_box_branch_uses_the_float64_box():
+    """sdf.py:556-557: bb is cast to the query dtype, so float64 queries measure against the un-rounded box."""
+    c = make_cached(f64=True)
+    far = torch.tensor([[1.0 + 1e-10, -2.0, 0.5], [0.3, 0.3 + 1e-11, 4.0]], dtype=torch.float64)
+    val, grad = c(far.cuda())
+    bb = c.bb.double().cpu().numpy()
+    p = far.numpy()
+    lo, hi = np.maximum(bb[:, 0] - p, 0), np.maximum(p - bb[:, 1], 0)
+    ref = np.linalg.norm(lo + hi, axis=-1)
+    assert np.allclose(val.cpu().numpy(), ref, rtol=0, atol=1e-15)
+    assert np.allclose(np.linalg.norm(grad.cpu().numpy(), axis=-1), 1.0, atol=1e-15)
+
+
+def test_lookup_gt_strategy_keeps_the_query_dtype():
+    obj = pv.MeshObjectFactory(H.mesh_path("probe.obj"))
+    c = pv.CachedSDF("probe", 0.02, obj.bounding_box(padding=0.05), pv.MeshSDF(obj),
+                     out_of_bounds_strategy=pv.OutOfBoundsStrategy.LOOKUP_GT_SDF, device="cuda", cache_path=None)
+    lo = np.array([r[0] for r in c.ranges]) - 0.1
+    hi = np.array([r[1] for r in c.ranges]) + 0.1
+    pts = H.uniform_points(5000, lo, hi, seed=5).double()
+    val, grad = c(pts.cuda())
+    assert val.dtype == torch.float64 and grad.dtype == torch.float64
+    v32, g32 = c(pts.float().cuda())
+    inb = c.voxels.get_valid_values(pts.cuda())
+    # out of range: ground truth from the mesh kernel (float32 arithmetic, sdf.py:132) widened to the query dtype
+    assert torch.equal(val[~inb], v32[~inb].double()) and (~inb).any()
