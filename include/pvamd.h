@@ -215,6 +215,15 @@ int pvamd_mesh_query(const pvamd_mesh_t* mesh, const float* points, const int32_
                      uint64_t jitter_seed, int64_t index_base, float* out_closest, float* out_dist, float* out_grad, int32_t* out_face,
                      float* out_normal, void* scratch, void* stream);
 
+/* The draw of sample_mesh_points (sdf.py:643-650: open3d's sample_points_uniformly + a random subset), counter-based so
+ * that it is reproducible: sample i picks the triangle t with cdf[t-1] <= u < cdf[t] (u, r1, r2 = 53-bit uniforms from
+ * splitmix64(seed, i)) and the point (1 - sqrt(r1)) a + sqrt(r1)(1 - r2) b + sqrt(r1) r2 c, in float64.
+ * tri: device [F][3][3] fp32 corners (any order).  cdf: device [F] float64 inclusive cumulative area fractions
+ * (non-decreasing, cdf[F-1] >= 1).  out_points: device [n][3] float64.  out_face: device [n] int32 index into tri, or
+ * NULL.  out_key: device [n] int64 non-negative random keys (the n' smallest select a uniform random subset), or NULL. */
+int pvamd_sample_surface(const float* tri, const double* cdf, int32_t F, int64_t n, uint64_t seed,
+                         double* out_points, int32_t* out_face, int64_t* out_key, void* stream);
+
 /* batch_chamfer_dist (chamfer.py:79-94) against a mesh: for each of B world->object transforms, transform the
  * N points, unsigned distance to the mesh, accumulate sum_n (scale*d)^2.  The caller divides by the GLOBAL N
  * (after an all-reduce when the points are sharded across GPUs).

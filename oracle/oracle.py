@@ -181,6 +181,16 @@ def cached_outside(grid, pts, level=0.0):
     return out.astype(bool)
 
 
+def sample_surface(tri, cdf, n, seed):
+    """The counter-based draw of sample_mesh_points: (points [n,3] float64, triangle index [n], subset keys [n])."""
+    tri = _f32(tri).reshape(-1, 9)
+    cdf = _f64(cdf)
+    pts, face, key = np.empty((n, 3), np.float64), np.empty((n,), np.int32), np.empty((n,), np.int64)
+    load().oracle_sample_surface(_p(tri), _p(cdf), ctypes.c_int32(len(tri)), ctypes.c_int64(n), ctypes.c_uint64(seed),
+                                 _p(pts), _p(face), _p(key))
+    return pts, face, key
+
+
 def composed_query(grids, tf, A, pts):
     """grids: list of S Grid; tf: [S*A,4,4] obj->leaf leaf-major; returns val [A,P], grad [A,P,3], leaf [A,P]."""
     S = len(grids)

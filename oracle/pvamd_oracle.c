@@ -388,6 +388,33 @@ static float jitter_normal(uint64_t seed, int64_t index, int c) {
     return (float)(s - 393210) * (1.0f / 65536.0f);
 }
 
+/* sample_mesh_points' draw (sdf.py:643-650), counter-based: see pvamd_sample_surface in include/pvamd.h */
+static double uniform01(uint64_t seed, int64_t index, int k) {
+    const uint64_t h = splitmix64(seed ^ splitmix64((uint64_t)index * 4u + (uint64_t)k));
+    return (double)(h >> 11) * 0x1.0p-53;
+}
+
+void oracle_sample_surface(const float* tri, const double* cdf, int32_t F, int64_t n, uint64_t seed, double* out_points,
+                           int32_t* out_face, int64_t* out_key) {
+#pragma omp parallel for schedule(static)
+    for (int64_t i = 0; i < n; ++i) {
+        const double u = uniform01(seed, i, 0);
+        int32_t lo = 0, hi = F - 1;
+        while (lo < hi) { /* first triangle whose cumulative area fraction exceeds u */
+            const int32_t mid = (lo + hi) >> 1;
+            if (cdf[mid] > u) hi = mid;
+            else lo = mid + 1;
+        }
+        const float* t = tri + 9 * (int64_t)lo;
+        const double s = sqrt(uniform01(seed, i, 1)), r2 = uniform01(seed, i, 2);
+        const double wa = 1.0 - s, wb = s * (1.0 - r2), wc = s * r2;
+        for (int d = 0; d < 3; ++d)
+            out_points[3 * i + d] = fma(wc, (double)t[6 + d], fma(wb, (double)t[3 + d], wa * (double)t[d]));
+        if (out_face) out_face[i] = lo;
+        if (out_key) out_key[i] = (int64_t)(splitmix64(seed ^ splitmix64((uint64_t)i * 4u + 3u)) >> 1);
+    }
+}
+
 void oracle_jitter_dir(const oracle_mesh_t* m, uint64_t seed, int64_t index, float* dir) {
     for (int c = 0; c < 3; ++c)
         dir[c] = (float)fma(1e-4, (double)jitter_normal(seed, index, c), m->ray_dir[c]); /* :147-150 */

@@ -153,6 +153,30 @@ class ObjectFactory(abc.ABC):
         self._mesh_desc_cache = desc
         return desc
 
+    def sample_surface(self, n, seed):
+        """n area-uniform surface points (float64, on the GPU), the index of the prepared triangle each came from and a
+        random key per sample; the draw of sample_mesh_points (sdf.py:643-650)."""
+        lib = _lib.load()
+        self._mesh_desc()
+        dev = self._tri_dev.device
+        if getattr(self, "_area_cdf_dev", None) is None or self._area_cdf_dev.device != dev:
+            t = self._tri_dev.double().cpu().numpy()  # areas of the float32 triangles the kernels hold, in their order
+            area = 0.5 * np.linalg.norm(np.cross(t[:, 1] - t[:, 0], t[:, 2] - t[:, 0]), axis=1)
+            if not np.isfinite(area).all() or area.sum() <= 0:
+                raise ValueError("mesh has no area to sample")
+            cdf = np.cumsum(area) / area.sum()
+            cdf[-1] = 1.0
+            self._area_cdf_dev = torch.from_numpy(cdf).to(dev)
+        pts = torch.empty((n, 3), dtype=torch.float64, device=dev)
+        face = torch.empty((n,), dtype=torch.int32, device=dev)
+        keys = torch.empty((n,), dtype=torch.int64, device=dev)
+        with _lib.on_device(dev):
+            _lib.check(lib.pvamd_sample_surface(_lib.ptr(self._tri_dev), _lib.ptr(self._area_cdf_dev),
+                                                int(self._tri_dev.shape[0]), n, ctypes.c_uint64(int(seed) & (2 ** 64 - 1)),
+                                                _lib.ptr(pts), _lib.ptr(face), _lib.ptr(keys), _lib.stream_ptr()),
+                       "pvamd_sample_surface")
+        return pts, face, keys
+
     @property
     def num_faces(self):
         return int(self._mesh.faces.shape[0])
@@ -668,8 +692,8 @@ def sample_mesh_points(obj_factory: ObjectFactory = None, num_points=100, seed=0
     """Seeded area-uniform surface samples + face normals (role of sdf.py:617-670).
 
     The reference draws these from open3d's RNG, which cannot be reproduced; this sampler keeps the call signature,
-    the over-sample-then-subselect scheme, the return triple and the cache layout
-    (cache[name][seed][num_points] = (points, normals, None)), with numpy's seeded Generator."""
+    the over-sample-then-subselect scheme, the normals from the mesh query, the return triple and the cache layout
+    (cache[name][seed][num_points] = (points, normals, None)), with a counter-based draw on the GPU."""
     given_cache = cache is not None
     if cache is not None or (dbpath is not None and os.path.exists(dbpath)):
         if cache is None:
@@ -684,17 +708,15 @@ def sample_mesh_points(obj_factory: ObjectFactory = None, num_points=100, seed=0
     if obj_factory is None:
         raise RuntimeError(f"Expect model points to be cached for {name} {seed} {num_points} in {dbpath}")
 
-    mesh = obj_factory._mesh
-    rng = np.random.default_rng(seed)
+    # the draw runs on the GPU (pvamd_sample_surface): counter-based, so the same (mesh, seed, num_points) gives the same
+    # points on any device / launch geometry; open3d's own generator (sdf.py:643-645) cannot be reproduced
     n_init = max(min_init_sample_points, 2 * num_points)
-    areas = mesh.triangle_areas()
-    fid = rng.choice(len(areas), size=n_init, p=areas / areas.sum())
-    r1, r2 = np.sqrt(rng.random(n_init)), rng.random(n_init)
-    t = mesh.triangle_soup()[fid]
-    pts = (1 - r1)[:, None] * t[:, 0] + (r1 * (1 - r2))[:, None] * t[:, 1] + (r1 * r2)[:, None] * t[:, 2]
-    keep = rng.permutation(n_init)[:num_points]
-    points = torch.tensor(pts[keep])
-    normals = torch.tensor(obj_factory._face_normals[fid[keep]])
+    pts_all, _, keys = obj_factory.sample_surface(n_init, seed)
+    keep = torch.argsort(keys)[:num_points]  # sdf.py:650: a random subset, to disperse the samples
+    points = pts_all[keep]
+    # normals: the face normal at the closest point, from the mesh query itself (sdf.py:652)
+    res = obj_factory.object_frame_closest_point(points, compute_normal=True)
+    points, normals = points.cpu(), res.normal.cpu()
 
     cache[name][seed][num_points] = points, normals, None
     if not given_cache and dbpath is not None:

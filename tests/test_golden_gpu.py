@@ -57,6 +57,18 @@ def test_cached_sdf_reproduces_the_reference_call(tag):
     assert list(vb.shape) == list(G[f"cached/{tag}/batched_shape"]) and gb.shape == (2, 3, 100, 3)
 
 
+def leaf_value_ties(c, tf, A, pts, tol=2e-6):
+    """(A, P) mask: the two smallest per-leaf values of a 3-leaf composition of `c` are within tol of each other."""
+    tf = torch.as_tensor(np.asarray(tf), dtype=torch.float32).reshape(3, A, 4, 4).cuda()
+    p = torch.as_tensor(np.asarray(pts), dtype=torch.float32).reshape(-1, 3).cuda()
+    vals = []
+    for s in range(3):
+        x = p.unsqueeze(0) @ tf[s, :, :3, :3].transpose(-1, -2) + tf[s, :, None, :3, 3]
+        vals.append(c(x)[0])
+    two = torch.stack(vals).sort(dim=0).values[:2]
+    return ((two[1] - two[0]).abs() <= tol).cpu().numpy()
+
+
 def test_composed_sdf_reproduces_the_reference_call():
     c = cached_from_golden("f64")
     pts = torch.from_numpy(G["composed/points"]).cuda().reshape(3, 500, 3)
@@ -66,10 +78,20 @@ def test_composed_sdf_reproduces_the_reference_call():
     comp.set_transforms(torch.from_numpy(G["composed/batched/tf"]), batch_dim=(4,))
     v2, g2 = comp(pts)
     assert v2.shape == (4, 3, 500) and g2.shape == (4, 3, 500, 3)
-    for v, g, name in ((v1, g1, "single"), (v2, g2, "batched")):
+    for v, g, name, A in ((v1, g1, "single", 1), (v2, g2, "batched", 4)):
         rv, rg = G[f"composed/{name}/val"], G[f"composed/{name}/grad"]
+        # 1e-6 everywhere, except where the shims' torch matmul and the kernel's fma chain -- a last-place difference in a
+        # leaf-frame coordinate -- land on different sides of a half-voxel plane or a range edge; every such point is
+        # accounted for individually (no percentage)
+        n_bad, n_unexplained = H.composed_disagreements_explained([c, c, c], G[f"composed/{name}/tf"], A,
+                                                                  G["composed/points"], v.cpu().numpy(), rv)
+        print(f"composed/{name}: {n_bad} of {rv.size} values differ by more than 1e-6, all on a voxel / range boundary")
+        assert n_unexplained == 0 and n_bad < 0.01 * rv.size
         close = np.isclose(v.cpu().numpy(), rv, rtol=0, atol=1e-6)
-        assert close.mean() > 0.995
-        gc = np.isclose(g.cpu().numpy()[close], rg[close], rtol=0, atol=2e-6) | np.isnan(rg[close])
-        assert gc.mean() > 0.999
+        # gradients of agreeing values: 2e-6, except where two leaves tie in value (either leaf's gradient is a valid
+        # first-minimum under 1-ulp value differences); ties are detected from the per-leaf values
+        gv = g.cpu().numpy()
+        gclose = np.isclose(gv, rg, rtol=0, atol=2e-6).all(axis=-1) | np.isnan(rg).any(axis=-1)
+        tie = leaf_value_ties(c, G[f"composed/{name}/tf"], A, G["composed/points"]).reshape(close.shape)
+        assert not (close & ~gclose & ~tie).any()
     assert np.abs(v2.cpu().numpy() - G["composed/batched/val"]).max() < 0.06  # a boundary crossing moves one voxel at most

@@ -176,18 +176,21 @@ def test_composed_transform_bookkeeping_without_gpu():
         pv.batch_chamfer_dist(torch.eye(4)[None], torch.zeros(3, 3)) if torch.cuda.is_available() else (_ for _ in ()).throw(ValueError())
 
 
-def test_sample_mesh_points_is_seeded_and_on_the_surface(tmp_path):
-    obj = pv.MeshObjectFactory(H.mesh_path("box_template.obj"))
+def test_sample_mesh_points_is_served_from_its_cache_file_without_a_mesh(tmp_path):
+    """The cache half of sample_mesh_points (sdf.py:620-636) needs neither a mesh nor a GPU: same file layout as the
+    reference, cache[name][seed][num_points] = (points, normals, None).  (The draw itself runs on the GPU:
+    tests/test_sampler_gpu.py.)"""
     db = str(tmp_path / "pts.pkl")
-    p1, n1, cache = pv.sample_mesh_points(obj, num_points=300, seed=4, name="box", dbpath=db)
-    p2, n2, _ = pv.sample_mesh_points(obj, num_points=300, seed=4, name="box", dbpath=None)
-    assert torch.equal(p1, p2) and p1.shape == (300, 3) and n1.shape == (300, 3)
-    assert torch.allclose(p1.abs().max(dim=1).values, torch.ones(300), atol=1e-6)  # on the cube surface
-    assert torch.allclose((p1 * n1).sum(-1), torch.ones(300), atol=1e-6)
-    p3, _, _ = pv.sample_mesh_points(None, num_points=300, seed=4, name="box", dbpath=db)  # served from the cache file
-    assert torch.equal(p3, p1)
+    pts, nrm = torch.rand(300, 3, dtype=torch.float64), torch.rand(300, 3)
+    torch.save({"box": {4: {300: (pts, nrm, None)}}}, db)
+    p3, n3, cache = pv.sample_mesh_points(None, num_points=300, seed=4, name="box", dbpath=db)
+    assert torch.equal(p3, pts.float()) and torch.equal(n3, nrm) and 300 in cache["box"][4]
+    p4, _, _ = pv.sample_mesh_points(None, num_points=300, seed=4, name="box", dbpath=db, dtype=torch.float64)
+    assert torch.equal(p4, pts)
     with pytest.raises(RuntimeError):
         pv.sample_mesh_points(None, num_points=7, seed=4, name="box", dbpath=db)
+    with pytest.raises(RuntimeError):
+        pv.sample_mesh_points(None, num_points=300, seed=5, name="box", dbpath=db)
 
 
 def test_oracle_fk_matches_torch_fk_on_a_branched_tree():
@@ -261,3 +264,28 @@ def test_composed_surface_bounding_box_matches_the_reference_glue():
     bb = comp.surface_bounding_box(padding=0.02)
     assert bb.shape == tuple(G["composed/batched/bbox"].shape) == (4, 3, 2)
     assert np.allclose(bb.numpy(), G["composed/batched/bbox"], atol=1e-6)
+
+
+def test_the_disagreement_accounting_of_the_composed_tests():
+    """tests/helpers.composed_disagreements_explained: a value difference counts as explained only when some leaf-frame
+    coordinate sits on a half-voxel plane or a range edge (to a few float32 ulps); anywhere else it is a failure."""
+    class Leaf:
+        pass
+    leaf = Leaf()
+    leaf._view = pv.voxel.RangeView([(0.0, 1.0)] * 3, (11, 11, 11))  # res 0.1: half-voxel planes at 0.05, 0.15, ...
+    eye = np.eye(4)[None]
+    pts = np.array([[0.25, 0.52, 0.52],            # on the x = 0.25 plane
+                    [0.52, 0.52, 0.52],            # well inside a cell
+                    [1.0 + 2e-8, 0.52, 0.52],      # on the range edge x = 1
+                    [0.52, 0.52, 0.350001],        # 1e-6 off the z = 0.35 plane: beyond 16 ulp (3e-7) of 0.35
+                    [3.0, 0.25, 0.52]])            # a plane coordinate, but far outside the range: nothing to flip
+    a = np.zeros((1, 5))
+    n_bad, n_unexplained = H.composed_disagreements_explained([leaf], eye, 1, pts, a, a)
+    assert (n_bad, n_unexplained) == (0, 0)
+    b = np.full((1, 5), 0.01)
+    n_bad, n_unexplained = H.composed_disagreements_explained([leaf], eye, 1, pts, a, b)
+    assert (n_bad, n_unexplained) == (5, 3)
+    shifted = eye.copy()
+    shifted[0, 0, 3] = -0.27  # leaf frame x = p.x - 0.27: the second point (0.52) now lands on the 0.25 plane
+    n_bad, n_unexplained = H.composed_disagreements_explained([leaf], shifted, 1, pts, a, b)
+    assert n_bad == 5 and n_unexplained == 4

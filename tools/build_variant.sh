@@ -11,7 +11,7 @@ C=pytorch_volumetric_amd/csrc
 which=$(basename "$src" .hip); which=${which%%_*}
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -fno-fast-math -ffp-contract=off -Wno-unused-value -I$C -Iinclude "$@" -c "$src" -o tools/variants/${which}_$name.o
 objs=""
-for o in api cached composed mesh chamfer_grid xform fk voxelgrid; do
+for o in api cached composed mesh chamfer_grid xform fk voxelgrid sample; do
   if [ $o = $which ]; then objs="$objs tools/variants/${which}_$name.o"; else objs="$objs $C/$o.o"; fi
 done
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -o tools/variants/libpvamd_$name.so $objs
