@@ -286,6 +286,6 @@ def test_the_disagreement_accounting_of_the_composed_tests():
     n_bad, n_unexplained = H.composed_disagreements_explained([leaf], eye, 1, pts, a, b)
     assert (n_bad, n_unexplained) == (5, 3)
     shifted = eye.copy()
-    shifted[0, 0, 3] = -0.27  # leaf frame x = p.x - 0.27: the second point (0.52) now lands on the 0.25 plane
-    n_bad, n_unexplained = H.composed_disagreements_explained([leaf], shifted, 1, pts, a, b)
-    assert n_bad == 5 and n_unexplained == 4
+    shifted[0, 0, 3] = -0.27  # leaf frame x = p.x - 0.27: points 2 and 4 (x = 0.52) now land on the 0.25 plane,
+    n_bad, n_unexplained = H.composed_disagreements_explained([leaf], shifted, 1, pts, a, b)  # points 1, 3, 5 on nothing
+    assert n_bad == 5 and n_unexplained == 3
