@@ -25,6 +25,9 @@ extern "C" int pvamd_grid_finalize(pvamd_grid_t* g) {
     if (!g) return PVAMD_E_NULL;
     for (int d = 0; d < 3; ++d) {
         if (g->shape[d] < 2) return PVAMD_E_SHAPE;
+        // a surface bounding box is (min, max) with min <= max: the kernels' median-of-three form of sdf.py:559-567
+        // relies on it (NaN bounds, i.e. "no box", pass)
+        if (g->bb_min[d] > g->bb_max[d] || g->dbb_min[d] > g->dbb_max[d]) return PVAMD_E_SHAPE;
         const double lo = g->index_f64 ? g->dmin[d] : (double)g->fmin[d];
         const double hi = g->index_f64 ? g->dmax[d] : (double)g->fmax[d];
         const double res = g->index_f64 ? g->dres[d] : (double)g->fres[d];

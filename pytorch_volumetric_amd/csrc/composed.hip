@@ -6,51 +6,120 @@
 //
 // Leaf descriptors and the S transforms of configuration a are wave-uniform, so they are read through the scalar
 // cache into SGPRs (no LDS round trip); blockIdx.y = a keeps them uniform for the whole block.
+//
+// The kernel is VALU-issue-bound (profiles/r02_*: SQ_ACTIVE_INST_VALU = the kernel's duration), so this file counts
+// vector instructions:
+//  * the bounding-box vector of sdf.py:559-567 is ONE v_med3_f32 per component: with d1 = x - bb_min >= d2 = x - bb_max,
+//    "negate (bb_min - x) where positive, else max(x - bb_max, 0)" is the median of (d1, d2, 0), exactly (negation and
+//    adding 0 are exact, x < bb_min <=> bb_min - x > 0);
+//  * its norm is the correctly rounded square root built from v_sqrt_f32 + the two-sided residual test (what the
+//    compiler emits, minus the denormal pre-scaling, which a one-compare guard sends to the generic path);
+//  * the out-of-range candidate is computed branch-free for all lanes and the gather only under the in-range mask;
+//  * whole leaves are skipped per 256-point wave tile from ONE bounding-sphere test evaluated by 64 lanes = 64 leaves
+//    in parallel (instead of a per-lane test in front of every visit).
 #include "common.h"
 #include "grid_lookup.h"
 
 namespace pvamd {
 
+constexpr int kUnnormalised = 1 << 30;
 struct Best {
     float v, gx, gy, gz;  // gradient kept in the winning leaf's frame until the end
-    int s;
-    bool unnormalised;    // (gx,gy,gz) is the bounding-box vector t; the gradient t/v is formed only for the winner
+    int tag;              // winning leaf | kUnnormalised when (gx,gy,gz) is the bounding-box vector t (gradient = t / v).
+                          // (Tracking that bit as a wave mask in SGPRs instead saves one v_cndmask per visit and costs
+                          // five scalar instructions: measured slower, C4 0.92 -> 0.94 ms -- the scalar unit is as busy
+                          // as the vector units in this kernel.)
 };
 
-template <bool ANY_F64>
-PVAMD_DEV void visit_leaf(const pvamd_grid_t& g, const float* __restrict__ M, int s, float px, float py, float pz,
-                          Best& best) {
+// Correctly rounded sqrt of a sum of squares (n2 >= 0 or NaN).  v_sqrt_f32 is within 1 ulp; the neighbour whose
+// residual says so replaces it (the same two-sided test the compiler's expansion of sqrtf uses).  That test needs
+// n2 >= 2^-96 to keep its residuals normal -- the compiler pre-scales smaller inputs; here they (rare: a distance below
+// 3.5e-15) take the generic path through one wave-uniform branch.  0, inf and NaN fall through the test unchanged.
+PVAMD_DEV float sqrt_rn_sumsq(float n2) {
+    const bool tiny = (unsigned)(__float_as_int(n2) - 1) < (unsigned)(0x0F800000 - 1);  // 0 < n2 < 2^-96
+    if (__builtin_expect(wave_any(tiny), 0)) return sqrt_rn(n2);
+    float s = __builtin_amdgcn_sqrtf(n2);
+    const float s_dn = __int_as_float(__float_as_int(s) - 1), s_up = __int_as_float(__float_as_int(s) + 1);
+    const float r_dn = fmaf(-s_dn, s, n2), r_up = fmaf(-s_up, s, n2);
+    s = (r_dn <= 0.f) ? s_dn : s;
+    s = (r_up > 0.f) ? s_up : s;
+    return s;
+}
+
+// One leaf for one point: candidate (v, a, b, c) and whether it came from the grid (valid) or is the unnormalised
+// bounding-box vector.  EXACT = false is the hot-loop form: the voxel index is the fp32 estimate and `unsure` is raised
+// where the estimate cannot be trusted (a few (point, leaf) pairs per million); the caller redoes those points with
+// EXACT = true (the reference's own statements: IEEE division in the leaf's index dtype) after its loop.
+template <bool EXACT>
+PVAMD_DEV void leaf_candidate(const pvamd_grid_t& g, const float* __restrict__ M, float px, float py, float pz,
+                               float& v, float& a, float& b, float& c, bool& valid, bool& unsure) {
     const float x = affine_row(M[0], M[1], M[2], M[3], px, py, pz);
     const float y = affine_row(M[4], M[5], M[6], M[7], px, py, pz);
     const float z = affine_row(M[8], M[9], M[10], M[11], px, py, pz);
-    float v, a, b, c;
-    const bool valid = in_range(g, x, y, z);
-    if (valid) {
-        const int flat = (ANY_F64 && g.index_f64) ? voxel_flat_in_range<true>(g, x, y, z)
-                                                  : voxel_flat_in_range<false>(g, x, y, z);
+    valid = in_range(g, x, y, z);
+    auto gather = [&]() {
+        int flat;
+        if constexpr (EXACT) {
+            if (g.index_f64) voxel_flat<true>(g, x, y, z, flat);
+            else voxel_flat<false>(g, x, y, z, flat);
+        } else {
+            flat = voxel_flat_estimate(g, x, y, z, unsure);
+        }
         const float4 r = reinterpret_cast<const float4*>(g.vox)[flat];
         v = r.x; a = r.y; b = r.z; c = r.w;
-    } else {
-        float t[3];
-        v = bounding_box_vector(g, x, y, z, t);  // out-of-range leaves cost no division unless they win
-        a = t[0]; b = t[1]; c = t[2];
+    };
+    if (wave_all(valid)) {  // wave-uniform: the whole wave is inside this leaf's range
+        gather();
+        return;
     }
-    // torch.argmin semantics (sdf.py:421): first minimum wins, NaN counts as the minimum
-    const bool take = (best.s < 0) || (v < best.v) || (v != v && best.v == best.v);
-    if (take) {
-        best.v = v;
-        best.gx = a;
-        best.gy = b;
-        best.gz = c;
-        best.s = s;
-        best.unnormalised = !valid;
+    // sdf.py:559-567 for every lane (no exec masking; the in-range lanes' results are overwritten below)
+    a = __builtin_amdgcn_fmed3f(sub_rn(x, g.bb_min[0]), sub_rn(x, g.bb_max[0]), 0.f);
+    b = __builtin_amdgcn_fmed3f(sub_rn(y, g.bb_min[1]), sub_rn(y, g.bb_max[1]), 0.f);
+    c = __builtin_amdgcn_fmed3f(sub_rn(z, g.bb_min[2]), sub_rn(z, g.bb_max[2]), 0.f);
+    v = sqrt_rn_sumsq(fmaf(c, c, fmaf(b, b, mul_rn(a, a))));  // sdf.py:568; the division of :570 waits for the winner
+    if (wave_any(valid)) {
+        if (valid) gather();
+    }
+}
+
+// All leaves of the mask for one point, first-minimum semantics (see keep_first_minimum).
+template <bool EXACT>
+PVAMD_DEV void walk_leaves(const pvamd_grid_t* __restrict__ grids, int S, const float* __restrict__ tf, int A, int a,
+                            uint64_t todo, float px, float py, float pz, struct Best& best, bool& unsure);
+
+// torch.argmin semantics (sdf.py:421): first minimum wins, NaN counts as the minimum.  `best` starts at +inf, so
+// "v is smaller, or v is NaN and the incumbent is not" is !(v >= best.v) && best.v == best.v.
+PVAMD_DEV void keep_first_minimum(Best& best, int s, float v, float a, float b, float c, bool valid) {
+    const bool take = !(v >= best.v) & (best.v == best.v);
+    best.v = take ? v : best.v;
+    best.gx = take ? a : best.gx;
+    best.gy = take ? b : best.gy;
+    best.gz = take ? c : best.gz;
+    best.tag = take ? (valid ? s : (s | kUnnormalised)) : best.tag;
+}
+
+// The state before any leaf: +inf loses to every finite value and to NaN; if every leaf answers +inf (an infinite
+// query coordinate) the first visited leaf stays the winner with the gradient inf/inf = NaN the reference gets.
+PVAMD_DEV Best best_init(int first_leaf) {
+    return Best{__builtin_inff(), __builtin_nanf(""), __builtin_nanf(""), __builtin_nanf(""), first_leaf | kUnnormalised};
+}
+
+template <bool EXACT>
+PVAMD_DEV void walk_leaves(const pvamd_grid_t* __restrict__ grids, int S, const float* __restrict__ tf, int A, int a,
+                            uint64_t todo, float px, float py, float pz, Best& best, bool& unsure) {
+    for (int s = 0; s < S; ++s) {
+        if (s < 64 && !((todo >> s) & 1ull)) continue;  // wave-uniform
+        float v, ga, gb, gc;
+        bool valid;
+        leaf_candidate<EXACT>(grids[s], tf + 16 * ((int64_t)s * A + a), px, py, pz, v, ga, gb, gc, valid, unsure);
+        keep_first_minimum(best, s, v, ga, gb, gc, valid);
     }
 }
 
 // g_obj = R^T g_leaf with R the obj->leaf rotation (sdf.py:409 transform_normals by the inverse transform)
 PVAMD_DEV void rotate_back(const float* __restrict__ M, const Best& b, float& ox, float& oy, float& oz) {
     float gx = b.gx, gy = b.gy, gz = b.gz;
-    if (b.unnormalised) {  // sdf.py:570 grad = dtotal / dist
+    if (b.tag & kUnnormalised) {  // sdf.py:570 grad = dtotal / dist
         gx = div_rn(gx, b.v);
         gy = div_rn(gy, b.v);
         gz = div_rn(gz, b.v);
@@ -61,12 +130,13 @@ PVAMD_DEV void rotate_back(const float* __restrict__ M, const Best& b, float& ox
 }
 
 // ---- leaf culling ----
-// Per (leaf, configuration) a sphere in the OBJECT frame: centre = centre of the leaf's valid range box, squared
-// radius of that box (a point farther than that is certainly out of range, so its value is the bounding-box
-// distance), and the radius of the leaf's surface bounding box about the same centre (that distance is at least
-// |p - c| - r_bb).  A leaf whose lower bound cannot beat the running minimum of any of the wave's 256 points is skipped
-// as a whole; the bounds are inflated, so skipping never changes a result (first-minimum semantics need a strictly
-// smaller value to replace the incumbent).  Pays off for spatially coherent queries (grids, slices, scans).
+// Per (leaf, configuration), in the OBJECT frame (rigid transforms preserve distances): c = centre of the leaf's valid
+// range box; r_range = radius of that box about c (a point farther away is certainly out of range, so its value is the
+// bounding-box distance); r_bb = radius of the surface bounding box about c (that distance is >= |p - c| - r_bb);
+// e = distance from c to the bounding box (that distance is <= |p - c| + e).  All inflated, so that skipping a leaf
+// never changes a result: a leaf is skipped for a 256-point tile only when every point of the tile is out of its range
+// AND its lower bound exceeds the upper bound some other out-of-range leaf guarantees for every point (strictly, with
+// margin -- first-minimum ties cannot be affected).
 constexpr int kMaxCullLeaves = 64;
 
 PVAMD_DEV void build_cull_spheres(const pvamd_grid_t* __restrict__ grids, int S, const float* __restrict__ tf, int A,
@@ -74,7 +144,7 @@ PVAMD_DEV void build_cull_spheres(const pvamd_grid_t* __restrict__ grids, int S,
     for (int s = threadIdx.x; s < S && s < kMaxCullLeaves; s += blockDim.x) {
         const pvamd_grid_t& g = grids[s];
         const float* M = tf + 16 * ((int64_t)s * A + a);
-        float cl[3], r2 = 0.f, e2 = 0.f;
+        float cl[3], r2 = 0.f, e2 = 0.f, q2 = 0.f;
 #pragma unroll
         for (int d = 0; d < 3; ++d) {
             cl[d] = 0.5f * (g.vlo[d] + g.vhi[d]);
@@ -82,30 +152,84 @@ PVAMD_DEV void build_cull_spheres(const pvamd_grid_t* __restrict__ grids, int S,
             r2 += h * h;
             const float e = fmaxf(fabsf(g.bb_min[d] - cl[d]), fabsf(g.bb_max[d] - cl[d]));
             e2 += e * e;
+            const float q = fmaxf(fmaxf(g.bb_min[d] - cl[d], cl[d] - g.bb_max[d]), 0.f);  // c to the box, per axis
+            q2 += q * q;
         }
         // c_obj = R^T (c_leaf - t)
         const float ux = cl[0] - M[3], uy = cl[1] - M[7], uz = cl[2] - M[11];
         cull[s][0] = M[0] * ux + M[4] * uy + M[8] * uz;
         cull[s][1] = M[1] * ux + M[5] * uy + M[9] * uz;
         cull[s][2] = M[2] * ux + M[6] * uy + M[10] * uz;
-        const float scale = fmaxf(fmaxf(fabsf(cl[0]), fabsf(cl[1])), fabsf(cl[2])) + sqrt_rn(r2) + sqrt_rn(e2);
-        const float rr = sqrt_rn(r2) * 1.0001f + 1e-5f * scale;
-        cull[s][3] = rr * rr;                                   // beyond this (squared) the point is out of range
-        cull[s][4] = sqrt_rn(e2) * 1.0001f + 1e-5f * scale;    // radius of the surface bounding box
-        cull[s][5] = cull[s][6] = cull[s][7] = 0.f;
+        const float scale = fmaxf(fmaxf(fabsf(cl[0]), fabsf(cl[1])), fabsf(cl[2])) + sqrt_rn(r2) + sqrt_rn(e2) +
+                            fabsf(M[3]) + fabsf(M[7]) + fabsf(M[11]);
+        cull[s][3] = sqrt_rn(r2) * 1.0001f + 1e-5f * scale;  // r_range
+        cull[s][4] = sqrt_rn(e2) * 1.0001f + 1e-5f * scale;  // r_bb
+        cull[s][5] = sqrt_rn(q2) * 1.0001f + 1e-5f * scale;  // e
+        cull[s][6] = cull[s][7] = 0.f;
     }
 }
 
-// 1 when leaf `c` provably cannot replace the incumbent minimum of this point.  Straight-line (no short-circuit): the
-// compiler turned the && / || form into a tree of exec-mask branches that kept the scalar unit busier than the test.
-PVAMD_DEV int leaf_cannot_win(const float* __restrict__ c, float px, float py, float pz, const Best& best) {
-    const float dx = px - c[0], dy = py - c[1], dz = pz - c[2];
-    const float d2 = fmaf(dz, dz, fmaf(dy, dy, dx * dx));
-    const float t = best.v + c[4];
-    const int has_best = best.s >= 0;
-    const int out_of_range = d2 > c[3];
-    const int beaten = (int)(t <= 0.f) | (int)(d2 >= t * t * 1.0003f);
-    return has_best & out_of_range & beaten;
+// wave64 min over lanes: v_min_f32 with a DPP source (butterfly within rows of 16, then row broadcasts); the result is
+// read from lane 63.  One vector instruction per step; the s_nop covers the VALU-write -> DPP-read hazard, which the
+// compiler does not track through inline assembly.  NaN inputs are ignored (v_min_f32 returns the other operand).
+#define PVAMD_DPP_MIN(v, ctrl) asm volatile("s_nop 1\n\tv_min_f32_dpp %0, %0, %0 " ctrl : "+v"(v))
+PVAMD_DEV float wave_min(float v) {
+    PVAMD_DPP_MIN(v, "quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf");
+    PVAMD_DPP_MIN(v, "quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf");
+    PVAMD_DPP_MIN(v, "row_half_mirror row_mask:0xf bank_mask:0xf");
+    PVAMD_DPP_MIN(v, "row_mirror row_mask:0xf bank_mask:0xf");
+    PVAMD_DPP_MIN(v, "row_bcast:15 row_mask:0xa bank_mask:0xf");
+    PVAMD_DPP_MIN(v, "row_bcast:31 row_mask:0xc bank_mask:0xf");
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
+}
+PVAMD_DEV float wave_max(float v) { return -wave_min(-v); }
+
+// Leaves (bit s of the result) that some point of the wave's 256-point tile may need.  lane = leaf.
+PVAMD_DEV uint64_t tile_leaf_mask(const float (*cull)[8], int S, int lane, const float* __restrict__ spf) {
+    float lo[3], hi[3];
+    bool odd = false;  // a NaN / infinite coordinate: no bounds, visit everything
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+        lo[d] = __builtin_inff();
+        hi[d] = -__builtin_inff();
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int p = lane + 64 * k;
+#pragma unroll
+        for (int d = 0; d < 3; ++d) {
+            const float x = spf[3 * p + d];
+            lo[d] = fminf(lo[d], x);
+            hi[d] = fmaxf(hi[d], x);
+            odd |= !(fabsf(x) < __builtin_inff());
+        }
+    }
+    const uint64_t all = S >= 64 ? ~0ull : ((1ull << S) - 1ull);
+    if (wave_any(odd)) return all;
+    float ct[3], rt2 = 0.f, mag = 0.f;
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+        const float l = wave_min(lo[d]), h = wave_max(hi[d]);
+        ct[d] = 0.5f * (l + h);
+        const float half = 0.5f * (h - l);
+        rt2 += half * half;
+        mag = fmaxf(mag, fmaxf(fabsf(l), fabsf(h)));
+    }
+    const float rt = fast_sqrt(rt2) * 1.0001f + 1e-5f * mag;  // 1-ulp sqrt: the bounds carry 1e-4 of slack
+    bool near = false;
+    float lower = -__builtin_inff(), upper = __builtin_inff();
+    if (lane < S) {
+        const float* c = cull[lane];  // S <= 64 rows of 8 floats: lanes read distinct rows
+        const float dx = ct[0] - c[0], dy = ct[1] - c[1], dz = ct[2] - c[2];
+        const float d = fast_sqrt(dx * dx + dy * dy + dz * dz);
+        const float slack = 1e-5f * (d + mag) + 1e-30f;
+        near = !(d * 0.9999f - slack > rt + c[3]);           // some point may be inside the leaf's range
+        lower = d * 0.9999f - slack - rt - c[4];              // every point's value for this leaf is >= lower (when far)
+        upper = near ? __builtin_inff() : d * 1.0001f + slack + rt + c[5];  // ... and <= upper (when far)
+    }
+    const float ub = wave_min(upper);
+    const bool visit = near | !(lower > ub);
+    return __ballot((int)(visit && lane < S)) | (S > 64 ? ~0ull : 0ull);
 }
 
 // One wave = 256 consecutive points of one configuration per pass; all global traffic in contiguous 1 KB pieces
@@ -115,9 +239,13 @@ constexpr int kTilePoints = 256;
 #ifndef PVAMD_COMPOSED_PPP
 #define PVAMD_COMPOSED_PPP 2
 #endif
+// 8 waves per SIMD (<= 64 VGPRs, a few spills) beat the 6 the allocator would pick on its own: C4 0.84 -> 0.80 ms
+#ifndef PVAMD_COMPOSED_MINWAVES
+#define PVAMD_COMPOSED_MINWAVES 8
+#endif
 
-template <bool ANY_F64, int PPP>
-__global__ __launch_bounds__(kWavesPerBlock * 64) void composed_query_wave(const pvamd_grid_t* __restrict__ grids, int S,
+template <int PPP>
+__global__ __launch_bounds__(kWavesPerBlock * 64, PVAMD_COMPOSED_MINWAVES) void composed_query_wave(const pvamd_grid_t* __restrict__ grids, int S,
                                                                            const float* __restrict__ tf, int A,
                                                                            const f32x4* __restrict__ pts4,
                                                                            int64_t ntiles, int64_t P,
@@ -140,6 +268,8 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void composed_query_wave(const
         sp[lane + 64] = src[lane + 64];
         sp[lane + 128] = src[lane + 128];
         PVAMD_WAVE_SYNC();
+        const uint64_t todo = tile_leaf_mask(cull, S, lane, spf);
+        const int first_leaf = todo ? __builtin_ctzll(todo) : 0;
         // PPP points per lane go through the leaf loop together (fewer live registers -> more waves per SIMD; the
         // leaf constants are scalar loads, so re-walking the leaves per pass costs SALU/SMEM, not VALU)
 #pragma unroll
@@ -152,33 +282,46 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void composed_query_wave(const
                 px[k] = spf[3 * p];
                 py[k] = spf[3 * p + 1];
                 pz[k] = spf[3 * p + 2];
-                best[k] = Best{0.f, 0.f, 0.f, 0.f, -1, false};
+                best[k] = best_init(first_leaf);
             }
-            for (int s = 0; s < S; ++s) {
-                if (s < kMaxCullLeaves) {
-                    const float* c = cull[s];  // wave-uniform: LDS broadcast
-                    int dead = 1;
+            bool unsure[PPP];
 #pragma unroll
-                    for (int k = 0; k < PPP; ++k) dead &= leaf_cannot_win(c, px[k], py[k], pz[k], best[k]);
-                    if (__all(dead)) continue;
-                }
+            for (int k = 0; k < PPP; ++k) unsure[k] = false;
+            for (int s = 0; s < S; ++s) {
+                if (s < 64 && !((todo >> s) & 1ull)) continue;  // wave-uniform
                 const float* M = tf + 16 * ((int64_t)s * A + a);  // wave-uniform: scalar loads
                 const pvamd_grid_t& g = grids[s];
 #pragma unroll
-                for (int k = 0; k < PPP; ++k) visit_leaf<ANY_F64>(g, M, s, px[k], py[k], pz[k], best[k]);
+                for (int k = 0; k < PPP; ++k) {
+                    float v, ga, gb, gc;
+                    bool valid;
+                    leaf_candidate<false>(g, M, px[k], py[k], pz[k], v, ga, gb, gc, valid, unsure[k]);
+                    keep_first_minimum(best[k], s, v, ga, gb, gc, valid);
+                }
+            }
+            // the few points whose index estimate could not be trusted for some leaf: all over again, exactly
+#pragma unroll
+            for (int k = 0; k < PPP; ++k) {
+                if (__builtin_expect(wave_any(unsure[k]), 0)) {
+                    Best redo = best_init(first_leaf);
+                    bool dummy = false;
+                    walk_leaves<true>(grids, S, tf, A, a, todo, px[k], py[k], pz[k], redo, dummy);
+                    if (unsure[k]) best[k] = redo;
+                }
             }
 #pragma unroll
             for (int k = 0; k < PPP; ++k) {
                 const int p = lane + 64 * (h + k);
+                const int s_win = best[k].tag & (kUnnormalised - 1);
                 // per-lane winner: these matrix reads are vector loads, but the S*A stack is tiny and cache-resident
-                const float* M = tf + 16 * ((int64_t)best[k].s * A + a);
+                const float* M = tf + 16 * ((int64_t)s_win * A + a);
                 float gx, gy, gz;
                 rotate_back(M, best[k], gx, gy, gz);
                 svf[p] = best[k].v;  // a lane overwrites only the LDS slots of the points it owns
                 spf[3 * p] = gx;
                 spf[3 * p + 1] = gy;
                 spf[3 * p + 2] = gz;
-                if (leaf) leaf[(int64_t)a * P + tile * kTilePoints + p] = best[k].s;
+                if (leaf) leaf[(int64_t)a * P + tile * kTilePoints + p] = s_win;
             }
         }
         PVAMD_WAVE_SYNC();
@@ -192,7 +335,6 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void composed_query_wave(const
     }
 }
 
-template <bool ANY_F64>
 __global__ __launch_bounds__(256) void composed_query_scalar(const pvamd_grid_t* __restrict__ grids, int S,
                                                               const float* __restrict__ tf, int A,
                                                               const float* __restrict__ pts, int64_t first,
@@ -200,20 +342,34 @@ __global__ __launch_bounds__(256) void composed_query_scalar(const pvamd_grid_t*
                                                               float* __restrict__ grad, int* __restrict__ leaf, int a0) {
     const int a = a0 + blockIdx.y;
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-    for (int64_t i = first + (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < P; i += stride) {
-        const float px = pts[3 * i], py = pts[3 * i + 1], pz = pts[3 * i + 2];
-        Best best{0.f, 0.f, 0.f, 0.f, -1, false};
-        for (int s = 0; s < S; ++s) {
-            visit_leaf<ANY_F64>(grids[s], tf + 16 * ((int64_t)s * A + a), s, px, py, pz, best);
+    const int64_t n = P - first;
+    // whole waves iterate together (leaf_candidate votes across the wave): lanes past the end carry a NaN point
+    const int64_t rounds = (n + stride - 1) / stride;
+    for (int64_t r = 0; r < rounds; ++r) {
+        const int64_t i = first + r * stride + (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+        const bool live = i < P;
+        const float nanv = __builtin_nanf("");
+        const float px = live ? pts[3 * i] : nanv, py = live ? pts[3 * i + 1] : nanv, pz = live ? pts[3 * i + 2] : nanv;
+        Best best = best_init(0);
+        bool unsure = false;
+        walk_leaves<false>(grids, S, tf, A, a, ~0ull, px, py, pz, best, unsure);
+        if (__builtin_expect(wave_any(unsure), 0)) {
+            Best redo = best_init(0);
+            bool dummy = false;
+            walk_leaves<true>(grids, S, tf, A, a, ~0ull, px, py, pz, redo, dummy);
+            if (unsure) best = redo;
         }
-        float gx, gy, gz;
-        rotate_back(tf + 16 * ((int64_t)best.s * A + a), best, gx, gy, gz);
-        const int64_t o = (int64_t)a * P + i;
-        val[o] = best.v;
-        grad[3 * o] = gx;
-        grad[3 * o + 1] = gy;
-        grad[3 * o + 2] = gz;
-        if (leaf) leaf[o] = best.s;
+        if (live) {
+            const int s_win = best.tag & (kUnnormalised - 1);
+            float gx, gy, gz;
+            rotate_back(tf + 16 * ((int64_t)s_win * A + a), best, gx, gy, gz);
+            const int64_t o = (int64_t)a * P + i;
+            val[o] = best.v;
+            grad[3 * o] = gx;
+            grad[3 * o + 1] = gy;
+            grad[3 * o + 2] = gz;
+            if (leaf) leaf[o] = s_win;
+        }
     }
 }
 
@@ -224,7 +380,7 @@ using namespace pvamd;
 extern "C" int pvamd_composed_query(const pvamd_grid_t* grids, int32_t S, const float* tf, int32_t A,
                                     const float* points, int64_t P, float* out_val, float* out_grad,
                                     int32_t* out_leaf, void* stream) {
-    if (S < 1 || A < 1 || P < 0) return PVAMD_E_SHAPE;
+    if (S < 1 || A < 1 || P < 0 || S >= kUnnormalised) return PVAMD_E_SHAPE;
     if (P == 0) return 0;
     if (!grids || !tf || !out_val || !out_grad || !points) return PVAMD_E_NULL;
     if (!aligned_to(grids, 8) || !aligned_to(tf, 4) || !aligned_to(points, 4)) return PVAMD_E_ALIGN;
@@ -249,14 +405,14 @@ extern "C" int pvamd_composed_query(const pvamd_grid_t* grids, int32_t S, const 
         if (ntiles > 0) {
             const int64_t need = (ntiles + kWavesPerBlock - 1) / kWavesPerBlock;
             const unsigned gx = (unsigned)(need < cap ? need : (cap < 1 ? 1 : cap));
-            hipLaunchKernelGGL((composed_query_wave<true, PVAMD_COMPOSED_PPP>), dim3(gx, An), dim3(kWavesPerBlock * 64), 0, s, grids, S, tf, A,
+            hipLaunchKernelGGL((composed_query_wave<PVAMD_COMPOSED_PPP>), dim3(gx, An), dim3(kWavesPerBlock * 64), 0, s, grids, S, tf, A,
                                reinterpret_cast<const f32x4*>(points), ntiles, P, out_val, out_grad, out_leaf, a0);
         }
         const int64_t first = ntiles * kTilePoints;
         if (first < P) {
             const int64_t need = (P - first + 255) / 256;
             const unsigned gx = (unsigned)(need < cap ? need : (cap < 1 ? 1 : cap));
-            hipLaunchKernelGGL((composed_query_scalar<true>), dim3(gx, An), dim3(256), 0, s, grids, S, tf, A, points, first,
+            hipLaunchKernelGGL(composed_query_scalar, dim3(gx, An), dim3(256), 0, s, grids, S, tf, A, points, first,
                                P, out_val, out_grad, out_leaf, a0);
         }
     }

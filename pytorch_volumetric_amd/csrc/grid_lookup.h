@@ -74,6 +74,30 @@ PVAMD_DEV int voxel_index_fast(const pvamd_grid_t& g, int d, float p) {
     return (int)k;
 }
 
+// Wave votes without the 0/1 round trip through a VGPR that __all / __any cost: the compare mask is already an SGPR pair.
+PVAMD_DEV bool wave_all(bool p) { return __builtin_amdgcn_ballot_w64(p) == __builtin_amdgcn_ballot_w64(true); }
+PVAMD_DEV bool wave_any(bool p) { return __builtin_amdgcn_ballot_w64(p) != 0; }
+
+// Index estimate only (no exact fallback inline): returns the flat index of the estimate and sets `unsure` when some
+// coordinate sits within its rounding bound of a half-integer -- the caller then redoes that POINT with the exact
+// statements (voxel_flat<F64>) outside its hot loop, which keeps the float64 division sequence (and its registers) out
+// of it.  The gather is kept in bounds by clamping the flat index once (a no-op for a well-formed descriptor, whose
+// in-range points always index inside the grid).
+PVAMD_DEV int voxel_flat_estimate(const pvamd_grid_t& g, float x, float y, float z, bool& unsure) {
+    const float p[3] = {x, y, z};
+    int k[3];
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+        const float t = mul_rn(sub_rn(p[d], g.fmin[d]), g.inv32[d]);
+        const float kc = __builtin_rintf(t);
+        unsure |= !(sub_rn(0.5f, fabsf(sub_rn(t, kc))) > g.err32[d]);  // NaN-safe: NaN is "unsure"
+        k[d] = (int)kc;
+    }
+    const unsigned flat = (unsigned)((k[0] * g.shape[1] + k[1]) * g.shape[2] + k[2]);
+    const unsigned last = (unsigned)(g.shape[0] * g.shape[1] * g.shape[2] - 1);
+    return (int)(flat < last ? flat : last);
+}
+
 template <bool F64>
 PVAMD_DEV int voxel_flat_in_range(const pvamd_grid_t& g, float x, float y, float z) {
     int kx = voxel_index_fast<F64>(g, 0, x), ky = voxel_index_fast<F64>(g, 1, y), kz = voxel_index_fast<F64>(g, 2, z);
