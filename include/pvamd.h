@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define PVAMD_ABI_VERSION 4
+#define PVAMD_ABI_VERSION 5
 
 #define PVAMD_E_NULL      (-1)  /* a required pointer is NULL            */
 #define PVAMD_E_SHAPE     (-2)  /* a size/shape argument is out of range */
@@ -173,10 +173,18 @@ int pvamd_voxel_scatter_u8(const pvamd_grid_t* grid, uint8_t* storage, const flo
  * s at x_s, rotate that gradient back with R^T, keep the first minimum over s.
  * grids: device [S] pvamd_grid_t (every oob_mode must be BOUNDING_BOX).  tf: device [S*A][4][4] obj->leaf,
  * leaf-major (model_to_sdf.py:100-113).  out_val: device [A][P].  out_grad: device [A][P][3].
- * out_leaf: device [A][P] int32 or NULL (arg-min leaf, for tests).                                      */
+ * out_leaf: device [A][P] int32 or NULL (arg-min leaf, for tests).
+ * flags: 0, or PVAMD_COMPOSED_INLINE_EXACT -- a tuning hint that never changes a result: the kernels estimate a voxel
+ * index in fp32 and fall back to the reference's exact division where the estimate is within its error bound (err32 of
+ * pvamd_grid_finalize) of a rounding boundary.  By default flagged points are redone after the leaf loop (cheapest when
+ * flags are rare and the grids are L2-resident, i.e. the kernel is instruction-bound); with the hint the exact statements
+ * sit inline (cheapest for large, gather-bound grids, whose larger coordinate / resolution ratios also flag more visits).
+ * The transforms must be RIGID (orthonormal 3x3, last row 0 0 0 1): the gradient is rotated back with R^T and the
+ * leaf-culling bounds rely on distances being preserved.                                                  */
+#define PVAMD_COMPOSED_INLINE_EXACT 1
 int pvamd_composed_query(const pvamd_grid_t* grids, int32_t S, const float* tf, int32_t A,
                          const float* points, int64_t P,
-                         float* out_val, float* out_grad, int32_t* out_leaf, void* stream);
+                         float* out_val, float* out_grad, int32_t* out_leaf, int32_t flags, void* stream);
 
 /* Prepare a mesh for the query kernels: per-triangle records (corners, original face id, bounding sphere, and the
  * triangle's in-plane bounding rectangle: centre, two unit axes, half extents) plus one bounding sphere per run of

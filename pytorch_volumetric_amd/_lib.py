@@ -11,9 +11,10 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("PVAMD_LIB") or os.path.join(_HERE, "csrc", "libpvamd.so")  # PVAMD_LIB: A/B builds (tools/)
 
-ABI_VERSION = 4
+ABI_VERSION = 5
 OOB_LOOKUP_GT_SDF = 0
 OOB_BOUNDING_BOX = 1
+COMPOSED_INLINE_EXACT = 1
 TRI_REC = 24
 TRI_TILE = 256
 TRI_GROUP = 16
@@ -103,7 +104,7 @@ SIGNATURES = {
                                              ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]),
     "pvamd_composed_query": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int32, ctypes.c_void_p, ctypes.c_int32,
                                             ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p,
-                                            ctypes.c_void_p, ctypes.c_void_p]),
+                                            ctypes.c_void_p, ctypes.c_int32, ctypes.c_void_p]),
     "pvamd_voxel_gather_f32": (ctypes.c_int, [ctypes.POINTER(GridDesc), ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64,
                                               ctypes.c_float, ctypes.c_void_p, ctypes.c_void_p]),
     "pvamd_voxel_gather_u8": (ctypes.c_int, [ctypes.POINTER(GridDesc), ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64,

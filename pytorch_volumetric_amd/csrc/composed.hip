@@ -46,11 +46,19 @@ PVAMD_DEV float sqrt_rn_sumsq(float n2) {
     return s;
 }
 
+// How a visit obtains its voxel index (all three give the reference's index, bit for bit):
+//   kEstimate    the fp32 estimate; `unsure` is raised where it cannot be trusted and the CALLER redoes those points with
+//                kExact after its leaf loop -- keeps the division sequence and its registers out of the hot loop; right
+//                when flags are rare (a few per million visits on 100 KB link grids)
+//   kInlineExact the estimate with the exact statements inline behind one rare branch -- right when flags are common
+//                (large coordinate / resolution ratios: 21 MB README-size link grids flag 22 % of the wave passes, and
+//                a redo pass per flag costs 6.2 -> 7.1 ms there)
+//   kExact       the reference's own statements only (IEEE division in the leaf's index dtype)
+enum IndexMode { kEstimate = 0, kInlineExact = 1, kExact = 2 };
+
 // One leaf for one point: candidate (v, a, b, c) and whether it came from the grid (valid) or is the unnormalised
-// bounding-box vector.  EXACT = false is the hot-loop form: the voxel index is the fp32 estimate and `unsure` is raised
-// where the estimate cannot be trusted (a few (point, leaf) pairs per million); the caller redoes those points with
-// EXACT = true (the reference's own statements: IEEE division in the leaf's index dtype) after its loop.
-template <bool EXACT>
+// bounding-box vector.
+template <int MODE>
 PVAMD_DEV void leaf_candidate(const pvamd_grid_t& g, const float* __restrict__ M, float px, float py, float pz,
                                float& v, float& a, float& b, float& c, bool& valid, bool& unsure) {
     const float x = affine_row(M[0], M[1], M[2], M[3], px, py, pz);
@@ -59,9 +67,11 @@ PVAMD_DEV void leaf_candidate(const pvamd_grid_t& g, const float* __restrict__ M
     valid = in_range(g, x, y, z);
     auto gather = [&]() {
         int flat;
-        if constexpr (EXACT) {
+        if constexpr (MODE == kExact) {
             if (g.index_f64) voxel_flat<true>(g, x, y, z, flat);
             else voxel_flat<false>(g, x, y, z, flat);
+        } else if constexpr (MODE == kInlineExact) {
+            flat = voxel_flat_in_range_fused(g, x, y, z);
         } else {
             flat = voxel_flat_estimate(g, x, y, z, unsure);
         }
@@ -83,7 +93,7 @@ PVAMD_DEV void leaf_candidate(const pvamd_grid_t& g, const float* __restrict__ M
 }
 
 // All leaves of the mask for one point, first-minimum semantics (see keep_first_minimum).
-template <bool EXACT>
+template <int MODE>
 PVAMD_DEV void walk_leaves(const pvamd_grid_t* __restrict__ grids, int S, const float* __restrict__ tf, int A, int a,
                             uint64_t todo, float px, float py, float pz, struct Best& best, bool& unsure);
 
@@ -104,14 +114,14 @@ PVAMD_DEV Best best_init(int first_leaf) {
     return Best{__builtin_inff(), __builtin_nanf(""), __builtin_nanf(""), __builtin_nanf(""), first_leaf | kUnnormalised};
 }
 
-template <bool EXACT>
+template <int MODE>
 PVAMD_DEV void walk_leaves(const pvamd_grid_t* __restrict__ grids, int S, const float* __restrict__ tf, int A, int a,
                             uint64_t todo, float px, float py, float pz, Best& best, bool& unsure) {
     for (int s = 0; s < S; ++s) {
         if (s < 64 && !((todo >> s) & 1ull)) continue;  // wave-uniform
         float v, ga, gb, gc;
         bool valid;
-        leaf_candidate<EXACT>(grids[s], tf + 16 * ((int64_t)s * A + a), px, py, pz, v, ga, gb, gc, valid, unsure);
+        leaf_candidate<MODE>(grids[s], tf + 16 * ((int64_t)s * A + a), px, py, pz, v, ga, gb, gc, valid, unsure);
         keep_first_minimum(best, s, v, ga, gb, gc, valid);
     }
 }
@@ -184,8 +194,10 @@ PVAMD_DEV float wave_min(float v) {
 }
 PVAMD_DEV float wave_max(float v) { return -wave_min(-v); }
 
-// Leaves (bit s of the result) that some point of the wave's 256-point tile may need.  lane = leaf.
-PVAMD_DEV uint64_t tile_leaf_mask(const float (*cull)[8], int S, int lane, const float* __restrict__ spf) {
+// Leaves (bit s of the result) that some point of the wave's 256-point tile may need.  lane = leaf.  `lower` (lane s)
+// = a lower bound of leaf s's value over the whole tile when the tile is entirely outside the leaf's range, -inf
+// otherwise: what the leaf loop re-tests against its running minimum (see composed_query_wave).
+PVAMD_DEV uint64_t tile_leaf_mask(const float (*cull)[8], int S, int lane, const float* __restrict__ spf, float& lower) {
     float lo[3], hi[3];
     bool odd = false;  // a NaN / infinite coordinate: no bounds, visit everything
 #pragma unroll
@@ -205,6 +217,7 @@ PVAMD_DEV uint64_t tile_leaf_mask(const float (*cull)[8], int S, int lane, const
         }
     }
     const uint64_t all = S >= 64 ? ~0ull : ((1ull << S) - 1ull);
+    lower = -__builtin_inff();
     if (wave_any(odd)) return all;
     float ct[3], rt2 = 0.f, mag = 0.f;
 #pragma unroll
@@ -217,19 +230,20 @@ PVAMD_DEV uint64_t tile_leaf_mask(const float (*cull)[8], int S, int lane, const
     }
     const float rt = fast_sqrt(rt2) * 1.0001f + 1e-5f * mag;  // 1-ulp sqrt: the bounds carry 1e-4 of slack
     bool near = false;
-    float lower = -__builtin_inff(), upper = __builtin_inff();
+    float upper = __builtin_inff();
     if (lane < S) {
         const float* c = cull[lane];  // S <= 64 rows of 8 floats: lanes read distinct rows
         const float dx = ct[0] - c[0], dy = ct[1] - c[1], dz = ct[2] - c[2];
         const float d = fast_sqrt(dx * dx + dy * dy + dz * dz);
         const float slack = 1e-5f * (d + mag) + 1e-30f;
         near = !(d * 0.9999f - slack > rt + c[3]);           // some point may be inside the leaf's range
-        lower = d * 0.9999f - slack - rt - c[4];              // every point's value for this leaf is >= lower (when far)
-        upper = near ? __builtin_inff() : d * 1.0001f + slack + rt + c[5];  // ... and <= upper (when far)
+        // when far: every point's value for this leaf is >= lower and <= upper
+        lower = near ? -__builtin_inff() : d * 0.9999f - slack - rt - c[4];
+        upper = near ? __builtin_inff() : d * 1.0001f + slack + rt + c[5];
     }
     const float ub = wave_min(upper);
-    const bool visit = near | !(lower > ub);
-    return __ballot((int)(visit && lane < S)) | (S > 64 ? ~0ull : 0ull);
+    const bool visit = !(lower > ub);
+    return __builtin_amdgcn_ballot_w64(visit && lane < S) | (S > 64 ? ~0ull : 0ull);
 }
 
 // One wave = 256 consecutive points of one configuration per pass; all global traffic in contiguous 1 KB pieces
@@ -239,13 +253,15 @@ constexpr int kTilePoints = 256;
 #ifndef PVAMD_COMPOSED_PPP
 #define PVAMD_COMPOSED_PPP 2
 #endif
-// 8 waves per SIMD (<= 64 VGPRs, a few spills) beat the 6 the allocator would pick on its own: C4 0.84 -> 0.80 ms
+// kEstimate (instruction-bound, L2-resident grids): 8 waves per SIMD (<= 64 VGPRs, a few spills) beat the 6 the allocator
+// would pick on its own, C4 0.84 -> 0.80 ms.  kInlineExact (gather-bound, large grids): forcing 8 costs spills around the
+// division sequence, 6.19 -> 6.57 ms on the README-size robot; the allocator's own choice (5-6) is left alone.
 #ifndef PVAMD_COMPOSED_MINWAVES
 #define PVAMD_COMPOSED_MINWAVES 8
 #endif
 
-template <int PPP>
-__global__ __launch_bounds__(kWavesPerBlock * 64, PVAMD_COMPOSED_MINWAVES) void composed_query_wave(const pvamd_grid_t* __restrict__ grids, int S,
+template <int PPP, int MODE>
+__global__ __launch_bounds__(kWavesPerBlock * 64, MODE == kEstimate ? PVAMD_COMPOSED_MINWAVES : 1) void composed_query_wave(const pvamd_grid_t* __restrict__ grids, int S,
                                                                            const float* __restrict__ tf, int A,
                                                                            const f32x4* __restrict__ pts4,
                                                                            int64_t ntiles, int64_t P,
@@ -268,8 +284,14 @@ __global__ __launch_bounds__(kWavesPerBlock * 64, PVAMD_COMPOSED_MINWAVES) void 
         sp[lane + 64] = src[lane + 64];
         sp[lane + 128] = src[lane + 128];
         PVAMD_WAVE_SYNC();
-        const uint64_t todo = tile_leaf_mask(cull, S, lane, spf);
+        float lower;
+        const uint64_t todo = tile_leaf_mask(cull, S, lane, spf, lower);
         const int first_leaf = todo ? __builtin_ctzll(todo) : 0;
+        // A tile compact enough for the static test to drop a leaf is worth re-testing as the minimum tightens: after
+        // every visited leaf the wave's largest running minimum is an upper bound of every point's final value, and the
+        // leaves whose lower bound exceeds it are dropped (strictly greater, so ties cannot be affected).  Scattered
+        // tiles (nothing dropped statically) skip the ~10 instructions per visited leaf.
+        const bool refine = S <= 64 && todo != (S >= 64 ? ~0ull : ((1ull << S) - 1ull));
         // PPP points per lane go through the leaf loop together (fewer live registers -> more waves per SIMD; the
         // leaf constants are scalar loads, so re-walking the leaves per pass costs SALU/SMEM, not VALU)
 #pragma unroll
@@ -287,26 +309,37 @@ __global__ __launch_bounds__(kWavesPerBlock * 64, PVAMD_COMPOSED_MINWAVES) void 
             bool unsure[PPP];
 #pragma unroll
             for (int k = 0; k < PPP; ++k) unsure[k] = false;
+            uint64_t rem = todo;
             for (int s = 0; s < S; ++s) {
-                if (s < 64 && !((todo >> s) & 1ull)) continue;  // wave-uniform
+                if (s < 64 && !((rem >> s) & 1ull)) continue;  // wave-uniform
                 const float* M = tf + 16 * ((int64_t)s * A + a);  // wave-uniform: scalar loads
                 const pvamd_grid_t& g = grids[s];
+                // all PPP candidates first, their comparisons after: the gathers of the PPP points are in flight together
+                float v[PPP], ga[PPP], gb[PPP], gc[PPP];
+                bool valid[PPP];
 #pragma unroll
-                for (int k = 0; k < PPP; ++k) {
-                    float v, ga, gb, gc;
-                    bool valid;
-                    leaf_candidate<false>(g, M, px[k], py[k], pz[k], v, ga, gb, gc, valid, unsure[k]);
-                    keep_first_minimum(best[k], s, v, ga, gb, gc, valid);
+                for (int k = 0; k < PPP; ++k)
+                    leaf_candidate<MODE>(g, M, px[k], py[k], pz[k], v[k], ga[k], gb[k], gc[k], valid[k], unsure[k]);
+#pragma unroll
+                for (int k = 0; k < PPP; ++k) keep_first_minimum(best[k], s, v[k], ga[k], gb[k], gc[k], valid[k]);
+                if (refine) {
+                    float m = best[0].v;
+#pragma unroll
+                    for (int k = 1; k < PPP; ++k) m = __builtin_fmaxf(m, best[k].v);
+                    const float ub = wave_max(m);  // NaN minima are ignored: nothing replaces them anyway
+                    rem &= ~__builtin_amdgcn_ballot_w64(lower > ub + 1e-6f * fabsf(ub));
                 }
             }
-            // the few points whose index estimate could not be trusted for some leaf: all over again, exactly
+            if constexpr (MODE == kEstimate) {
+                // the few points whose index estimate could not be trusted for some leaf: all over again, exactly
 #pragma unroll
-            for (int k = 0; k < PPP; ++k) {
-                if (__builtin_expect(wave_any(unsure[k]), 0)) {
-                    Best redo = best_init(first_leaf);
-                    bool dummy = false;
-                    walk_leaves<true>(grids, S, tf, A, a, todo, px[k], py[k], pz[k], redo, dummy);
-                    if (unsure[k]) best[k] = redo;
+                for (int k = 0; k < PPP; ++k) {
+                    if (__builtin_expect(wave_any(unsure[k]), 0)) {
+                        Best redo = best_init(first_leaf);
+                        bool dummy = false;
+                        walk_leaves<kExact>(grids, S, tf, A, a, todo, px[k], py[k], pz[k], redo, dummy);
+                        if (unsure[k]) best[k] = redo;
+                    }
                 }
             }
 #pragma unroll
@@ -352,13 +385,7 @@ __global__ __launch_bounds__(256) void composed_query_scalar(const pvamd_grid_t*
         const float px = live ? pts[3 * i] : nanv, py = live ? pts[3 * i + 1] : nanv, pz = live ? pts[3 * i + 2] : nanv;
         Best best = best_init(0);
         bool unsure = false;
-        walk_leaves<false>(grids, S, tf, A, a, ~0ull, px, py, pz, best, unsure);
-        if (__builtin_expect(wave_any(unsure), 0)) {
-            Best redo = best_init(0);
-            bool dummy = false;
-            walk_leaves<true>(grids, S, tf, A, a, ~0ull, px, py, pz, redo, dummy);
-            if (unsure) best = redo;
-        }
+        walk_leaves<kInlineExact>(grids, S, tf, A, a, ~0ull, px, py, pz, best, unsure);
         if (live) {
             const int s_win = best.tag & (kUnnormalised - 1);
             float gx, gy, gz;
@@ -379,7 +406,7 @@ using namespace pvamd;
 
 extern "C" int pvamd_composed_query(const pvamd_grid_t* grids, int32_t S, const float* tf, int32_t A,
                                     const float* points, int64_t P, float* out_val, float* out_grad,
-                                    int32_t* out_leaf, void* stream) {
+                                    int32_t* out_leaf, int32_t flags, void* stream) {
     if (S < 1 || A < 1 || P < 0 || S >= kUnnormalised) return PVAMD_E_SHAPE;
     if (P == 0) return 0;
     if (!grids || !tf || !out_val || !out_grad || !points) return PVAMD_E_NULL;
@@ -405,8 +432,12 @@ extern "C" int pvamd_composed_query(const pvamd_grid_t* grids, int32_t S, const 
         if (ntiles > 0) {
             const int64_t need = (ntiles + kWavesPerBlock - 1) / kWavesPerBlock;
             const unsigned gx = (unsigned)(need < cap ? need : (cap < 1 ? 1 : cap));
-            hipLaunchKernelGGL((composed_query_wave<PVAMD_COMPOSED_PPP>), dim3(gx, An), dim3(kWavesPerBlock * 64), 0, s, grids, S, tf, A,
-                               reinterpret_cast<const f32x4*>(points), ntiles, P, out_val, out_grad, out_leaf, a0);
+            if (flags & PVAMD_COMPOSED_INLINE_EXACT)
+                hipLaunchKernelGGL((composed_query_wave<PVAMD_COMPOSED_PPP, kInlineExact>), dim3(gx, An), dim3(kWavesPerBlock * 64), 0, s,
+                                   grids, S, tf, A, reinterpret_cast<const f32x4*>(points), ntiles, P, out_val, out_grad, out_leaf, a0);
+            else
+                hipLaunchKernelGGL((composed_query_wave<PVAMD_COMPOSED_PPP, kEstimate>), dim3(gx, An), dim3(kWavesPerBlock * 64), 0, s,
+                                   grids, S, tf, A, reinterpret_cast<const f32x4*>(points), ntiles, P, out_val, out_grad, out_leaf, a0);
         }
         const int64_t first = ntiles * kTilePoints;
         if (first < P) {

@@ -98,6 +98,37 @@ PVAMD_DEV int voxel_flat_estimate(const pvamd_grid_t& g, float x, float y, float
     return (int)(flat < last ? flat : last);
 }
 
+// The estimate with the exact statements inline, behind ONE rare branch for all three coordinates: the flagged lanes redo
+// them with the IEEE division of the leaf's index dtype (a loop, not unrolled: the float64 division sequence exists
+// once).  For grids where the flag is common (large coordinate / resolution ratios, e.g. 21 MB README-size link grids:
+// 22 % of the wave passes hold a flagged (lane, leaf)) this is cheaper than redoing whole points after the loop.
+PVAMD_DEV int voxel_flat_in_range_fused(const pvamd_grid_t& g, float x, float y, float z) {
+    const float p[3] = {x, y, z};
+    int k[3];
+    bool unsure = false;
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+        const float t = mul_rn(sub_rn(p[d], g.fmin[d]), g.inv32[d]);
+        const float kc = __builtin_rintf(t);
+        unsure |= !(sub_rn(0.5f, fabsf(sub_rn(t, kc))) > g.err32[d]);  // NaN-safe: NaN takes the exact path
+        k[d] = (int)kc;
+    }
+    if (__builtin_expect(wave_any(unsure), 0)) {
+        if (unsure) {
+#pragma unroll 1
+            for (int d = 0; d < 3; ++d) {
+                long long kd;
+                if (g.index_f64) voxel_index_1d<true>(g, d, p[d], kd);
+                else voxel_index_1d<false>(g, d, p[d], kd);
+                k[d] = (int)kd;
+            }
+        }
+    }
+    const unsigned flat = (unsigned)((k[0] * g.shape[1] + k[1]) * g.shape[2] + k[2]);
+    const unsigned last = (unsigned)(g.shape[0] * g.shape[1] * g.shape[2] - 1);
+    return (int)(flat < last ? flat : last);
+}
+
 template <bool F64>
 PVAMD_DEV int voxel_flat_in_range(const pvamd_grid_t& g, float x, float y, float z) {
     int kx = voxel_index_fast<F64>(g, 0, x), ky = voxel_index_fast<F64>(g, 1, y), kz = voxel_index_fast<F64>(g, 2, z);

@@ -600,10 +600,17 @@ class ComposedSDF(ObjectFrameSDF):
     def _leaf_grids(self, dev):
         key = tuple((id(s), s._packed.data_ptr()) for s in self.sdfs) + (str(dev),)
         if self._grids_dev is None or self._grids_key != key:
-            descs = (_lib.GridDesc * len(self.sdfs))(*[s._grid_desc() for s in self.sdfs])
+            host = [s._grid_desc() for s in self.sdfs]
+            descs = (_lib.GridDesc * len(self.sdfs))(*host)
             raw = torch.frombuffer(bytearray(bytes(descs)), dtype=torch.uint8)
             self._grids_dev = raw.to(dev)
             self._grids_key = key
+            # tuning hint (never changes a result, include/pvamd.h).  Grids that fit the 4 MB L2 of an XCD make the kernel
+            # instruction-bound: keep the exact-division fallback out of its hot loop (flagged points are redone after
+            # it).  Larger grids make it gather-bound and, with their larger coordinate / resolution ratios, flag far more
+            # visits (21 MB README-size link grids: 22 % of the wave passes): the inline fallback is cheaper there.
+            grid_bytes = sum(int(s._packed.numel()) * 4 for s in {id(s): s for s in self.sdfs}.values())
+            self._query_flags = _lib.COMPOSED_INLINE_EXACT if grid_bytes > (4 << 20) else 0
         return self._grids_dev
 
     def _tf_device(self, dev):
@@ -630,9 +637,10 @@ class ComposedSDF(ObjectFrameSDF):
             val = torch.empty((A, P), dtype=torch.float32, device=dev)
             grad = torch.empty((A, P, 3), dtype=torch.float32, device=dev)
             with _lib.on_device(dev):
-                _lib.check(lib.pvamd_composed_query(_lib.ptr(self._leaf_grids(dev)), S, _lib.ptr(self._tf_device(dev)),
+                grids = self._leaf_grids(dev)
+                _lib.check(lib.pvamd_composed_query(_lib.ptr(grids), S, _lib.ptr(self._tf_device(dev)),
                                                     A, _lib.ptr(flat), P, _lib.ptr(val), _lib.ptr(grad), None,
-                                                    _lib.stream_ptr()), "pvamd_composed_query")
+                                                    self._query_flags, _lib.stream_ptr()), "pvamd_composed_query")
         else:
             val, grad = self._generic(flat, S, A)
         if self.tsf_batch is not None:
@@ -660,9 +668,11 @@ class ComposedSDF(ObjectFrameSDF):
             raise _lib.PvamdError(f"query_into: the leaf grids live on {self._owner_device()}; points / outputs are on "
                                   f"{dev} / {out_val.device} / {out_grad.device}")
         with _lib.on_device(dev):
-            _lib.check(_lib.load().pvamd_composed_query(_lib.ptr(self._leaf_grids(dev)), len(self.sdfs),
+            grids = self._leaf_grids(dev)
+            _lib.check(_lib.load().pvamd_composed_query(_lib.ptr(grids), len(self.sdfs),
                                                         _lib.ptr(self._tf_device(dev)), A, _lib.ptr(points), P,
-                                                        _lib.ptr(out_val), _lib.ptr(out_grad), None, _lib.stream_ptr()),
+                                                        _lib.ptr(out_val), _lib.ptr(out_grad), None, self._query_flags,
+                                                        _lib.stream_ptr()),
                        "pvamd_composed_query")
 
     def _generic(self, flat, S, A):

@@ -187,3 +187,34 @@ def test_compose_of_mesh_sdfs_like_the_reference_test():
     expect = torch.minimum(v1, v2)
     assert torch.allclose(vals, expect, atol=1e-6)
     assert torch.allclose(grads, torch.where((v2 < v1).unsqueeze(-1), g2, g1), atol=1e-5)
+
+
+@pytest.mark.parametrize("flags", [0, 1])
+def test_both_index_modes_give_the_reference_index_where_the_estimate_is_shaky(flags):
+    """pvamd_composed_query's tuning hint (redo flagged points after the loop / exact statements inline) must never
+    change a result.  A leaf far from its own origin (coordinates ~200 x the resolution -> a wide error bound on the
+    fp32 index estimate) and query points sprayed on its half-voxel planes make flagged visits the rule."""
+    gt = H.AnalyticEllipsoidSDF([7.0, -5.0, 3.0], [0.3, 0.2, 0.25], [[6.7, 7.3], [-5.2, -4.8], [2.75, 3.25]])
+    rng = [(6.5, 7.5), (-5.5, -4.5), (2.5, 3.5)]
+    leaves = [pv.CachedSDF(f"far{i}", 0.02, np.array(rng) if i % 2 == 0 else rng, gt, device="cuda", cache_path=None)
+              for i in range(4)]
+    S, A = 4, 24
+    tfm = H.random_rigid(S * A, seed=11, trans=0.2)
+    comp = pv.ComposedSDF(leaves, None)
+    comp.set_transforms(pv.Transform3d(matrix=tfm), batch_dim=(A,))
+    v = leaves[0]._view
+    g = np.random.default_rng(5)
+    n = 1 << 15
+    k = g.integers(0, np.array(v.shape) - 1, size=(n, 3))
+    on_plane = v.dmin.numpy() + (k + 0.5) * v.dres.numpy() + g.normal(scale=2e-6, size=(n, 3))
+    # bring the leaf-frame targets back to the object frame of leaf (s = i mod S, a = 0) so that they land on the planes
+    inv = tf_inv = torch.linalg.inv(tfm.reshape(S, A, 4, 4)[:, 0].double()).numpy()
+    pts = np.stack([inv[i % S, :3, :3] @ on_plane[i] + inv[i % S, :3, 3] for i in range(n)]).astype(np.float32)
+    pts = torch.from_numpy(pts)
+    dev = torch.device("cuda", torch.cuda.current_device())
+    comp._leaf_grids(dev)
+    comp._query_flags = flags
+    val, grad = comp(pts.cuda())
+    oval, ograd, _ = oracle.composed_query([H.oracle_grid_from_cached(l) for l in leaves], tfm.numpy(), A, pts.numpy())
+    assert np.array_equal(val.cpu().numpy(), oval, equal_nan=True)
+    assert np.array_equal(grad.cpu().numpy(), ograd, equal_nan=True)
