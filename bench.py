@@ -232,17 +232,29 @@ def leg_c4(torch, dist, Wk, pv, timer, rank, world, steps, padding, with_gather,
     val = torch.empty((A, n), dtype=torch.float32, device="cuda")
     grad = torch.empty((A, n, 3), dtype=torch.float32, device="cuda")
 
-    def sharded_steps():
-        for _ in range(steps):
+    # 100 KB link grids: the allocation-free entry (query_into, what a planner loop would call).  README-size grids: the
+    # drop-in call robot(points), which sorts the shared point set once per call and un-permutes (ComposedSDF.bucket_points)
+    bucketed = robot.sdf._bucketing_pays(A, n)
+    if bucketed:
+        def one_step():
+            return robot(mine)
+    else:
+        def one_step():
             robot.query_into(mine, val, grad)
 
+    def sharded_steps():
+        for _ in range(steps):
+            one_step()
+
     for _ in range(3):
-        robot.query_into(mine, val, grad)
+        one_step()
     t = timer(sharded_steps)
     pairs = A * P * steps
     out = {"config": f"C4: RobotSDF 8 links, link grids res 0.02 padding {padding}, A={A} x P={P}, points sharded x{world}",
            "scaling": "strong", "n_gpus": world, "steps": steps, "unit": "(configuration, point) pairs/s",
            "link_grid_voxels": [int(s._packed.shape[0]) for s in robot.sdf.sdfs],
+           "call": "robot(points): Morton-bucketed fused kernel + un-permute, output allocation included" if bucketed
+                   else "robot.query_into(points, val, grad): fused kernel, caller's buffers",
            "sharded": {"gather": False, "value": pairs / t, "ms_per_step": t / steps * 1e3,
                        "roofline": {"bound": "hbm", "achieved": BYTES_PER_PAIR_C4 * pairs / t / 1e9, "peak": HBM_PEAK_GBS * world,
                                     "unit": "GB/s", "frac": BYTES_PER_PAIR_C4 * pairs / t / 1e9 / (HBM_PEAK_GBS * world),

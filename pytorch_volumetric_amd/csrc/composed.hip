@@ -260,7 +260,7 @@ constexpr int kTilePoints = 256;
 #define PVAMD_COMPOSED_MINWAVES 8
 #endif
 
-template <int PPP, int MODE>
+template <int PPP, int MODE, bool PACKED>
 __global__ __launch_bounds__(kWavesPerBlock * 64, MODE == kEstimate ? PVAMD_COMPOSED_MINWAVES : 1) void composed_query_wave(const pvamd_grid_t* __restrict__ grids, int S,
                                                                            const float* __restrict__ tf, int A,
                                                                            const f32x4* __restrict__ pts4,
@@ -274,11 +274,14 @@ __global__ __launch_bounds__(kWavesPerBlock * 64, MODE == kEstimate ? PVAMD_COMP
     float* spf = lds[wave];
     f32x4_alias* sp = reinterpret_cast<f32x4_alias*>(spf);
     float* svf = spf + 768;
-    const int a = a0 + blockIdx.y;
+    // blockIdx.x = configuration (fastest), blockIdx.y = tile block: the A configurations of one group of tiles run
+    // back to back, so the leaf-grid region that tile touches (it moves little between configurations) and the tile's
+    // points stay in L2 -- what matters once the grids are far larger than L2 (README-size link grids)
+    const int a = a0 + blockIdx.x;
     build_cull_spheres(grids, S, tf, A, a, cull);
     __syncthreads();
-    const int64_t wstride = (int64_t)gridDim.x * kWavesPerBlock;
-    for (int64_t tile = (int64_t)blockIdx.x * kWavesPerBlock + wave; tile < ntiles; tile += wstride) {
+    const int64_t wstride = (int64_t)gridDim.y * kWavesPerBlock;
+    for (int64_t tile = (int64_t)blockIdx.y * kWavesPerBlock + wave; tile < ntiles; tile += wstride) {
         const f32x4* src = pts4 + tile * 192;  // re-read for every configuration: L2-resident
         sp[lane] = src[lane];
         sp[lane + 64] = src[lane + 64];
@@ -350,14 +353,22 @@ __global__ __launch_bounds__(kWavesPerBlock * 64, MODE == kEstimate ? PVAMD_COMP
                 const float* M = tf + 16 * ((int64_t)s_win * A + a);
                 float gx, gy, gz;
                 rotate_back(M, best[k], gx, gy, gz);
-                svf[p] = best[k].v;  // a lane overwrites only the LDS slots of the points it owns
-                spf[3 * p] = gx;
-                spf[3 * p + 1] = gy;
-                spf[3 * p + 2] = gz;
+                if constexpr (PACKED) {
+                    // one (val, gx, gy, gz) record per point, in processing order: lanes hold consecutive points, so the
+                    // wave's store is a contiguous 1 KB as it is; plain stores -- the un-permute pass reads them back
+                    // from L2 / Infinity Cache right away
+                    reinterpret_cast<f32x4*>(val)[(int64_t)a * P + tile * kTilePoints + p] = f32x4{best[k].v, gx, gy, gz};
+                } else {
+                    svf[p] = best[k].v;  // a lane overwrites only the LDS slots of the points it owns
+                    spf[3 * p] = gx;
+                    spf[3 * p + 1] = gy;
+                    spf[3 * p + 2] = gz;
+                }
                 if (leaf) leaf[(int64_t)a * P + tile * kTilePoints + p] = s_win;
             }
         }
         PVAMD_WAVE_SYNC();
+        if constexpr (PACKED) continue;
         const int64_t o = (int64_t)a * P + tile * kTilePoints;  // multiple of 4: rows start 16-byte aligned
         __builtin_nontemporal_store(sp[192 + lane], reinterpret_cast<f32x4*>(val + o) + lane);
         f32x4* dst = reinterpret_cast<f32x4*>(grad + 3 * o);
@@ -400,9 +411,103 @@ __global__ __launch_bounds__(256) void composed_query_scalar(const pvamd_grid_t*
     }
 }
 
+// ---- bucketed path: un-permute ----
+// The kernel above ran on spatially sorted points and left one packed record per (configuration, sorted position);
+// this pass brings them back to the caller's point order: out[a][j] = packed[a][inv[j]].  One wave = 256 consecutive
+// caller points of one configuration: 4 gathers of a 16-byte record per lane (a configuration's records are a 4 MB
+// window that was written moments ago), results staged through the wave's LDS slice and written as 1 + 3 contiguous
+// 1 KB stores like everywhere else.  Blocks of one configuration are kept on one XCD (block b runs on XCD b % 8) so that
+// the window is pulled into ONE L2 instead of eight.
+__global__ __launch_bounds__(kWavesPerBlock * 64) void composed_unpermute_kernel(const f32x4* __restrict__ packed,
+                                                                                 const int* __restrict__ inv, int64_t P,
+                                                                                 int64_t Pp, int A, int64_t tile_blocks,
+                                                                                 float* __restrict__ val,
+                                                                                 float* __restrict__ grad) {
+    __shared__ __attribute__((aligned(16))) float lds[kWavesPerBlock][1024];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    float* spf = lds[wave];
+    f32x4_alias* sp = reinterpret_cast<f32x4_alias*>(spf);
+    float* svf = spf + 768;
+    // b -> (configuration, tile block): eight consecutive blocks go to the eight XCDs and carry eight different
+    // configurations; the next eight continue the same configurations with the next tile block
+    const int64_t b = blockIdx.x;
+    const int64_t group = b / (8 * tile_blocks), within = b % (8 * tile_blocks);
+    const int a = (int)(group * 8 + within % 8);
+    if (a >= A) return;
+    const int64_t tile = (within / 8) * kWavesPerBlock + wave;
+    if (tile * kTilePoints >= P) return;
+    const f32x4* src = packed + (int64_t)a * Pp;
+    const int64_t j0 = tile * kTilePoints;
+    const bool full = (j0 + kTilePoints <= P) && (P % 4 == 0);
+    f32x4 r[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int64_t j = j0 + lane + 64 * k;
+        r[k] = j < P ? src[inv[j]] : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    const int64_t o = (int64_t)a * P + j0;
+    if (full) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int p = lane + 64 * k;
+            svf[p] = r[k].x;
+            spf[3 * p] = r[k].y;
+            spf[3 * p + 1] = r[k].z;
+            spf[3 * p + 2] = r[k].w;
+        }
+        PVAMD_WAVE_SYNC();
+        __builtin_nontemporal_store(sp[192 + lane], reinterpret_cast<f32x4*>(val + o) + lane);
+        f32x4* dst = reinterpret_cast<f32x4*>(grad + 3 * o);
+        __builtin_nontemporal_store(sp[lane], dst + lane);
+        __builtin_nontemporal_store(sp[lane + 64], dst + lane + 64);
+        __builtin_nontemporal_store(sp[lane + 128], dst + lane + 128);
+    } else {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int64_t j = j0 + lane + 64 * k;
+            if (j < P) {
+                val[(int64_t)a * P + j] = r[k].x;
+                float* g = grad + 3 * ((int64_t)a * P + j);
+                g[0] = r[k].y;
+                g[1] = r[k].z;
+                g[2] = r[k].w;
+            }
+        }
+    }
+}
+
 }  // namespace pvamd
 
 using namespace pvamd;
+
+extern "C" int pvamd_composed_query_bucketed(const pvamd_grid_t* grids, int32_t S, const float* tf, int32_t A,
+                                             const float* sorted_points, const int32_t* inv, int64_t P, int64_t Pp,
+                                             float* scratch, float* out_val, float* out_grad, int32_t flags,
+                                             void* stream) {
+    if (S < 1 || A < 1 || P < 1 || Pp < P || Pp % kTilePoints != 0 || S >= kUnnormalised) return PVAMD_E_SHAPE;
+    if (!grids || !tf || !sorted_points || !inv || !scratch || !out_val || !out_grad) return PVAMD_E_NULL;
+    if (!aligned_to(grids, 8) || !aligned_to(tf, 4) || !aligned_to(sorted_points, 16) || !aligned_to(scratch, 16) ||
+        !aligned_to(inv, 4) || !aligned_to(out_val, 16) || !aligned_to(out_grad, 16))
+        return PVAMD_E_ALIGN;
+    hipStream_t s = (hipStream_t)stream;
+    const int64_t ntiles = Pp / kTilePoints;
+    const int64_t tile_blocks = (ntiles + kWavesPerBlock - 1) / kWavesPerBlock;
+    constexpr int kSlab = 65535;  // gridDim.y of the query kernel = tile blocks
+    if (tile_blocks > kSlab) return PVAMD_E_SHAPE;  // > 67 M points per call: use the direct entry point
+    const f32x4* p4 = reinterpret_cast<const f32x4*>(sorted_points);
+    if (flags & PVAMD_COMPOSED_INLINE_EXACT)
+        hipLaunchKernelGGL((composed_query_wave<PVAMD_COMPOSED_PPP, kInlineExact, true>), dim3(A, (unsigned)tile_blocks),
+                           dim3(kWavesPerBlock * 64), 0, s, grids, S, tf, A, p4, ntiles, Pp, scratch, nullptr, nullptr, 0);
+    else
+        hipLaunchKernelGGL((composed_query_wave<PVAMD_COMPOSED_PPP, kEstimate, true>), dim3(A, (unsigned)tile_blocks),
+                           dim3(kWavesPerBlock * 64), 0, s, grids, S, tf, A, p4, ntiles, Pp, scratch, nullptr, nullptr, 0);
+    const int64_t groups = ((int64_t)A + 7) / 8;
+    const int64_t blocks = groups * 8 * tile_blocks;
+    if (blocks > 0x7fffffffLL) return PVAMD_E_SHAPE;
+    hipLaunchKernelGGL(composed_unpermute_kernel, dim3((unsigned)blocks), dim3(kWavesPerBlock * 64), 0, s,
+                       reinterpret_cast<const f32x4*>(scratch), inv, P, Pp, A, tile_blocks, out_val, out_grad);
+    return (int)hipGetLastError();
+}
 
 extern "C" int pvamd_composed_query(const pvamd_grid_t* grids, int32_t S, const float* tf, int32_t A,
                                     const float* points, int64_t P, float* out_val, float* out_grad,
@@ -428,15 +533,16 @@ extern "C" int pvamd_composed_query(const pvamd_grid_t* grids, int32_t S, const 
     constexpr int kSlab = 65535;
     for (int a0 = 0; a0 < A; a0 += kSlab) {
         const int An = A - a0 < kSlab ? A - a0 : kSlab;
-        const int64_t cap = ((int64_t)65536 + An - 1) / An;
+        int64_t cap = ((int64_t)65536 + An - 1) / An;
+        if (cap > 65535) cap = 65535;  // gridDim.y
         if (ntiles > 0) {
             const int64_t need = (ntiles + kWavesPerBlock - 1) / kWavesPerBlock;
             const unsigned gx = (unsigned)(need < cap ? need : (cap < 1 ? 1 : cap));
             if (flags & PVAMD_COMPOSED_INLINE_EXACT)
-                hipLaunchKernelGGL((composed_query_wave<PVAMD_COMPOSED_PPP, kInlineExact>), dim3(gx, An), dim3(kWavesPerBlock * 64), 0, s,
+                hipLaunchKernelGGL((composed_query_wave<PVAMD_COMPOSED_PPP, kInlineExact, false>), dim3(An, gx), dim3(kWavesPerBlock * 64), 0, s,
                                    grids, S, tf, A, reinterpret_cast<const f32x4*>(points), ntiles, P, out_val, out_grad, out_leaf, a0);
             else
-                hipLaunchKernelGGL((composed_query_wave<PVAMD_COMPOSED_PPP, kEstimate>), dim3(gx, An), dim3(kWavesPerBlock * 64), 0, s,
+                hipLaunchKernelGGL((composed_query_wave<PVAMD_COMPOSED_PPP, kEstimate, false>), dim3(An, gx), dim3(kWavesPerBlock * 64), 0, s,
                                    grids, S, tf, A, reinterpret_cast<const f32x4*>(points), ntiles, P, out_val, out_grad, out_leaf, a0);
         }
         const int64_t first = ntiles * kTilePoints;

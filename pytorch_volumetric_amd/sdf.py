@@ -590,6 +590,18 @@ class ComposedSDF(ObjectFrameSDF):
             isinstance(s, CachedSDF) and s.out_of_bounds_strategy == OutOfBoundsStrategy.BOUNDING_BOX
             for s in self.sdfs)
 
+    bucket_points = "auto"  # True / False / "auto": sort the query points spatially before the fused kernel (see __call__)
+
+    def _bucketing_pays(self, A, P):
+        """Sorting the points costs a sort + a second pass over the outputs (~0.5 ms for 200 x 262,144); it pays when
+        the leaf grids are far larger than L2, so that gather locality decides the time, and the sort is shared by enough
+        configurations.  Measured on the README-size robot (8 x 21 MB grids, A = 200, P = 262,144 random points):
+        4.9 ms direct, 1.6 ms bucketed; with 100 KB grids the kernel is instruction-bound and bucketing only adds its
+        overhead (0.82 -> 1.1 ms).  Spatially ordered input (grids, slices) needs no sort: pass bucket_points = False."""
+        if self.bucket_points != "auto":
+            return bool(self.bucket_points) and P >= 256
+        return self._query_flags == _lib.COMPOSED_INLINE_EXACT and A >= 8 and P >= 32768 and A * P * 16 <= (8 << 30)
+
     def _owner_device(self):
         """The one GPU every leaf grid lives on (the fused kernel reads all of them through raw pointers)."""
         devs = {s._packed.device for s in self.sdfs}
@@ -638,9 +650,23 @@ class ComposedSDF(ObjectFrameSDF):
             grad = torch.empty((A, P, 3), dtype=torch.float32, device=dev)
             with _lib.on_device(dev):
                 grids = self._leaf_grids(dev)
-                _lib.check(lib.pvamd_composed_query(_lib.ptr(grids), S, _lib.ptr(self._tf_device(dev)),
-                                                    A, _lib.ptr(flat), P, _lib.ptr(val), _lib.ptr(grad), None,
-                                                    self._query_flags, _lib.stream_ptr()), "pvamd_composed_query")
+                if self._bucketing_pays(A, P):
+                    # one Morton sort of the shared point set, amortised over the A configurations; the kernel then
+                    # sees spatially compact wave tiles and a second pass restores the caller's point order
+                    order = _lib.morton_order(flat, min_points=0).long()
+                    Pp = -(-P // 256) * 256
+                    inv = torch.empty((P,), dtype=torch.int32, device=dev)
+                    inv[order] = torch.arange(P, dtype=torch.int32, device=dev)
+                    spts = flat[torch.cat((order, order[-1:].expand(Pp - P)))].contiguous()
+                    scratch = torch.empty((A, Pp, 4), dtype=torch.float32, device=dev)
+                    _lib.check(lib.pvamd_composed_query_bucketed(_lib.ptr(grids), S, _lib.ptr(self._tf_device(dev)), A,
+                                                                 _lib.ptr(spts), _lib.ptr(inv), P, Pp, _lib.ptr(scratch),
+                                                                 _lib.ptr(val), _lib.ptr(grad), self._query_flags,
+                                                                 _lib.stream_ptr()), "pvamd_composed_query_bucketed")
+                else:
+                    _lib.check(lib.pvamd_composed_query(_lib.ptr(grids), S, _lib.ptr(self._tf_device(dev)),
+                                                        A, _lib.ptr(flat), P, _lib.ptr(val), _lib.ptr(grad), None,
+                                                        self._query_flags, _lib.stream_ptr()), "pvamd_composed_query")
         else:
             val, grad = self._generic(flat, S, A)
         if self.tsf_batch is not None:

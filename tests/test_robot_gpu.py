@@ -211,3 +211,51 @@ def test_full_size_c4_properties(tmp_path):
     assert np.array_equal(val[sel, :20_000].cpu().numpy(), ov, equal_nan=True)
     assert np.array_equal(grad[sel, :20_000].cpu().numpy(), og, equal_nan=True)
     assert (val < 0).any()  # some points are inside the arm
+
+
+def test_readme_size_link_grids_match_oracle_bitwise():
+    """C4 at the reference README's setting (README.md:150-151, tests/test_model_to_sdf.py:182): link caches at
+    resolution 0.02 with padding=1.0 -> ~1.3 M voxels (21 MB) per link, 170 MB in total, every workspace point inside
+    every link's range.  The fused kernel (large-grid mode: inline exact index fallback) vs the oracle on a slice of
+    configurations x points, bit for bit, plus the small-grid mode forced on the same scene."""
+    import workloads as Wk
+    robot = Wk.build_c4(resolution=0.02, padding=1.0)
+    leaves = robot.sdf.sdfs
+    assert all(l._packed.shape[0] > 1_000_000 for l in leaves)
+    A, P = 6, 20_480
+    robot.set_joint_configuration(Wk.c4_joint_configs(A, seed=3))
+    pts = Wk.c4_points(P, seed=4)
+    val, grad = robot(pts)
+    assert val.shape == (A, P) and robot.sdf._query_flags == pv._lib.COMPOSED_INLINE_EXACT
+    tfm = robot.object_to_link_frames.get_matrix().cpu().numpy()
+    ogrids = [H.oracle_grid_from_cached(l) for l in leaves]
+    oval, ograd, oleaf = oracle.composed_query(ogrids, tfm, A, pts.cpu().numpy())
+    assert np.array_equal(val.cpu().numpy(), oval, equal_nan=True)
+    assert np.array_equal(grad.cpu().numpy(), ograd, equal_nan=True)
+    assert len(np.unique(oleaf)) == 8  # every link wins somewhere
+    inr = np.mean([l.voxels.get_valid_values(pts).float().mean().item() for l in leaves[:1]])
+    assert inr > 0.7  # the regime: most points are inside the padded range of every link
+    robot.sdf._query_flags = 0  # the other index mode: same bits
+    v0, g0 = robot(pts)
+    assert torch.equal(v0, val) and torch.equal(g0.nan_to_num(5.0), grad.nan_to_num(5.0))
+
+
+@pytest.mark.parametrize("P", [20_480, 20_481, 777])
+def test_bucketed_path_returns_the_direct_path_bits_in_caller_order(P):
+    """ComposedSDF.bucket_points: Morton-sort the shared point set, run the fused kernel on the sorted points, un-permute
+    (pvamd_composed_query_bucketed).  Same bits as the direct path, in the caller's order, for point counts that are and
+    are not multiples of the tile / vector widths, on both grid sizes (= both index modes)."""
+    import workloads as Wk
+    for padding in (0.1, 1.0):
+        robot = Wk.build_c4(resolution=0.02, padding=padding)
+        A = 9
+        robot.set_joint_configuration(Wk.c4_joint_configs(A, seed=5))
+        pts = Wk.c4_points(P, seed=6)
+        robot.sdf.bucket_points = False
+        v_direct, g_direct = robot(pts)
+        robot.sdf.bucket_points = True
+        v_b, g_b = robot(pts)
+        assert v_b.shape == (A, P) and g_b.shape == (A, P, 3)
+        assert torch.equal(v_b, v_direct) and torch.equal(g_b.nan_to_num(4.0), g_direct.nan_to_num(4.0))
+    robot.sdf.bucket_points = "auto"
+    assert robot.sdf._bucketing_pays(200, 1 << 18) and not robot.sdf._bucketing_pays(2, 1 << 18)
