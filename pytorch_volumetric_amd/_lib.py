@@ -120,6 +120,8 @@ SIGNATURES = {
     "pvamd_points_aabb": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p]),
     "pvamd_morton_keys": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p,
                                          ctypes.c_void_p]),
+    "pvamd_morton_order": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p,
+                                          ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]),
     "pvamd_mesh_prepare": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int32, ctypes.c_float,
                                           ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]),
     "pvamd_mesh_query": (ctypes.c_int, [ctypes.POINTER(MeshDesc), ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64,
@@ -249,15 +251,24 @@ def as_query_points(points, device=None, keep_f64=False):
     return flat, lead, points.dtype if points.dtype.is_floating_point else torch.float32, points.device
 
 
-def morton_order(points, min_points=2048):
+def morton_order_scratch_words(P):
+    """PVAMD_MORTON_ORDER_SCRATCH_BYTES(P) / 4"""
+    return 8 + (1 << (18 if P >= (1 << 20) else 15)) + P
+
+
+def morton_order(points, min_points=2048, want_inverse=False, want_sorted=False):
     """int32 permutation that walks fp32 [P,3] device points along a Z-order curve (None below `min_points`, where
-    sorting costs more than it saves).  Spatially coherent waves are what lets the mesh kernels skip far tiles.
-    Bounds + key kernels + one device sort; nothing comes back to the host."""
+    ordering costs more than it saves).  Spatially coherent waves are what lets the mesh kernels skip far tiles and the
+    bucketed composed kernel skip far leaves.  One C-ABI call (pvamd_morton_order: a five-launch counting sort on Morton
+    cells); nothing comes back to the host.  With want_inverse / want_sorted: (order, inverse, sorted points)."""
     P = points.shape[0]
-    if P < min_points:
-        return None
-    box = torch.empty((2, 3), dtype=torch.float32, device=points.device)
-    keys = torch.empty((P,), dtype=torch.int32, device=points.device)
-    check(load().pvamd_points_aabb(ptr(points), P, ptr(box), stream_ptr()), "pvamd_points_aabb")
-    check(load().pvamd_morton_keys(ptr(points), P, ptr(box), ptr(keys), stream_ptr()), "pvamd_morton_keys")
-    return torch.argsort(keys).to(torch.int32)
+    if P < min_points or P == 0:
+        return (None, None, None) if (want_inverse or want_sorted) else None
+    dev = points.device
+    order = torch.empty((P,), dtype=torch.int32, device=dev)
+    inv = torch.empty((P,), dtype=torch.int32, device=dev) if want_inverse else None
+    spts = torch.empty((P, 3), dtype=torch.float32, device=dev) if want_sorted else None
+    scratch = torch.empty((morton_order_scratch_words(P),), dtype=torch.int32, device=dev)
+    check(load().pvamd_morton_order(ptr(points), P, ptr(order), ptr(inv), ptr(spts), ptr(scratch), stream_ptr()),
+          "pvamd_morton_order")
+    return (order, inv, spts) if (want_inverse or want_sorted) else order

@@ -288,7 +288,12 @@ __global__ __launch_bounds__(kWavesPerBlock * 64, MODE == kEstimate ? PVAMD_COMP
         sp[lane + 128] = src[lane + 128];
         PVAMD_WAVE_SYNC();
         float lower;
+#ifdef PVAMD_NO_TILE_MASK
+        lower = -__builtin_inff();
+        const uint64_t todo = S >= 64 ? ~0ull : ((1ull << S) - 1ull);
+#else
         const uint64_t todo = tile_leaf_mask(cull, S, lane, spf, lower);
+#endif
         const int first_leaf = todo ? __builtin_ctzll(todo) : 0;
         // A tile compact enough for the static test to drop a leaf is worth re-testing as the minimum tightens: after
         // every visited leaf the wave's largest running minimum is an upper bound of every point's final value, and the
@@ -520,10 +525,14 @@ extern "C" int pvamd_composed_query(const pvamd_grid_t* grids, int32_t S, const 
     const bool vec_ok = (P % 4 == 0) && aligned_to(points, 16) && aligned_to(out_val, 16) && aligned_to(out_grad, 16);
     // The leaf descriptors live in device memory; whether any of them asks for float64 index arithmetic is not
     // known host-side, so the kernels are built for the general case and test the (wave-uniform) flag per leaf.
-    // The wave-tile kernel walks 4 points per lane one after the other: it wins once there are enough 256-point tiles to
-    // fill the chip (1024 SIMDs x a few waves); below that the one-point-per-lane kernel has 4x the parallelism and a
-    // quarter of the latency (100k points x 8 leaves: 36 -> see profiles/ latency numbers).
-    const bool enough = vec_ok && (P / kTilePoints) * (int64_t)A >= 4096;
+    // Two kernels.  The wave-tile kernel (256 points per wave through LDS, per-tile leaf mask, configuration-fastest block
+    // order) is the one that scales with configurations and exploits coherent points; the one-point-per-lane kernel has
+    // 4x the parallelism, no per-tile overhead, and 44 VGPRs (8 waves per SIMD without spills).  Measured (tools/
+    // scalar_probe.py, ms, wave-tile | one-point-per-lane): C3 4M random 0.106 | 0.095, C3 Morton-sorted 0.064 | 0.074,
+    // C4 200 x 262k random 0.85 | 0.97, sorted 0.60 | 0.82, README-size grids 4.9 | 6.4 and 1.0 | 2.6.  So: a single
+    // configuration, or too few tiles to fill the chip (100k points x 8 leaves: 36 -> 17 us), takes the per-lane kernel.
+    // (flags bit 1, undocumented: force the per-lane kernel -- tools/scalar_probe.py.)
+    const bool enough = vec_ok && A >= 2 && (P / kTilePoints) * (int64_t)A >= 4096 && !(flags & 2);
     const int64_t ntiles = enough ? P / kTilePoints : 0;
     // up to ~65536 blocks in total, split over the A configurations: about one 256-point tile per wave.  (Sweep on C4,
     // 200 x 262,144: 1024 blocks 1.40 ms, 4096 1.17, 8192 1.13, 32768 1.09, 65536 1.08 -- the hardware dispatcher

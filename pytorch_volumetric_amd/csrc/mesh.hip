@@ -16,6 +16,7 @@
 //   * ties in d^2 resolve to the lowest ORIGINAL face id (lexicographic min), independent of processing order.
 #include "common.h"
 #include "mesh_math.h"
+#include "morton.h"
 
 namespace pvamd {
 
@@ -687,37 +688,18 @@ __global__ __launch_bounds__(64 * SLICES) void chamfer_mesh_kernel(MeshArgs m, c
     if (lane == 0) atomicAdd(out_sum + blockIdx.y, acc);
 }
 
-// Z-order key of each point inside the box [lo, hi] (device [2][3]): 3 x 10 bits, interleaved.  Sorting queries by it
-// makes the 64 points of a wave neighbours in space, which is what the tile culling feeds on.
+// Z-order key of each point inside the box [lo, hi] (device [2][3]).  Sorting queries by it makes the 64 points of a
+// wave neighbours in space, which is what the tile culling feeds on.
 __global__ __launch_bounds__(256) void morton_keys_kernel(const float* __restrict__ pts, int64_t P,
                                                           const float* __restrict__ box, int* __restrict__ keys) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= P) return;
-    unsigned key = 0;
-#pragma unroll
-    for (int d = 0; d < 3; ++d) {
-        const float lo = box[d], hi = box[3 + d];
-        float t = (pts[3 * i + d] - lo) / fmaxf(hi - lo, 1e-30f) * 1023.f;
-        t = fminf(fmaxf(t, 0.f), 1023.f);  // NaN -> 0
-        unsigned c = (unsigned)t;
-        c = (c | (c << 16)) & 0x030000FFu;  // spread 10 bits to every third position
-        c = (c | (c << 8)) & 0x0300F00Fu;
-        c = (c | (c << 4)) & 0x030C30C3u;
-        c = (c | (c << 2)) & 0x09249249u;
-        key |= c << d;
-    }
-    keys[i] = (int)key;
+    const float lo[3] = {box[0], box[1], box[2]}, hi[3] = {box[3], box[4], box[5]};
+    keys[i] = (int)morton_key30(pts[3 * i], pts[3 * i + 1], pts[3 * i + 2], lo, hi);
 }
 
-// axis-aligned bounds of the finite coordinates of a point set, for the Morton keys.  Floats are folded through an
-// order-preserving map to uint32 so that atomicMin/atomicMax work; box holds the codes until aabb_decode_kernel.
-PVAMD_DEV unsigned order_code(float f) {
-    const unsigned b = (unsigned)__float_as_int(f);
-    return (b & 0x80000000u) ? ~b : (b | 0x80000000u);
-}
-PVAMD_DEV float order_decode(unsigned c) {
-    return __int_as_float((int)((c & 0x80000000u) ? (c & 0x7fffffffu) : ~c));
-}
+// axis-aligned bounds of the finite coordinates of a point set, for the Morton keys (order_code: morton.h); box holds
+// the codes until aabb_decode_kernel.
 __global__ void aabb_init_kernel(unsigned* box) {
     if (threadIdx.x < 3) box[threadIdx.x] = order_code(INFINITY);
     else if (threadIdx.x < 6) box[threadIdx.x] = order_code(-INFINITY);

@@ -600,6 +600,9 @@ class ComposedSDF(ObjectFrameSDF):
         overhead (0.82 -> 1.1 ms).  Spatially ordered input (grids, slices) needs no sort: pass bucket_points = False."""
         if self.bucket_points != "auto":
             return bool(self.bucket_points) and P >= 256
+        if not self._fusable():
+            return False
+        self._leaf_grids(self._owner_device())  # derives _query_flags from the grid sizes
         return self._query_flags == _lib.COMPOSED_INLINE_EXACT and A >= 8 and P >= 32768 and A * P * 16 <= (8 << 30)
 
     def _owner_device(self):
@@ -653,11 +656,10 @@ class ComposedSDF(ObjectFrameSDF):
                 if self._bucketing_pays(A, P):
                     # one Morton sort of the shared point set, amortised over the A configurations; the kernel then
                     # sees spatially compact wave tiles and a second pass restores the caller's point order
-                    order = _lib.morton_order(flat, min_points=0).long()
+                    _, inv, spts = _lib.morton_order(flat, min_points=0, want_inverse=True, want_sorted=True)
                     Pp = -(-P // 256) * 256
-                    inv = torch.empty((P,), dtype=torch.int32, device=dev)
-                    inv[order] = torch.arange(P, dtype=torch.int32, device=dev)
-                    spts = flat[torch.cat((order, order[-1:].expand(Pp - P)))].contiguous()
+                    if Pp != P:  # whole 256-point tiles: pad with copies of the last point (never read back)
+                        spts = torch.cat((spts, spts[-1:].expand(Pp - P, 3))).contiguous()
                     scratch = torch.empty((A, Pp, 4), dtype=torch.float32, device=dev)
                     _lib.check(lib.pvamd_composed_query_bucketed(_lib.ptr(grids), S, _lib.ptr(self._tf_device(dev)), A,
                                                                  _lib.ptr(spts), _lib.ptr(inv), P, Pp, _lib.ptr(scratch),

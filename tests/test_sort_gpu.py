@@ -1,0 +1,71 @@
+"""-m gpu: pvamd_morton_order, the five-launch counting sort that gives the mesh kernels and the bucketed composed path
+their spatial processing order (replaces torch.argsort of Morton keys)."""
+import numpy as np
+import pytest
+import torch
+
+import pytorch_volumetric_amd as pv
+from pytorch_volumetric_amd import _lib
+from tests import helpers as H
+
+pytestmark = pytest.mark.gpu
+
+
+def coarse_cells(pts, bits):
+    """Host restatement of the cell a point falls in: the leading `bits` bits of the 30-bit Morton key over the bounds of
+    the finite coordinates (csrc/morton.h)."""
+    p = pts.astype(np.float32)
+    fin = np.where(np.isfinite(p), p, np.nan)
+    lo, hi = np.nanmin(fin, axis=0).astype(np.float32), np.nanmax(fin, axis=0).astype(np.float32)
+    span = np.maximum((hi - lo).astype(np.float32), np.float32(1e-30))
+    with np.errstate(invalid="ignore"):
+        t = ((p - lo) / span * np.float32(1023.0)).astype(np.float32)
+    t = np.where(np.isnan(t), 0.0, np.clip(t, 0.0, 1023.0))
+    c = t.astype(np.uint32)
+    key = np.zeros(len(p), dtype=np.uint64)
+    for b in range(10):
+        for d in range(3):
+            key |= ((c[:, d].astype(np.uint64) >> b) & 1) << (3 * b + d)
+    return key >> (30 - bits)
+
+
+@pytest.mark.parametrize("P", [1, 5, 300, 10_000, 262_144, (1 << 20) + 77])
+def test_order_is_a_permutation_that_walks_the_cells_in_z_order(P):
+    pts = H.uniform_points(P, [-0.7, -0.7, -0.2], [0.7, 0.7, 1.5], seed=P).cuda()
+    order, inv, spts = _lib.morton_order(pts, min_points=0, want_inverse=True, want_sorted=True)
+    o = order.cpu().numpy()
+    assert np.array_equal(np.sort(o), np.arange(P))
+    assert np.array_equal(inv.cpu().numpy()[o], np.arange(P))
+    assert torch.equal(spts, pts[order.long()])
+    cells = coarse_cells(pts.cpu().numpy(), 18 if P >= (1 << 20) else 15)
+    walked = cells[o]
+    assert (np.diff(walked.astype(np.int64)) >= 0).all()  # cells in Z order; inside a cell any order
+
+
+def test_non_finite_points_are_placed_somewhere_and_nothing_else_moves():
+    pts = H.uniform_points(5000, [-1] * 3, [1] * 3, seed=1)
+    pts[7] = float("nan")
+    pts[11, 1] = float("inf")
+    pts[13, 2] = float("-inf")
+    order = _lib.morton_order(pts.cuda(), min_points=0).cpu().numpy()
+    assert np.array_equal(np.sort(order), np.arange(5000))
+
+
+def test_degenerate_clouds():
+    same = torch.ones(4096, 3).cuda() * 0.25  # zero extent: one cell
+    assert np.array_equal(np.sort(_lib.morton_order(same, min_points=0).cpu().numpy()), np.arange(4096))
+    line = torch.zeros(4096, 3)
+    line[:, 0] = torch.linspace(0, 1, 4096)
+    o = _lib.morton_order(line.cuda(), min_points=0).cpu().numpy()
+    assert np.array_equal(np.sort(o), np.arange(4096))
+    assert (np.diff(line[o, 0].numpy()) >= -1.0 / 31).all()  # monotone up to the cell size
+
+
+def test_mesh_query_bits_do_not_depend_on_the_processing_order():
+    """The order inside a cell is run-dependent; the mesh kernel's results are not."""
+    obj = pv.MeshObjectFactory(H.mesh_path("probe.obj"))
+    pts = H.uniform_points(30_000, [-0.05] * 3, [0.08] * 3, seed=2).cuda()
+    a = obj.object_frame_closest_point(pts, compute_normal=True)
+    b = obj.object_frame_closest_point(pts, compute_normal=True)
+    for x, y in zip(a, b):
+        assert torch.equal(x, y)

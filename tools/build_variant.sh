@@ -12,7 +12,7 @@ which=$(basename "$src" .hip); which=${which%%_*}
 extra=""; [ "$which" = composed ] && extra="-fno-slp-vectorize"   # as csrc/Makefile (FLAGS_composed)
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -fno-fast-math -ffp-contract=off -Wno-unused-value -I$C -Iinclude $extra "$@" -c "$src" -o tools/variants/${which}_$name.o
 objs=""
-for o in api cached composed mesh chamfer_grid xform fk voxelgrid sample; do
+for o in api cached composed mesh chamfer_grid xform fk voxelgrid sample sort; do
   if [ $o = $which ]; then objs="$objs tools/variants/${which}_$name.o"; else objs="$objs $C/$o.o"; fi
 done
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -o tools/variants/libpvamd_$name.so $objs
