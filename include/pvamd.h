@@ -221,14 +221,14 @@ int pvamd_points_aabb(const float* points, int64_t P, float* box_out, void* stre
  * keys_out: device [P] int32.                                                                                  */
 int pvamd_morton_keys(const float* points, int64_t P, const float* box, int32_t* keys_out, void* stream);
 
-/* A spatial processing order for a point set, in one call (bounds, Morton cell counts, scan, scatter: five small
+/* A spatial processing order for a point set, in one call (bounds, Morton cell counts, scan, scatter: seven small
  * launches instead of a general-purpose device sort): order_out[k] = index of the k-th point along a Z-order curve of
- * 32^3 cells over the points' bounding box (64^3 from a million points).  Points of one cell come out in an arbitrary,
+ * 16^3 cells over the points' bounding box up to 16 k points (one launch), 32^3 / 64^3 / 128^3 beyond 16 k / 64 k / 1 M.  Points of one cell come out in an arbitrary,
  * run-dependent order -- the kernels that take an `order` return the same bits for any order.
  * order_out: device [P] int32.  inv_out: device [P] int32 or NULL, inv[order[k]] = k.  sorted_points_out: device [P][3] or
  * NULL, the points in that order.  scratch: device, PVAMD_MORTON_ORDER_SCRATCH_BYTES(P) bytes, 4-byte aligned.          */
-#define PVAMD_MORTON_ORDER_BITS(P) ((P) >= (1 << 20) ? 18 : 15)
-#define PVAMD_MORTON_ORDER_SCRATCH_BYTES(P) (4 * (8 + (1 << PVAMD_MORTON_ORDER_BITS(P)) + (int64_t)(P)))
+#define PVAMD_MORTON_ORDER_BITS(P) ((P) >= (1 << 20) ? 21 : ((P) >= (1 << 16) ? 18 : 15))
+#define PVAMD_MORTON_ORDER_SCRATCH_BYTES(P) (4 * (8 + (1 << PVAMD_MORTON_ORDER_BITS(P)) + (int64_t)(P) + 2048))
 int pvamd_morton_order(const float* points, int64_t P, int32_t* order_out, int32_t* inv_out, float* sorted_points_out,
                        void* scratch, void* stream);
 

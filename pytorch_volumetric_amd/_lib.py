@@ -253,13 +253,13 @@ def as_query_points(points, device=None, keep_f64=False):
 
 def morton_order_scratch_words(P):
     """PVAMD_MORTON_ORDER_SCRATCH_BYTES(P) / 4"""
-    return 8 + (1 << (18 if P >= (1 << 20) else 15)) + P
+    return 8 + (1 << (21 if P >= (1 << 20) else (18 if P >= (1 << 16) else 15))) + P + 2048
 
 
 def morton_order(points, min_points=2048, want_inverse=False, want_sorted=False):
     """int32 permutation that walks fp32 [P,3] device points along a Z-order curve (None below `min_points`, where
     ordering costs more than it saves).  Spatially coherent waves are what lets the mesh kernels skip far tiles and the
-    bucketed composed kernel skip far leaves.  One C-ABI call (pvamd_morton_order: a five-launch counting sort on Morton
+    bucketed composed kernel skip far leaves.  One C-ABI call (pvamd_morton_order: a seven-launch counting sort on Morton
     cells); nothing comes back to the host.  With want_inverse / want_sorted: (order, inverse, sorted points)."""
     P = points.shape[0]
     if P < min_points or P == 0:

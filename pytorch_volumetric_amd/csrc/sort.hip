@@ -1,10 +1,12 @@
-// Spatial processing order of a point set in five small launches: bounds, Morton cell counts, scan, scatter.
+// Spatial processing order of a point set in seven small launches: bounds, Morton cell counts, scan (3), scatter.
 // Replaces `torch.argsort(morton keys)` (a ~10-launch rocprim radix sort, ~60 us for 10 k points and 0.14 ms for 262 k:
 // more than the mesh query of BASELINE C1 itself) in front of the mesh kernels and of the bucketed composed path.
 //
 // The kernels only need points that are neighbours in space to be neighbours in processing order, not a total order:
-// this is a COUNTING sort on the leading `bits` bits of the 30-bit Morton key (32^3 cells, 64^3 beyond a million
-// points).  Cells come out in Z order; the order of the points inside a cell is whatever the atomics make it -- it may
+// this is a COUNTING sort on the leading `bits` bits of the 30-bit Morton key (16^3 cells up to 16 k points -- one
+// workgroup does it all in LDS -- 32^3 up to 64 k, 64^3 up to
+// a million, 128^3 beyond: about one point per cell or fewer -- with 8 points per cell the 64-point groups of the mesh
+// kernels are visibly less compact, C5 7.9 -> 8.8 ms).  Cells come out in Z order; the order of the points inside a cell is whatever the atomics make it -- it may
 // differ from run to run, and no result depends on it (the mesh kernels and the composed kernel return the same bits
 // for any processing order; tests/test_mesh_gpu.py, tests/test_robot_gpu.py).
 #include "common.h"
@@ -12,8 +14,8 @@
 
 namespace pvamd {
 
-// scratch layout (uint32 words): [0..5] bounds codes, [6] unused, [8 .. 8 + cells) cell counters / offsets,
-// then P keys
+// scratch layout (uint32 words): [0..5] bounds codes, [8 .. 8 + cells) cell counters / offsets, then P keys, then
+// cells / 1024 block sums of the scan
 constexpr int kBoxWords = 8;
 
 __global__ __launch_bounds__(256) void order_init_kernel(unsigned* __restrict__ scratch, int cells) {
@@ -74,7 +76,8 @@ __global__ __launch_bounds__(256) void order_count_kernel(const float* __restric
     atomicAdd(scratch + kBoxWords + (key >> shift), 1u);
 }
 
-// exclusive scan of `cells` counters in place, one block of 1024 threads (cells is a multiple of 1024)
+// exclusive scan of `cells` values in place, one block of 1024 threads (cells a multiple of 1024; used on the <= 2048
+// block sums, 1-2 values per thread)
 __global__ __launch_bounds__(1024) void order_scan_kernel(unsigned* __restrict__ counters, int cells) {
     __shared__ unsigned partial[1024];
     const int per = cells / 1024, t = threadIdx.x;
@@ -96,6 +99,37 @@ __global__ __launch_bounds__(1024) void order_scan_kernel(unsigned* __restrict__
     }
 }
 
+// ---- three-kernel scan: block sums, scan of the block sums, per-block scan ----
+__global__ __launch_bounds__(1024) void order_blocksum_kernel(const unsigned* __restrict__ counters,
+                                                              unsigned* __restrict__ blocksum) {
+    __shared__ unsigned part[16];
+    unsigned v = counters[(int64_t)blockIdx.x * 1024 + threadIdx.x];
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = v;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        unsigned s = 0;
+        for (int k = 0; k < 16; ++k) s += part[k];
+        blocksum[blockIdx.x] = s;
+    }
+}
+
+__global__ __launch_bounds__(1024) void order_blockscan_kernel(unsigned* __restrict__ counters,
+                                                               const unsigned* __restrict__ blockprefix) {
+    __shared__ unsigned sh[1024];
+    const int t = threadIdx.x;
+    const unsigned c = counters[(int64_t)blockIdx.x * 1024 + t];
+    sh[t] = c;
+    __syncthreads();
+    for (int off = 1; off < 1024; off <<= 1) {
+        const unsigned add = t >= off ? sh[t - off] : 0u;
+        __syncthreads();
+        sh[t] += add;
+        __syncthreads();
+    }
+    counters[(int64_t)blockIdx.x * 1024 + t] = blockprefix[blockIdx.x] + sh[t] - c;  // exclusive
+}
+
 __global__ __launch_bounds__(256) void order_scatter_kernel(const float* __restrict__ pts, int64_t P,
                                                             unsigned* __restrict__ scratch, int shift,
                                                             int* __restrict__ order, int* __restrict__ inv,
@@ -114,6 +148,79 @@ __global__ __launch_bounds__(256) void order_scatter_kernel(const float* __restr
     }
 }
 
+// ---- up to 16384 points: the whole thing in ONE workgroup (bounds, 16^3-cell histogram in LDS, scan, scatter) ----
+// The seven launches above cost ~4.5 us each whatever their size; for the 10k-point query of BASELINE C1 that was a
+// quarter of the call.
+constexpr int kSmallCells = 4096, kSmallShift = 18;
+__global__ __launch_bounds__(1024) void order_small_kernel(const float* __restrict__ pts, int P, int* __restrict__ order,
+                                                           int* __restrict__ inv, float* __restrict__ sorted_pts) {
+    __shared__ unsigned hist[kSmallCells];
+    __shared__ unsigned partial[1024];
+    __shared__ float part[16][6];
+    __shared__ float box[6];
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+    for (int i = t; i < P; i += 1024) {
+#pragma unroll
+        for (int d = 0; d < 3; ++d) {
+            const float v = pts[3 * i + d];
+            if (fabsf(v) < INFINITY) {
+                lo[d] = fminf(lo[d], v);
+                hi[d] = fmaxf(hi[d], v);
+            }
+        }
+    }
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+        for (int off = 32; off > 0; off >>= 1) {
+            lo[d] = fminf(lo[d], __shfl_xor(lo[d], off, 64));
+            hi[d] = fmaxf(hi[d], __shfl_xor(hi[d], off, 64));
+        }
+    }
+    if (lane == 0) {
+#pragma unroll
+        for (int d = 0; d < 3; ++d) { part[wave][d] = lo[d]; part[wave][3 + d] = hi[d]; }
+    }
+    for (int c = t; c < kSmallCells; c += 1024) hist[c] = 0u;
+    __syncthreads();
+    if (t < 6) {
+        float v = part[0][t];
+        for (int w = 1; w < 16; ++w) v = t < 3 ? fminf(v, part[w][t]) : fmaxf(v, part[w][t]);
+        box[t] = v;
+    }
+    __syncthreads();
+    const float blo[3] = {box[0], box[1], box[2]}, bhi[3] = {box[3], box[4], box[5]};
+    for (int i = t; i < P; i += 1024)
+        atomicAdd(&hist[morton_key30(pts[3 * i], pts[3 * i + 1], pts[3 * i + 2], blo, bhi) >> kSmallShift], 1u);
+    __syncthreads();
+    unsigned c4[4], sum = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { c4[k] = hist[4 * t + k]; sum += c4[k]; }
+    partial[t] = sum;
+    __syncthreads();
+    for (int off = 1; off < 1024; off <<= 1) {
+        const unsigned add = t >= off ? partial[t - off] : 0u;
+        __syncthreads();
+        partial[t] += add;
+        __syncthreads();
+    }
+    unsigned run = partial[t] - sum;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { hist[4 * t + k] = run; run += c4[k]; }
+    __syncthreads();
+    for (int i = t; i < P; i += 1024) {
+        const float x = pts[3 * i], y = pts[3 * i + 1], z = pts[3 * i + 2];
+        const unsigned slot = atomicAdd(&hist[morton_key30(x, y, z, blo, bhi) >> kSmallShift], 1u);
+        order[slot] = i;
+        if (inv) inv[i] = (int)slot;
+        if (sorted_pts) {
+            sorted_pts[3 * slot] = x;
+            sorted_pts[3 * slot + 1] = y;
+            sorted_pts[3 * slot + 2] = z;
+        }
+    }
+}
+
 }  // namespace pvamd
 
 using namespace pvamd;
@@ -125,13 +232,24 @@ extern "C" int pvamd_morton_order(const float* points, int64_t P, int32_t* order
     if (!points || !order_out || !scratch) return PVAMD_E_NULL;
     if (!aligned_to(scratch, 4) || !aligned_to(points, 4)) return PVAMD_E_ALIGN;
     hipStream_t s = (hipStream_t)stream;
+    if (P <= 16384) {
+        hipLaunchKernelGGL(order_small_kernel, dim3(1), dim3(1024), 0, s, points, (int)P, order_out, inv_out, sorted_points_out);
+        return (int)hipGetLastError();
+    }
     unsigned* w = reinterpret_cast<unsigned*>(scratch);
     const int bits = PVAMD_MORTON_ORDER_BITS(P), shift = 30 - bits, cells = 1 << bits;
     hipLaunchKernelGGL(order_init_kernel, dim3((cells + 255) / 256), dim3(256), 0, s, w, cells);
     const int64_t want = (P + 255) / 256;
     hipLaunchKernelGGL(order_bounds_kernel, dim3(want < 512 ? (unsigned)want : 512u), dim3(256), 0, s, points, P, w);
     hipLaunchKernelGGL(order_count_kernel, dim3((unsigned)want), dim3(256), 0, s, points, P, w, shift);
-    hipLaunchKernelGGL(order_scan_kernel, dim3(1), dim3(1024), 0, s, w + kBoxWords, cells);
+    {   // exclusive scan of the cell counters: block sums, scan of the <= 2048 block sums, per-block scan.  (One block
+        // walking 32 consecutive counters per thread took 51 us for 32768 cells: serial, uncoalesced.)
+        unsigned* blocksum = w + kBoxWords + cells + P;
+        const int nblocks = cells / 1024;
+        hipLaunchKernelGGL(order_blocksum_kernel, dim3(nblocks), dim3(1024), 0, s, w + kBoxWords, blocksum);
+        hipLaunchKernelGGL(order_scan_kernel, dim3(1), dim3(1024), 0, s, blocksum, nblocks < 1024 ? 1024 : nblocks);
+        hipLaunchKernelGGL(order_blockscan_kernel, dim3(nblocks), dim3(1024), 0, s, w + kBoxWords, blocksum);
+    }
     hipLaunchKernelGGL(order_scatter_kernel, dim3((unsigned)want), dim3(256), 0, s, points, P, w, shift, order_out, inv_out,
                        sorted_points_out);
     return (int)hipGetLastError();

@@ -4,7 +4,7 @@ sys.path.insert(0, os.getcwd())
 import torch
 import pytorch_volumetric_amd as pv
 from pytorch_volumetric_amd import mesh_io
-from tests import helpers as H
+import workloads as H
 
 
 def timed(fn, reps):

@@ -9,7 +9,7 @@ make -s -C pytorch_volumetric_amd/csrc
 mkdir -p tools/variants
 C=pytorch_volumetric_amd/csrc
 which=$(basename "$src" .hip); which=${which%%_*}
-extra=""; [ "$which" = composed ] && extra="-fno-slp-vectorize"   # as csrc/Makefile (FLAGS_composed)
+extra=""; { [ "$which" = composed ] || [ "$which" = mesh ]; } && extra="-fno-slp-vectorize"   # as csrc/Makefile (FLAGS_*)
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -fno-fast-math -ffp-contract=off -Wno-unused-value -I$C -Iinclude $extra "$@" -c "$src" -o tools/variants/${which}_$name.o
 objs=""
 for o in api cached composed mesh chamfer_grid xform fk voxelgrid sample sort; do
