@@ -186,6 +186,18 @@ int pvamd_composed_query(const pvamd_grid_t* grids, int32_t S, const float* tf, 
                          const float* points, int64_t P,
                          float* out_val, float* out_grad, int32_t* out_leaf, int32_t flags, void* stream);
 
+/* The glue of ComposedSDF.__call__ for leaves that are not cached grids (MeshSDF, SphereSDF, nested compositions;
+ * sdf.py:392-433 around per-leaf queries), with the fused kernel's rounding so that both paths state the same numbers:
+ * pvamd_transform_points: out[a][p] = tf[a] p (sdf.py:399).  tf: device [A][4][4] -- the A transforms of ONE leaf.
+ *   points: device [P][3].  out: device [A][P][3].  A <= 65535.
+ * pvamd_compose_merge: fold leaf s into the running first minimum (sdf.py:409,421): where leaf_val is smaller than
+ *   best_val (or is NaN against a number; everywhere when first != 0) take it, with the gradient brought back to the
+ *   object frame as L^T g (L = linear part of tf[a]; valid for any affine transform).  leaf_val / best_val: device [A][P].
+ *   leaf_grad / best_grad: device [A][P][3].  best_leaf: device [A][P] int32 or NULL.                                  */
+int pvamd_transform_points(const float* tf, int32_t A, const float* points, int64_t P, float* out, void* stream);
+int pvamd_compose_merge(const float* tf, int32_t A, int64_t P, const float* leaf_val, const float* leaf_grad,
+                        int32_t s, int32_t first, float* best_val, float* best_grad, int32_t* best_leaf, void* stream);
+
 /* The same query when the caller has sorted the points spatially (e.g. along the Morton curve of pvamd_morton_keys):
  * coherent wave tiles let whole leaves be skipped and keep the leaf-grid region a tile touches in L2, which is what
  * decides the time once the grids are far larger than L2 (README-size link grids: 4.9 -> 1.6 ms for 200 x 262,144).

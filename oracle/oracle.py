@@ -191,6 +191,24 @@ def sample_surface(tri, cdf, n, seed):
     return pts, face, key
 
 
+def transform_points(tf, pts):
+    """x[a][p] = tf[a] p, the k-ordered fma chain of the composed kernels (sdf.py:399).  tf: [A,4,4]."""
+    tf = _f32(tf).reshape(-1, 16)
+    pts = _f32(pts).reshape(-1, 3)
+    out = np.empty((len(tf), len(pts), 3), np.float32)
+    load().oracle_transform_points(_p(tf), ctypes.c_int32(len(tf)), _p(pts), ctypes.c_int64(len(pts)), _p(out))
+    return out
+
+
+def compose_merge(tf, leaf_val, leaf_grad, s, best_val, best_grad, best_leaf=None):
+    """Fold leaf s into the running first minimum in place (sdf.py:409,421); s == 0 initialises."""
+    tf = _f32(tf).reshape(-1, 16)
+    A, P = leaf_val.shape
+    lv, lg = _f32(leaf_val), _f32(leaf_grad)
+    load().oracle_compose_merge(_p(tf), ctypes.c_int32(A), ctypes.c_int64(P), _p(lv), _p(lg), ctypes.c_int32(s),
+                                ctypes.c_int32(1 if s == 0 else 0), _p(best_val), _p(best_grad), _p(best_leaf))
+
+
 def composed_query(grids, tf, A, pts):
     """grids: list of S Grid; tf: [S*A,4,4] obj->leaf leaf-major; returns val [A,P], grad [A,P,3], leaf [A,P]."""
     S = len(grids)

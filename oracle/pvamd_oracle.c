@@ -251,6 +251,29 @@ static void affine_apply(const float* M, const float* p, float* x) {
     }
 }
 
+/* The glue of ComposedSDF.__call__ around arbitrary leaves (sdf.py:399 transform, :409 normals back, :421 argmin) */
+void oracle_transform_points(const float* tf, int32_t A, const float* pts, int64_t P, float* out) {
+    for (int32_t a = 0; a < A; ++a)
+        for (int64_t i = 0; i < P; ++i) affine_apply(tf + 16 * (int64_t)a, pts + 3 * i, out + 3 * ((int64_t)a * P + i));
+}
+
+void oracle_compose_merge(const float* tf, int32_t A, int64_t P, const float* leaf_val, const float* leaf_grad, int32_t s,
+                          int32_t first, float* best_val, float* best_grad, int32_t* best_leaf) {
+    for (int32_t a = 0; a < A; ++a) {
+        const float* M = tf + 16 * (int64_t)a;
+        for (int64_t i = 0; i < P; ++i) {
+            const int64_t o = (int64_t)a * P + i;
+            const float v = leaf_val[o];
+            const int take = first || (v < best_val[o]) || (isnan(v) && !isnan(best_val[o]));
+            if (!take) continue;
+            const float* g = leaf_grad + 3 * o;
+            best_val[o] = v;
+            for (int j = 0; j < 3; ++j) best_grad[3 * o + j] = fmaf(M[8 + j], g[2], fmaf(M[4 + j], g[1], M[j] * g[0]));
+            if (best_leaf) best_leaf[o] = s;
+        }
+    }
+}
+
 /* ComposedSDF.__call__ over CachedSDF leaves, sdf.py:392-433 (+ RobotSDF.__call__, model_to_sdf.py:117-125).
  * tf: [S*A][16] obj->leaf, leaf-major.  out_val [A][P], out_grad [A][P][3], out_leaf [A][P] or NULL. */
 void oracle_composed_query(const oracle_grid_t* grids, int32_t S, const float* tf, int32_t A, const float* pts,

@@ -109,6 +109,11 @@ SIGNATURES = {
                                                      ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_int64,
                                                      ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int32,
                                                      ctypes.c_void_p]),
+    "pvamd_transform_points": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int32, ctypes.c_void_p, ctypes.c_int64,
+                                              ctypes.c_void_p, ctypes.c_void_p]),
+    "pvamd_compose_merge": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int32, ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p,
+                                           ctypes.c_int32, ctypes.c_int32, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
+                                           ctypes.c_void_p]),
     "pvamd_voxel_gather_f32": (ctypes.c_int, [ctypes.POINTER(GridDesc), ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64,
                                               ctypes.c_float, ctypes.c_void_p, ctypes.c_void_p]),
     "pvamd_voxel_gather_u8": (ctypes.c_int, [ctypes.POINTER(GridDesc), ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64,

@@ -416,6 +416,48 @@ __global__ __launch_bounds__(256) void composed_query_scalar(const pvamd_grid_t*
     }
 }
 
+// ---- generic leaves (MeshSDF, SphereSDF, nested compositions): the glue of sdf.py:392-433 around per-leaf queries ----
+// x[a][p] = T[a] p with the fused kernel's rounding (k-ordered fma chain, sdf.py:399)
+__global__ __launch_bounds__(256) void transform_points_kernel(const float* __restrict__ tf, int A,
+                                                                const float* __restrict__ pts, int64_t P,
+                                                                float* __restrict__ out) {
+    const int a = blockIdx.y;
+    const float* M = tf + 16 * (int64_t)a;  // wave-uniform: scalar loads
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < P; i += stride) {
+        const float px = pts[3 * i], py = pts[3 * i + 1], pz = pts[3 * i + 2];
+        float* o = out + 3 * ((int64_t)a * P + i);
+        o[0] = affine_row(M[0], M[1], M[2], M[3], px, py, pz);
+        o[1] = affine_row(M[4], M[5], M[6], M[7], px, py, pz);
+        o[2] = affine_row(M[8], M[9], M[10], M[11], px, py, pz);
+    }
+}
+
+// fold leaf s into the running first-minimum: g_obj = L^T g_leaf (sdf.py:409; L = linear part of obj->leaf, any affine
+// transform), take where the leaf's value is smaller or is NaN against a number (sdf.py:421 argmin); first = 1 for s = 0
+__global__ __launch_bounds__(256) void compose_merge_kernel(const float* __restrict__ tf, int A, int64_t P,
+                                                             const float* __restrict__ leaf_val,
+                                                             const float* __restrict__ leaf_grad, int s, int first,
+                                                             float* __restrict__ best_val, float* __restrict__ best_grad,
+                                                             int* __restrict__ best_leaf) {
+    const int a = blockIdx.y;
+    const float* M = tf + 16 * (int64_t)a;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < P; i += stride) {
+        const int64_t o = (int64_t)a * P + i;
+        const float v = leaf_val[o], bv = first ? 0.f : best_val[o];
+        const bool take = first || (v < bv) || (v != v && bv == bv);
+        if (take) {
+            const float gx = leaf_grad[3 * o], gy = leaf_grad[3 * o + 1], gz = leaf_grad[3 * o + 2];
+            best_val[o] = v;
+            best_grad[3 * o] = fmaf(M[8], gz, fmaf(M[4], gy, mul_rn(M[0], gx)));
+            best_grad[3 * o + 1] = fmaf(M[9], gz, fmaf(M[5], gy, mul_rn(M[1], gx)));
+            best_grad[3 * o + 2] = fmaf(M[10], gz, fmaf(M[6], gy, mul_rn(M[2], gx)));
+            if (best_leaf) best_leaf[o] = s;
+        }
+    }
+}
+
 // ---- bucketed path: un-permute ----
 // The kernel above ran on spatially sorted points and left one packed record per (configuration, sorted position);
 // this pass brings them back to the caller's point order: out[a][j] = packed[a][inv[j]].  One wave = 256 consecutive
@@ -562,5 +604,26 @@ extern "C" int pvamd_composed_query(const pvamd_grid_t* grids, int32_t S, const 
                                P, out_val, out_grad, out_leaf, a0);
         }
     }
+    return (int)hipGetLastError();
+}
+
+extern "C" int pvamd_transform_points(const float* tf, int32_t A, const float* points, int64_t P, float* out,
+                                      void* stream) {
+    if (A < 1 || A > 65535 || P < 0) return PVAMD_E_SHAPE;
+    if (P == 0) return 0;
+    if (!tf || !points || !out) return PVAMD_E_NULL;
+    hipLaunchKernelGGL(transform_points_kernel, dim3(stream_grid(P, 256), A), dim3(256), 0, (hipStream_t)stream, tf, A, points,
+                       P, out);
+    return (int)hipGetLastError();
+}
+
+extern "C" int pvamd_compose_merge(const float* tf, int32_t A, int64_t P, const float* leaf_val, const float* leaf_grad,
+                                   int32_t s, int32_t first, float* best_val, float* best_grad, int32_t* best_leaf,
+                                   void* stream) {
+    if (A < 1 || A > 65535 || P < 0 || s < 0) return PVAMD_E_SHAPE;
+    if (P == 0) return 0;
+    if (!tf || !leaf_val || !leaf_grad || !best_val || !best_grad) return PVAMD_E_NULL;
+    hipLaunchKernelGGL(compose_merge_kernel, dim3(stream_grid(P, 256), A), dim3(256), 0, (hipStream_t)stream, tf, A, P,
+                       leaf_val, leaf_grad, s, first, best_val, best_grad, best_leaf);
     return (int)hipGetLastError();
 }

@@ -704,23 +704,30 @@ class ComposedSDF(ObjectFrameSDF):
                        "pvamd_composed_query")
 
     def _generic(self, flat, S, A):
-        """Leaves that are not cached grids (MeshSDF, SphereSDF, nested compositions): per-leaf query kernels with
-        the transform / rotate-back / first-minimum glue done on device."""
+        """Leaves that are not cached grids (MeshSDF -- the reference's own tests/test_sdf.py:61-80 -- SphereSDF, nested
+        compositions): per leaf one transform kernel, the leaf's own query, one merge kernel (pvamd_transform_points /
+        pvamd_compose_merge: the fused kernel's arithmetic, valid for any affine transform)."""
+        lib = _lib.load()
         dev = flat.device
+        P = flat.shape[0]
         m = self._tf_device(dev).reshape(S, A, 4, 4)
-        best_v = best_g = None
+        if A > 65535:
+            raise ValueError("the per-leaf path takes at most 65535 configurations per call")
+        best_v = torch.empty((A, P), dtype=torch.float32, device=dev)
+        best_g = torch.empty((A, P, 3), dtype=torch.float32, device=dev)
+        x = torch.empty((A, P, 3), dtype=torch.float32, device=dev)
         for i, sdf in enumerate(self.sdfs):
-            r, t = m[i, :, :3, :3], m[i, :, :3, 3]
-            x = flat.unsqueeze(0) @ r.transpose(-1, -2) + t.unsqueeze(1)  # (A,P,3) in leaf i's frame
+            tf_i = m[i].contiguous()
+            with _lib.on_device(dev):
+                _lib.check(lib.pvamd_transform_points(_lib.ptr(tf_i), A, _lib.ptr(flat), P, _lib.ptr(x), _lib.stream_ptr()),
+                           "pvamd_transform_points")
             v, g = sdf(x)
-            v = v.to(device=dev, dtype=torch.float32)
-            g = g.to(device=dev, dtype=torch.float32) @ r  # row-vector form of R^T g
-            if best_v is None:
-                best_v, best_g = v, g
-            else:
-                take = (v < best_v) | (torch.isnan(v) & ~torch.isnan(best_v))  # strict: first minimum wins
-                best_v = torch.where(take, v, best_v)
-                best_g = torch.where(take.unsqueeze(-1), g, best_g)
+            v = v.to(device=dev, dtype=torch.float32).reshape(A, P).contiguous()
+            g = g.to(device=dev, dtype=torch.float32).reshape(A, P, 3).contiguous()
+            with _lib.on_device(dev):
+                _lib.check(lib.pvamd_compose_merge(_lib.ptr(tf_i), A, P, _lib.ptr(v), _lib.ptr(g), i, 1 if i == 0 else 0,
+                                                   _lib.ptr(best_v), _lib.ptr(best_g), None, _lib.stream_ptr()),
+                           "pvamd_compose_merge")
         return best_v, best_g
 
 

@@ -218,3 +218,52 @@ def test_both_index_modes_give_the_reference_index_where_the_estimate_is_shaky(f
     oval, ograd, _ = oracle.composed_query([H.oracle_grid_from_cached(l) for l in leaves], tfm.numpy(), A, pts.numpy())
     assert np.array_equal(val.cpu().numpy(), oval, equal_nan=True)
     assert np.array_equal(grad.cpu().numpy(), ograd, equal_nan=True)
+
+
+def test_mesh_leaves_with_rotations_and_a_batch_match_the_oracle_composition_bitwise():
+    """ComposedSDF over MeshSDF leaves (the per-leaf path: pvamd_transform_points -> mesh kernel -> pvamd_compose_merge)
+    against the same composition stated with the oracle's pieces: transform (fma chain), brute-force mesh query with the
+    same jitter counter, merge.  Rigid transforms with rotations, a configuration batch of 3."""
+    objs = [pv.MeshObjectFactory(H.mesh_path("probe.obj")), pv.MeshObjectFactory(H.mesh_path("box_template.obj"), scale=0.03)]
+    S, A, P = 2, 3, 4000
+    tfm = H.random_rigid(S * A, seed=21, trans=0.05)
+    comp = pv.ComposedSDF([pv.MeshSDF(o) for o in objs], None)
+    comp.set_transforms(pv.Transform3d(matrix=tfm), batch_dim=(A,))
+    pts = H.uniform_points(P, [-0.1] * 3, [0.1] * 3, seed=8)
+    val, grad = comp(pts.cuda())
+    assert val.shape == (A, P) and grad.shape == (A, P, 3)
+    best_v, best_g = np.empty((A, P), np.float32), np.empty((A, P, 3), np.float32)
+    best_leaf = np.empty((A, P), np.int32)
+    for s, obj in enumerate(objs):
+        tf_s = tfm.reshape(S, A, 4, 4)[s].numpy()
+        x = oracle.transform_points(tf_s, pts.numpy())  # [A,P,3]
+        _, d, g, _, _ = oracle.mesh_query(H.oracle_mesh_from_factory(obj), x.reshape(-1, 3), seed=obj.jitter_seed)
+        oracle.compose_merge(tf_s, d.reshape(A, P), g.reshape(A, P, 3), s, best_v, best_g, best_leaf)
+    assert np.array_equal(val.cpu().numpy(), best_v)
+    assert np.array_equal(grad.cpu().numpy(), best_g, equal_nan=True)
+    assert len(np.unique(best_leaf)) == 2
+
+
+def test_non_rigid_transforms_take_the_general_path_and_stay_consistent():
+    """A scaled (non-rigid) obj->leaf transform: the reference inverts it with a general matrix inverse (sdf.py:380) and
+    its __call__ is valid for any affine map; here set_transforms detects it, leaves the fused kernel (whose culling and
+    R^T need rigidity) and x = L p + t, g_obj = L^T g_leaf are applied per leaf."""
+    leaf = make_leaf()
+    m = H.random_rigid(2, seed=4, trans=0.1)
+    m[1, :3, :3] *= 1.3  # uniform scale on the second leaf
+    comp = pv.ComposedSDF([leaf, leaf], m)
+    assert comp._rigid is False and not comp._fusable()
+    inv = comp.link_frame_to_obj_frame[1].get_matrix()[0]
+    assert torch.allclose(inv @ m[1], torch.eye(4), atol=1e-5)  # a true inverse, not R^T
+    pts = scene_points(20_000, seed=12, extent=0.3).cuda()
+    val, grad = comp(pts)
+    v0, g0 = leaf(pts @ m[0, :3, :3].T.cuda() + m[0, :3, 3].cuda())
+    v1, g1 = leaf(pts @ m[1, :3, :3].T.cuda() + m[1, :3, 3].cuda())
+    expect = torch.minimum(v0, v1)
+    near_tie = (v0 - v1).abs() < 1e-5
+    assert torch.allclose(val[~near_tie], expect[~near_tie], atol=2e-5)  # torch matmul vs fma chain: last-place differences
+    g_expect = torch.where((v1 < v0).unsqueeze(-1), g1 @ m[1, :3, :3].cuda(), g0 @ m[0, :3, :3].cuda())
+    ok = torch.isclose(val, expect, atol=1e-6) & ~near_tie
+    assert torch.allclose(grad[ok].nan_to_num(0.0), g_expect[ok].nan_to_num(0.0), atol=1e-4) and ok.float().mean() > 0.95
+    rigid = pv.ComposedSDF([leaf, leaf], H.random_rigid(2, seed=4, trans=0.1))
+    assert rigid._rigid is True and rigid._fusable()
