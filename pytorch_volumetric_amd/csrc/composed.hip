@@ -464,7 +464,8 @@ __global__ __launch_bounds__(256) void compose_merge_kernel(const float* __restr
 // caller points of one configuration: 4 gathers of a 16-byte record per lane (a configuration's records are a 4 MB
 // window that was written moments ago), results staged through the wave's LDS slice and written as 1 + 3 contiguous
 // 1 KB stores like everywhere else.  Blocks of one configuration are kept on one XCD (block b runs on XCD b % 8) so that
-// the window is pulled into ONE L2 instead of eight.
+// the window is pulled into ONE L2 instead of eight (README-size C4, whole bucketed call: 1.67 ms pinned, 2.06 ms with
+// configuration-major blocks, 2.30 ms with configuration-fastest blocks).
 __global__ __launch_bounds__(kWavesPerBlock * 64) void composed_unpermute_kernel(const f32x4* __restrict__ packed,
                                                                                  const int* __restrict__ inv, int64_t P,
                                                                                  int64_t Pp, int A, int64_t tile_blocks,
@@ -542,6 +543,9 @@ extern "C" int pvamd_composed_query_bucketed(const pvamd_grid_t* grids, int32_t 
     constexpr int kSlab = 65535;  // gridDim.y of the query kernel = tile blocks
     if (tile_blocks > kSlab) return PVAMD_E_SHAPE;  // > 67 M points per call: use the direct entry point
     const f32x4* p4 = reinterpret_cast<const f32x4*>(sorted_points);
+    // One query launch, one un-permute launch.  (Alternating the two over chunks of configurations small enough for the
+    // packed records to stay in the 256 MB Infinity Cache was slower: README-size C4 1.66 ms unchunked, 1.89 / 2.10 / 3.29
+    // ms with 192 / 96 / 32 MB chunks -- the query kernel lives off the L2 reuse between MANY configurations of a tile.)
     if (flags & PVAMD_COMPOSED_INLINE_EXACT)
         hipLaunchKernelGGL((composed_query_wave<PVAMD_COMPOSED_PPP, kInlineExact, true>), dim3(A, (unsigned)tile_blocks),
                            dim3(kWavesPerBlock * 64), 0, s, grids, S, tf, A, p4, ntiles, Pp, scratch, nullptr, nullptr, 0);

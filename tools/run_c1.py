@@ -3,7 +3,7 @@ import sys, os, time
 sys.path.insert(0, os.getcwd())
 import torch
 import pytorch_volumetric_amd as pv
-from tests import helpers as H
+import workloads as H
 drill = pv.MeshObjectFactory(H.mesh_path("ycb_power_drill.npz"))
 sdf = pv.MeshSDF(drill)
 pts = H.uniform_points(10000, [-0.2] * 3, [0.2] * 3, seed=1).cuda()

@@ -3,7 +3,7 @@ import sys, os
 sys.path.insert(0, os.getcwd())
 import torch
 import pytorch_volumetric_amd as pv
-from tests import helpers as H
+import workloads as H
 obj = pv.MeshObjectFactory(H.mesh_path("ycb_power_drill.npz"))
 cached = pv.CachedSDF("drill", 0.01, obj.bounding_box(padding=0.1), pv.MeshSDF(obj), device="cuda", cache_path=None)
 comp = pv.ComposedSDF([cached] * 8, pv.Transform3d(matrix=H.random_rigid(8, seed=0)))

@@ -1,19 +1,14 @@
-import sys, os, tempfile
+"""C4 (RobotSDF, 200 configurations x 262,144 random points, 100 KB link grids) a few times, for rocprofv3 passes."""
+import os, sys
 sys.path.insert(0, os.getcwd())
-import numpy as np, torch
-import pytorch_volumetric_amd as pv
-from tests import helpers as H
-sys.path.insert(0, os.path.join(os.getcwd(), "tools"))
-from bench_configs import synthetic_arm
-with tempfile.TemporaryDirectory() as tmp:
-    chain = synthetic_arm(tmp)
-    robot = pv.RobotSDF(chain, path_prefix=tmp, link_sdf_cls=pv.cache_link_sdf_factory(resolution=0.02, padding=0.1, device="cuda", cache_path=None))
-A, P4 = 200, 1 << 18
-th0 = torch.tensor([0.0, -np.pi / 4, 0.0, np.pi / 2, 0.0, np.pi / 4, 0.0])
-th = torch.cat((th0.view(1, -1), th0 + torch.randn(A - 1, 7, generator=torch.Generator().manual_seed(0)) * 0.1))
-robot.set_joint_configuration(th)
-pts4 = H.uniform_points(P4, [-0.7, -0.7, -0.2], [0.7, 0.7, 1.5], seed=1).cuda()
+import torch
+import workloads as Wk
+robot = Wk.build_c4(0.02, 0.1)
+A, P = 200, 1 << 18
+robot.set_joint_configuration(Wk.c4_joint_configs(A))
+pts = Wk.c4_points(P)
+val = torch.empty((A, P), dtype=torch.float32, device="cuda"); grad = torch.empty((A, P, 3), dtype=torch.float32, device="cuda")
 for _ in range(3):
-    v, g = robot(pts4)
+    robot.query_into(pts, val, grad)
 torch.cuda.synchronize()
-print(v.shape, float(v.mean()))
+print(val.shape, float(val.mean()))

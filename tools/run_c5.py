@@ -3,7 +3,7 @@ sys.path.insert(0, os.getcwd())
 import torch
 import pytorch_volumetric_amd as pv
 from pytorch_volumetric_amd import mesh_io
-from tests import helpers as H
+import workloads as H
 n = int(sys.argv[1]) if len(sys.argv) > 1 else (1 << 21)
 m = mesh_io.uv_sphere_mesh(0.1, 250, 200)
 sphere = pv.MeshObjectFactory(mesh=m)
