@@ -119,7 +119,7 @@ class RobotSDF(sdf.ObjectFrameSDF):
                                                  _lib.ptr(stack), _lib.stream_ptr()), "pvamd_transform_stack")
         self.object_to_link_frames = tf.Transform3d(matrix=stack)
         if self.sdf is not None:
-            self.sdf.set_transforms(self.object_to_link_frames, batch_dim=self.configuration_batch)
+            self.sdf.set_transforms(self.object_to_link_frames, batch_dim=self.configuration_batch, known_rigid=True)
 
     def _offset_inv_dev(self, dev):
         if getattr(self, "_offset_inv_cache", None) is None or self._offset_inv_cache.device != dev:

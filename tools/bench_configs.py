@@ -20,6 +20,7 @@ import pytorch_volumetric_amd as pv
 from oracle import oracle
 from pytorch_volumetric_amd import mesh_io
 from tests import helpers as H
+import workloads as Wk
 
 HBM_PEAK = 8000.0      # GB/s
 FP32_PEAK = 157.3      # TFLOP/s vector
@@ -53,7 +54,10 @@ def cpu_time(fn, budget=3.0):
             return dt / n
 
 
-def synthetic_arm(tmp, n_links=8):
+synthetic_arm = Wk.synthetic_arm
+
+
+def _unused_synthetic_arm(tmp, n_links=8):
     for i in range(n_links):
         m = mesh_io.uv_sphere_mesh(1.0, 24, 12, scale=(0.06, 0.06, 0.11), center=(0, 0, 0.09))
         mesh_io.save_obj(os.path.join(tmp, f"link_{i}.obj"), m)
