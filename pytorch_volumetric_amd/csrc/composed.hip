@@ -577,8 +577,8 @@ extern "C" int pvamd_composed_query(const pvamd_grid_t* grids, int32_t S, const 
     // scalar_probe.py, ms, wave-tile | one-point-per-lane): C3 4M random 0.106 | 0.095, C3 Morton-sorted 0.064 | 0.074,
     // C4 200 x 262k random 0.85 | 0.97, sorted 0.60 | 0.82, README-size grids 4.9 | 6.4 and 1.0 | 2.6.  So: a single
     // configuration, or too few tiles to fill the chip (100k points x 8 leaves: 36 -> 17 us), takes the per-lane kernel.
-    // (flags bit 1, undocumented: force the per-lane kernel -- tools/scalar_probe.py.)
-    const bool enough = vec_ok && A >= 2 && (P / kTilePoints) * (int64_t)A >= 4096 && !(flags & 2);
+    // (flags bits 1 and 2, for tools/scalar_probe.py and the tests: force the per-lane / the wave-tile kernel.)
+    const bool enough = vec_ok && ((A >= 2 && (P / kTilePoints) * (int64_t)A >= 4096 && !(flags & 2)) || (flags & 4));
     const int64_t ntiles = enough ? P / kTilePoints : 0;
     // up to ~65536 blocks in total, split over the A configurations: about one 256-point tile per wave.  (Sweep on C4,
     // 200 x 262,144: 1024 blocks 1.40 ms, 4096 1.17, 8192 1.13, 32768 1.09, 65536 1.08 -- the hardware dispatcher

@@ -189,10 +189,10 @@ def test_compose_of_mesh_sdfs_like_the_reference_test():
     assert torch.allclose(grads, torch.where((v2 < v1).unsqueeze(-1), g2, g1), atol=1e-5)
 
 
-@pytest.mark.parametrize("flags", [0, 1])
+@pytest.mark.parametrize("flags", [4, 4 | 1, 2])
 def test_both_index_modes_give_the_reference_index_where_the_estimate_is_shaky(flags):
-    """pvamd_composed_query's tuning hint (redo flagged points after the loop / exact statements inline) must never
-    change a result.  A leaf far from its own origin (coordinates ~200 x the resolution -> a wide error bound on the
+    """pvamd_composed_query's tuning hints must never change a result: wave-tile kernel with flagged points redone after the
+    loop (4), with the exact statements inline (4 | 1), and the per-lane kernel (2).  A leaf far from its own origin (coordinates ~200 x the resolution -> a wide error bound on the
     fp32 index estimate) and query points sprayed on its half-voxel planes make flagged visits the rule."""
     gt = H.AnalyticEllipsoidSDF([7.0, -5.0, 3.0], [0.3, 0.2, 0.25], [[6.7, 7.3], [-5.2, -4.8], [2.75, 3.25]])
     rng = [(6.5, 7.5), (-5.5, -4.5), (2.5, 3.5)]

@@ -89,10 +89,23 @@ def test_composed_query_fuzz(seed):
     comp.set_transforms(tfm, batch_dim=(A,) if A > 1 else None)
     n = int(rng.choice([7, 256, 1000, 4096, 10_003]))
     pts = (rng.random((n, 3)) * 6 - 3).astype(np.float32)
-    val, grad = comp(torch.from_numpy(pts).cuda())
+    if seed % 3 == 1:  # spatially coherent tiles: clusters of 256 points -> the per-tile leaf mask and its refinement fire
+        centres = (rng.random((max(n // 256, 1), 3)) * 6 - 3).repeat(256, axis=0)[:n]
+        pts[: len(centres)] = (centres + rng.normal(scale=0.05, size=centres.shape)).astype(np.float32)[: n]
+    if n > 300 and seed % 5 == 0:
+        pts[257] = [np.nan, 0.1, 0.2]
+        pts[3] = [np.inf, 0.0, 0.0]
     oval, ograd, _ = oracle.composed_query([H.oracle_grid_from_cached(l) for l in leaves], tfm.numpy(), A, pts)
-    assert np.array_equal(val.cpu().numpy().reshape(A, -1), oval, equal_nan=True)
-    assert np.array_equal(grad.cpu().numpy().reshape(A, -1, 3), ograd, equal_nan=True)
+    dev = torch.device("cuda", torch.cuda.current_device())
+    comp._leaf_grids(dev)
+    # every kernel / index mode the dispatcher can pick (include/pvamd.h): per-lane, wave-tile x {estimate + redo, inline
+    # exact}, and the bucketed path (sort, packed records, un-permute) -- all must give the oracle's bits
+    for flags, bucket in ((2, False), (4, False), (4 | 1, False), (0, True), (1, True)):
+        comp._query_flags = flags
+        comp.bucket_points = bucket
+        val, grad = comp(torch.from_numpy(pts).cuda())
+        assert np.array_equal(val.cpu().numpy().reshape(A, -1), oval, equal_nan=True), (flags, bucket)
+        assert np.array_equal(grad.cpu().numpy().reshape(A, -1, 3), ograd, equal_nan=True), (flags, bucket)
 
 
 def random_mesh(rng):
