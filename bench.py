@@ -49,6 +49,9 @@ def parse_args():
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL over xGMI)")
     ap.add_argument("--share-gpu", action="store_true",
                     help="functional test on a 1-GPU box: every rank uses cuda:0 and collectives go through gloo")
+    ap.add_argument("--force-pg", action="store_true",
+                    help="test hook: create the process group and run the gather / all-reduce legs even with ONE rank "
+                         "(exercises the RCCL calls on a 1-GPU box)")
     ap.add_argument("--launch-check", action="store_true",
                     help="no GPU work: start the ranks, all-reduce over gloo, print the rank count (CPU test of --gpus N)")
     return ap.parse_args()
@@ -217,7 +220,7 @@ def read_traffic(P):
 
 
 # ------------------------------------------------------------------------------------------------ legs: C4 and C5
-def leg_c4(torch, dist, Wk, pv, timer, rank, world, steps, padding, with_gather, small=False):
+def leg_c4(torch, dist, Wk, pv, timer, rank, world, steps, padding, with_gather, small=False, use_pg=False):
     """BASELINE configs[3]: RobotSDF (7-DOF, 8 links), A=200 joint configurations x P=262,144 points, the POINTS
     sharded over the ranks (strong scaling: the total work is fixed).  Leg 1 leaves (val, grad) sharded -- no
     collective; leg 2 times ShardedSDF.__call__: query + RCCL all-gather of val and grad + the strided copy back to
@@ -259,7 +262,7 @@ def leg_c4(torch, dist, Wk, pv, timer, rank, world, steps, padding, with_gather,
                        "roofline": {"bound": "hbm", "achieved": BYTES_PER_PAIR_C4 * pairs / t / 1e9, "peak": HBM_PEAK_GBS * world,
                                     "unit": "GB/s", "frac": BYTES_PER_PAIR_C4 * pairs / t / 1e9 / (HBM_PEAK_GBS * world),
                                     "note": "16 B written per pair; the kernel itself is VALU-bound (DESIGN.md 3.2)"}}}
-    if with_gather and world > 1:
+    if with_gather and (world > 1 or use_pg):
         sharded = pv.ShardedSDF(robot, gather=True, compute_device=torch.device("cuda"))
         gsteps = max(2, steps // 4)
         full = None
@@ -280,7 +283,7 @@ def leg_c4(torch, dist, Wk, pv, timer, rank, world, steps, padding, with_gather,
     return out
 
 
-def leg_c5(torch, dist, Wk, pv, timer, rank, world, steps, small=False):
+def leg_c5(torch, dist, Wk, pv, timer, rank, world, steps, small=False, use_pg=False):
     """BASELINE configs[4]: unidirectional chamfer, 2,097,152 source points -> 99,500-triangle mesh, the source
     points sharded over the ranks; each rank reduces its slice, then ONE all-reduce of B float64 partial sums (+ the
     count) -- chamfer.py:79-94 with the mean taken over the global N."""
@@ -293,7 +296,7 @@ def leg_c5(torch, dist, Wk, pv, timer, rank, world, steps, small=False):
     def run():
         nonlocal err
         for _ in range(steps):
-            if world > 1:
+            if world > 1 or use_pg:
                 err = pv.sharded_chamfer(W, pts, obj_factory=mesh, scale=1000.0)
             else:
                 err = pv.batch_chamfer_dist(W, pts, obj_factory=mesh, scale=1000.0)
@@ -305,7 +308,7 @@ def leg_c5(torch, dist, Wk, pv, timer, rank, world, steps, small=False):
     return {"config": f"C5: chamfer, {N} points -> {F}-triangle sphere mesh, points sharded x{world}, B=1",
             "scaling": "strong", "n_gpus": world, "steps": steps, "unit": "points/s", "value": N * steps / t,
             "ms_per_step": t / steps * 1e3, "brute_force_equivalent_pairs_per_s": N * F * steps / t,
-            "collective": None if world == 1 else f"all_reduce of B=1 float64 sums + count ({dist.get_backend()})",
+            "collective": None if (world == 1 and not use_pg) else f"all_reduce of B=1 float64 sums + count ({dist.get_backend()})",
             "chamfer_mm2": float(err[0]), "analytic_sphere_mm2": analytic,
             "rel_err_vs_analytic": abs(float(err[0]) - analytic) / analytic}
 
@@ -333,15 +336,19 @@ def main():
             raise SystemExit(f"bench.py: {world} ranks but only {torch.cuda.device_count()} GPU(s) visible "
                              "(one process per GPU; --share-gpu is the 1-GPU functional test)")
     torch.cuda.set_device(local_rank)
-    if world > 1:
+    use_pg = world > 1 or args.force_pg
+    if use_pg:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", str(free_port()))
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
         else:
             dist.init_process_group(backend)
     import pytorch_volumetric_amd as pv
     import workloads as Wk
-    timer = Timer(torch, dist, world)
+    timer = Timer(torch, dist, world if not args.force_pg else max(world, 2))  # force-pg: barriers / all-reduce run too
 
     cached = Wk.build_c2_cache()
     pts = Wk.c2_points(cached, args.points, seed=1234 + rank)
@@ -403,7 +410,7 @@ def main():
                        "timed_region": "barrier + synchronize | K steps | event-query spin + synchronize | barrier; "
                                        "max over ranks",
                        "gather": False, "parallelism": f"points x{world}", "ranks": world,
-                       "backend": (dist.get_backend() if world > 1 else None), "gpus_requested": args.gpus},
+                       "backend": (dist.get_backend() if use_pg else None), "gpus_requested": args.gpus},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
                          "kernel": "pvamd::cached_query_wave", "launch_ms_mean": k_ms,
@@ -419,9 +426,9 @@ def main():
     if not args.no_legs:
         leg_steps = 20
         sm = args.small_legs
-        for name, fn in (("c4", lambda: leg_c4(torch, dist, Wk, pv, timer, rank, world, leg_steps, 0.1, True, sm)),
+        for name, fn in (("c4", lambda: leg_c4(torch, dist, Wk, pv, timer, rank, world, leg_steps, 0.1, True, sm, use_pg)),
                          ("c4_readme_grid", lambda: leg_c4(torch, dist, Wk, pv, timer, rank, world, leg_steps, 1.0, False, sm)),
-                         ("c5", lambda: leg_c5(torch, dist, Wk, pv, timer, rank, world, 5, sm))):
+                         ("c5", lambda: leg_c5(torch, dist, Wk, pv, timer, rank, world, 5, sm, use_pg))):
             try:
                 legs[name] = fn()
             except Exception as exc:  # a failing leg must not take the headline line with it
@@ -473,10 +480,19 @@ def main():
                          "oracle": "oracle/pvamd_oracle.c (in-repo CPU restatement; third-party arithmetic UNPINNED)"}
         if not args.no_cpu_baseline and world == 1:  # the CPU baseline is timed on rank 0 of the 1-GPU run only
             out["cpu_baseline"] = cpu_baseline(torch, np, cached, pts, args.cpu_seconds)
-        print(json.dumps(out))
-    if world > 1:
+    if use_pg:
         dist.barrier()
         dist.destroy_process_group()
+    if rank == 0:
+        # the JSON line is the LAST thing on stdout: RCCL prints a version banner through C stdio, which would otherwise
+        # be flushed after Python's own buffer at exit
+        import ctypes
+        sys.stdout.flush()
+        try:
+            ctypes.CDLL(None).fflush(None)
+        except Exception:
+            pass
+        print(json.dumps(out), flush=True)
 
 
 if __name__ == "__main__":

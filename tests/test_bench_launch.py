@@ -64,3 +64,19 @@ def test_single_rank_line_has_the_contract_fields():
     assert "SEPARATE" in roof["timing"] and "traffic_source" in roof
     assert line["steps"] == 20 and line["warmup"] == 5 and line["n_gpus"] == 1
     assert line["cpu_baseline"]["kind"] == "port" and line["cpu_baseline"]["cores"] >= 1
+
+
+@pytest.mark.gpu
+def test_rccl_calls_of_the_legs_run_on_one_rank():
+    """The 8-GPU run belongs to the driver; what can be checked on a 1-GPU box is that every torch.distributed call of the
+    multi-rank path is valid against the nccl (= RCCL) backend: process group with device_id, barrier, MAX all-reduce of the
+    timing, ShardedSDF's all_gather_into_tensor x2, sharded_chamfer's all-reduces -- with a single rank (--force-pg)."""
+    line = run_bench("--steps", "5", "--warmup", "2", "--points", "65536", "--small-legs", "--no-large", "--no-cpu-baseline",
+                     "--force-pg")
+    assert line["config"]["backend"] == "nccl"
+    legs = line["legs"]
+    for name in ("c4", "c4_readme_grid", "c5"):
+        assert "error" not in legs[name], legs[name]
+    assert legs["c4"]["gathered"]["gather"] is True and "nccl" in legs["c4"]["gathered"]["collective"]
+    assert legs["c4"]["gathered"]["output_shape"] == [[8, 16384], [8, 16384, 3]]
+    assert "nccl" in legs["c5"]["collective"] and legs["c5"]["rel_err_vs_analytic"] < 1e-3
