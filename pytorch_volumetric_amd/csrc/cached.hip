@@ -260,6 +260,9 @@ extern "C" int pvamd_cached_query(const pvamd_grid_t* grid, const float* points,
     const int64_t ntiles = vec_ok ? P / kTilePoints : 0;
     if (ntiles > 0) {
         const int64_t need = (ntiles + kWavesPerBlock - 1) / kWavesPerBlock;
+#ifndef PVAMD_CQ_BIG_ST_NT
+#define PVAMD_CQ_BIG_ST_NT false
+#endif
 #ifndef PVAMD_CQ_BLOCKS
 #define PVAMD_CQ_BLOCKS 1024
 #endif
@@ -270,7 +273,7 @@ extern "C" int pvamd_cached_query(const pvamd_grid_t* grid, const float* points,
         const bool big = P > ((int64_t)8 << 20);  // > 8M points (96 MB of xyz): streaming regime
 #define PVAMD_LAUNCH_CQ(F64_, OOB_)                                                                                      \
     do {                                                                                                                \
-        if (big) hipLaunchKernelGGL((cached_query_wave<F64_, OOB_, true, false>), grid_dim, block, 0, s, *grid, p4, ntiles, v4, g4, out_oob); \
+        if (big) hipLaunchKernelGGL((cached_query_wave<F64_, OOB_, true, PVAMD_CQ_BIG_ST_NT>), grid_dim, block, 0, s, *grid, p4, ntiles, v4, g4, out_oob); \
         else hipLaunchKernelGGL((cached_query_wave<F64_, OOB_, false, true>), grid_dim, block, 0, s, *grid, p4, ntiles, v4, g4, out_oob);    \
     } while (0)
         if (f64) {

@@ -458,6 +458,12 @@ __global__ __launch_bounds__(256) void compose_merge_kernel(const float* __restr
     }
 }
 
+// tiles per wave in the un-permute pass (= gathers in flight per lane / 4): 1 is best (whole README-size call 1.65 ms;
+// 1.70 with 2, 1.83 with 4 -- the pass is not latency-bound)
+#ifndef PVAMD_UNPERMUTE_TILES
+#define PVAMD_UNPERMUTE_TILES 1
+#endif
+constexpr int kUnpermuteTiles = PVAMD_UNPERMUTE_TILES;
 // ---- bucketed path: un-permute ----
 // The kernel above ran on spatially sorted points and left one packed record per (configuration, sorted position);
 // this pass brings them back to the caller's point order: out[a][j] = packed[a][inv[j]].  One wave = 256 consecutive
@@ -482,43 +488,50 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void composed_unpermute_kernel
     const int64_t group = b / (8 * tile_blocks), within = b % (8 * tile_blocks);
     const int a = (int)(group * 8 + within % 8);
     if (a >= A) return;
-    const int64_t tile = (within / 8) * kWavesPerBlock + wave;
-    if (tile * kTilePoints >= P) return;
     const f32x4* src = packed + (int64_t)a * Pp;
-    const int64_t j0 = tile * kTilePoints;
-    const bool full = (j0 + kTilePoints <= P) && (P % 4 == 0);
-    f32x4 r[4];
+    // kUnpermuteTiles tiles per wave: all their gathers are issued before the first result is used
+    f32x4 r[kUnpermuteTiles][4];
+    const int64_t tile0 = ((within / 8) * kWavesPerBlock + wave) * kUnpermuteTiles;
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        const int64_t j = j0 + lane + 64 * k;
-        r[k] = j < P ? src[inv[j]] : f32x4{0.f, 0.f, 0.f, 0.f};
-    }
-    const int64_t o = (int64_t)a * P + j0;
-    if (full) {
+    for (int t = 0; t < kUnpermuteTiles; ++t) {
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-            const int p = lane + 64 * k;
-            svf[p] = r[k].x;
-            spf[3 * p] = r[k].y;
-            spf[3 * p + 1] = r[k].z;
-            spf[3 * p + 2] = r[k].w;
+            const int64_t j = (tile0 + t) * kTilePoints + lane + 64 * k;
+            r[t][k] = j < P ? src[inv[j]] : f32x4{0.f, 0.f, 0.f, 0.f};
         }
-        PVAMD_WAVE_SYNC();
-        __builtin_nontemporal_store(sp[192 + lane], reinterpret_cast<f32x4*>(val + o) + lane);
-        f32x4* dst = reinterpret_cast<f32x4*>(grad + 3 * o);
-        __builtin_nontemporal_store(sp[lane], dst + lane);
-        __builtin_nontemporal_store(sp[lane + 64], dst + lane + 64);
-        __builtin_nontemporal_store(sp[lane + 128], dst + lane + 128);
-    } else {
+    }
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const int64_t j = j0 + lane + 64 * k;
-            if (j < P) {
-                val[(int64_t)a * P + j] = r[k].x;
-                float* g = grad + 3 * ((int64_t)a * P + j);
-                g[0] = r[k].y;
-                g[1] = r[k].z;
-                g[2] = r[k].w;
+    for (int t = 0; t < kUnpermuteTiles; ++t) {
+        const int64_t j0 = (tile0 + t) * kTilePoints;
+        if (j0 >= P) break;
+        const int64_t o = (int64_t)a * P + j0;
+        if ((j0 + kTilePoints <= P) && (P % 4 == 0)) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int p = lane + 64 * k;
+                svf[p] = r[t][k].x;
+                spf[3 * p] = r[t][k].y;
+                spf[3 * p + 1] = r[t][k].z;
+                spf[3 * p + 2] = r[t][k].w;
+            }
+            PVAMD_WAVE_SYNC();
+            __builtin_nontemporal_store(sp[192 + lane], reinterpret_cast<f32x4*>(val + o) + lane);
+            f32x4* dst = reinterpret_cast<f32x4*>(grad + 3 * o);
+            __builtin_nontemporal_store(sp[lane], dst + lane);
+            __builtin_nontemporal_store(sp[lane + 64], dst + lane + 64);
+            __builtin_nontemporal_store(sp[lane + 128], dst + lane + 128);
+            PVAMD_WAVE_SYNC();
+        } else {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int64_t j = j0 + lane + 64 * k;
+                if (j < P) {
+                    val[(int64_t)a * P + j] = r[t][k].x;
+                    float* g = grad + 3 * ((int64_t)a * P + j);
+                    g[0] = r[t][k].y;
+                    g[1] = r[t][k].z;
+                    g[2] = r[t][k].w;
+                }
             }
         }
     }
@@ -553,10 +566,11 @@ extern "C" int pvamd_composed_query_bucketed(const pvamd_grid_t* grids, int32_t 
         hipLaunchKernelGGL((composed_query_wave<PVAMD_COMPOSED_PPP, kEstimate, true>), dim3(A, (unsigned)tile_blocks),
                            dim3(kWavesPerBlock * 64), 0, s, grids, S, tf, A, p4, ntiles, Pp, scratch, nullptr, nullptr, 0);
     const int64_t groups = ((int64_t)A + 7) / 8;
-    const int64_t blocks = groups * 8 * tile_blocks;
+    const int64_t ublocks = (tile_blocks + kUnpermuteTiles - 1) / kUnpermuteTiles;
+    const int64_t blocks = groups * 8 * ublocks;
     if (blocks > 0x7fffffffLL) return PVAMD_E_SHAPE;
     hipLaunchKernelGGL(composed_unpermute_kernel, dim3((unsigned)blocks), dim3(kWavesPerBlock * 64), 0, s,
-                       reinterpret_cast<const f32x4*>(scratch), inv, P, Pp, A, tile_blocks, out_val, out_grad);
+                       reinterpret_cast<const f32x4*>(scratch), inv, P, Pp, A, ublocks, out_val, out_grad);
     return (int)hipGetLastError();
 }
 
