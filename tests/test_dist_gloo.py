@@ -53,6 +53,21 @@ class OracleRobot:
         return torch.from_numpy(v), torch.from_numpy(g)
 
 
+class OracleFlatComposed:
+    """A composition WITHOUT a transform batch: like the reference (sdf.py:418-426,433) it returns FLAT (P,) / (P,3) even
+    for batched points.  Carries the two attributes ShardedSDF recognises such an object by."""
+
+    def __init__(self):
+        self.leaf = OracleLeaf()
+        self.sdfs = [self.leaf] * 3
+        self.tsf_batch = None
+        self.tf = H.random_rigid(3, seed=12).numpy()
+
+    def __call__(self, pts):
+        v, g, _ = oracle.composed_query([self.leaf.grid] * 3, self.tf, 1, pts.reshape(-1, 3).numpy())
+        return torch.from_numpy(v[0]), torch.from_numpy(g[0])
+
+
 def worker(rank, world, port, P, results):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
@@ -72,6 +87,12 @@ def worker(rank, world, port, P, results):
         rv, rg = robot(pts)
         srv, srg = ShardedSDF(robot)(pts)
         ok = ok and srv.shape == (4, P) and torch.equal(srv, rv) and torch.equal(srg.nan_to_num(7.), rg.nan_to_num(7.))
+        # a composition without a transform batch stays flat for batched points, sharded or not
+        if P % 7 == 0:
+            flat = OracleFlatComposed()
+            fv, fg = flat(pts.reshape(7, P // 7, 3))
+            sfv, sfg = ShardedSDF(flat)(pts.reshape(7, P // 7, 3))
+            ok = ok and fv.shape == (P,) and sfv.shape == (P,) and sfg.shape == (P, 3) and torch.equal(sfv, fv)
         # gather=False: the local slice only
         lv, lg, (a, b) = ShardedSDF(leaf, gather=False)(pts)
         ok = ok and (a, b) == shard_range(P, world, rank)[:2] and torch.equal(lv, full_v[a:b])
