@@ -367,12 +367,15 @@ def main():
     if not args.no_graph:
         # the launch-bound inner loop (a ~6 us kernel) captured once: K launches, one replay
         graph = capture_graph(torch, step, args.steps)
-        # untimed: the first replay uploads the graph; the rest let the clocks settle (MI355X DVFS needs a few thousand
-        # of these ~6 us launches, MI355X_MICROARCH.md) when the caller asks for a short K / W.  Each replay is
-        # synchronised: a burst of un-synchronised replays leaves the HIP runtime with housekeeping that the NEXT launch
-        # call pays for (measured, tools/k20_probe.py: the launch call returns after ~200 us instead of ~15 us).  The
-        # timed region below is still exactly K steps.
-        for _ in range(max(3, -(-3000 // max(args.steps, 1)))):
+        # untimed: the first replay uploads the graph; a back-to-back burst lets the clocks settle (MI355X DVFS needs a few
+        # thousand of these ~6 us launches, MI355X_MICROARCH.md) when the caller asks for a short K / W.  A burst of
+        # un-synchronised replays leaves the HIP runtime with housekeeping that the NEXT launch call pays for (measured,
+        # tools/k20_probe.py: that call returns after ~200 us instead of ~15 us), so the burst is followed by three
+        # synchronised replays that absorb it.  The timed region below is still exactly K steps.
+        for _ in range(max(1, -(-3000 // max(args.steps, 1)))):
+            graph.replay()
+        torch.cuda.synchronize()
+        for _ in range(3):
             graph.replay()
             torch.cuda.synchronize()
 
