@@ -453,6 +453,23 @@ def main():
                                      "achieved_GBs": BYTES_PER_QUERY * P / (t_in * 1e-3) / 1e9,
                                      "frac_of_8TBs": BYTES_PER_QUERY * P / (t_in * 1e-3) / 1e9 / HBM_PEAK_GBS}
         del g2, pin
+        # secondary: 8M points (235 MB of traffic: larger than every L2, just inside the 256 MB Infinity Cache) -- the size
+        # at which launch ramp no longer matters and the kernel streams at its best
+        PM = 1 << 23
+        mid = Wk.c2_points(cached, PM, seed=98)
+        mval = torch.empty((PM,), dtype=torch.float32, device="cuda")
+        mgrad = torch.empty((PM, 3), dtype=torch.float32, device="cuda")
+        for _ in range(100):
+            cached.query_into(mid, mval, mgrad)
+        gm = capture_graph(torch, lambda: cached.query_into(mid, mval, mgrad), 200)
+        gm.replay()
+        torch.cuda.synchronize()
+        t_mid = graph_ms_per_launch(torch, gm, 200)
+        out["mid_batch"] = {"points": PM, "ms_per_launch": t_mid, "queries_per_s": PM / (t_mid * 1e-3),
+                            "achieved_GBs": BYTES_PER_QUERY * PM / (t_mid * 1e-3) / 1e9,
+                            "frac_of_8TBs": BYTES_PER_QUERY * PM / (t_mid * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                            "note": "working set inside the Infinity Cache: fabric, not HBM, bandwidth"}
+        del gm, mid, mval, mgrad
         # secondary: a batch far beyond the 256 MB Infinity Cache, where the kernel is HBM- rather than launch-bound
         PL = 1 << 26
         big = Wk.c2_points(cached, PL, seed=99)

@@ -775,6 +775,9 @@ static MeshArgs mesh_args(const pvamd_mesh_t& mesh) {
 //                            groups, not the throughput, set the kernel time (C5, 389 tiles: 8.2 ms with 8, 9.5 with 4,
 //                            16 with 2; 45 ms with one wave per group in the first version of the scan).
 static int pick_slices(int64_t point_tiles, int mesh_tiles) {
+#ifdef PVAMD_FORCE_SLICES
+    return PVAMD_FORCE_SLICES;
+#endif
     if (point_tiles < (int64_t)kNumCU * 4) return 16;
     if (point_tiles < (int64_t)kNumCU * 16) return 8;  // 100k random points on the drill: 0.65 (16) / 0.56 (8) / 0.60 ms (4)
     return mesh_tiles > 128 ? 8 : 4;
