@@ -52,7 +52,8 @@ def batch_chamfer_dist(world_to_object: torch.tensor, model_points_world_frame_e
     Wd = W.detach().to(device=dev, dtype=torch.float32).contiguous()
     sums = torch.empty((B,), dtype=torch.float64, device=dev)
 
-    fused_grid = isinstance(obj_sdf, CachedSDF) and obj_sdf.out_of_bounds_strategy == OutOfBoundsStrategy.BOUNDING_BOX
+    fused_grid = isinstance(obj_sdf, CachedSDF) and obj_sdf._dim == 3 and \
+        obj_sdf.out_of_bounds_strategy == OutOfBoundsStrategy.BOUNDING_BOX
     with _lib.on_device(dev):
         if fused_grid:
             desc = obj_sdf._grid_desc()

@@ -306,15 +306,18 @@ class VoxelView:
 
     def __init__(self, owner: "CachedSDF"):
         self._owner = owner
-        self.shape = owner._view.shape
+        self.shape = owner._view.shape[:owner._dim]
 
     @property
     def raw_data(self):
+        if self._owner._dim == 2:  # the planar cache is stored as two identical z layers: expose one
+            nx, ny, _ = self._owner._view.shape
+            return self._owner._packed.reshape(nx, ny, 2, 4)[:, :, 0, 0].reshape(-1)
         return self._owner._packed[:, 0]
 
     def _index(self, points, want_key=False, want_flat=False, want_valid=False):
         lib = _lib.load()
-        flat, lead, _, device = _lib.as_query_points(points, self._owner._packed.device, keep_f64=True)
+        flat, lead, _, device = _lib.as_query_points(self._owner._lift(points), self._owner._packed.device, keep_f64=True)
         P = flat.shape[0]
         key = torch.empty((P, 3), dtype=torch.int64, device=flat.device) if want_key else None
         ravel = torch.empty((P,), dtype=torch.int64, device=flat.device) if want_flat else None
@@ -324,7 +327,8 @@ class VoxelView:
         with _lib.on_device(flat.device):
             _lib.check(entry(ctypes.byref(desc), _lib.ptr(flat), P, _lib.ptr(key), _lib.ptr(ravel),
                              _lib.ptr(valid), _lib.stream_ptr()), "pvamd_voxel_index")
-        return (key.reshape(*lead, 3) if want_key else None, ravel.reshape(*lead) if want_flat else None,
+        d = self._owner._dim
+        return (key.reshape(*lead, 3)[..., :d] if want_key else None, ravel.reshape(*lead) if want_flat else None,
                 valid.reshape(*lead).bool() if want_valid else None)
 
     def ensure_index_key(self, points):
@@ -332,6 +336,8 @@ class VoxelView:
 
     def ravel_multi_index(self, key, shape=None):
         shape = shape or self.shape
+        if len(shape) == 2:
+            return key[..., 0] * shape[1] + key[..., 1]
         return (key[..., 0] * shape[1] + key[..., 1]) * shape[2] + key[..., 2]
 
     def get_valid_values(self, points):
@@ -400,7 +406,21 @@ class CachedSDF(ObjectFrameSDF):
                 torch.save(data, cache_path)
                 logger.info("caching sdf for %s to %s", self.name, cache_path)
 
-        self._view = RangeView(self.ranges, val.shape)
+        # The kernels are three-dimensional.  A planar (d = 2) cache -- the protocol allows it, sdf.py:222 -- is stored as
+        # two identical z layers over z in [-1, 1] and queried at z = 0: x / y index arithmetic, range test and the
+        # bounding-box branch (t_z = 0) are the planar statements, the z component of every output is dropped.
+        self._dim = len(self.ranges)
+        if self._dim not in (2, 3):
+            raise ValueError(f"CachedSDF works in 2 or 3 dimensions, got a {self._dim}-dimensional range")
+        view_ranges = list(self.ranges)
+        if self._dim == 2:
+            one = type(self.ranges[0][0])(1.0) if isinstance(self.ranges[0][0], (float, np.floating)) else 1.0
+            view_ranges = view_ranges + [(-one, one)]
+            val = torch.stack((val, val), dim=-1)
+            g2 = grad.reshape(-1, 2)
+            g3 = torch.cat((g2, torch.zeros_like(g2[:, :1])), dim=1)
+            grad = torch.stack((g3, g3), dim=1).reshape(-1, 3)
+        self._view = RangeView(view_ranges, val.shape)
         dev = _lib.require_gpu()
         lib = _lib.load()
         val_d = val.to(device=dev, dtype=torch.float32).contiguous().reshape(-1)
@@ -412,15 +432,28 @@ class CachedSDF(ObjectFrameSDF):
         self.voxels = VoxelView(self)
         self.voxels_grad = self._packed[:, 1:]
         self.bb = self.surface_bounding_box().to(device=dev)
+        if self._dim == 2 and self.bb.shape[0] == 2:
+            self.bb = torch.cat((self.bb, torch.tensor([[-1.0, 1.0]], dtype=self.bb.dtype, device=dev)), dim=0)
 
         if self.debug_check_sdf and gt_sdf is not None:
             _, pts = get_coordinates_and_points_in_grid(self.resolution, self.ranges)
             q, _ = self(pts)
             ok = self.voxels.get_valid_values(pts).to(q.device)  # fp32 boundary centres can round outside a f64 range
-            assert torch.allclose(val.reshape(-1).to(q.device, q.dtype)[ok], q[ok])  # voxel centres map to themselves
+            centre_val = val[..., 0] if self._dim == 2 else val
+            assert torch.allclose(centre_val.reshape(-1).to(q.device, q.dtype)[ok], q[ok])  # voxel centres map to themselves
 
     def surface_bounding_box(self, **kwargs):
         return self.gt_sdf.surface_bounding_box(**kwargs)
+
+    def _lift(self, points):
+        """planar caches: (..., 2) query points -> (..., 3) with z = 0 (see __init__)"""
+        if getattr(self, "_dim", 3) == 3:
+            return points
+        if not torch.is_tensor(points):
+            points = torch.as_tensor(points)
+        if points.shape[-1] != 2:
+            raise ValueError(f"this cache is planar: query points must have last dimension 2, got {tuple(points.shape)}")
+        return torch.cat((points, torch.zeros_like(points[..., :1])), dim=-1)
 
     def _grid_desc(self, oob_mode=None):
         """pvamd_grid_t for this cache (built once per out-of-bounds mode: filling it costs ~40 host scalar reads)."""
@@ -449,7 +482,7 @@ class CachedSDF(ObjectFrameSDF):
         # the launch happens on the GPU that holds the grid, whatever device is current in the calling code
         # float64 points are looked up in float64 (index arithmetic, range test and bounding-box branch all promote to
         # the query dtype in the reference: sdf.py:537-540,545-547,556-571); everything else is computed in float32
-        flat, lead, dtype, _ = _lib.as_query_points(points_in_object_frame, self._packed.device, keep_f64=True)
+        flat, lead, dtype, _ = _lib.as_query_points(self._lift(points_in_object_frame), self._packed.device, keep_f64=True)
         P = flat.shape[0]
         dev = flat.device
         val = torch.empty((P,), dtype=flat.dtype, device=dev)
@@ -464,11 +497,11 @@ class CachedSDF(ObjectFrameSDF):
         if lookup_gt:
             idx = oob.nonzero().squeeze(-1)  # sdf.py:552-554: ground truth on the out-of-range subset only
             if idx.numel() > 0:
-                v_gt, g_gt = self.gt_sdf(flat[idx])
+                v_gt, g_gt = self.gt_sdf(flat[idx][:, :self._dim])
                 val[idx] = v_gt.to(device=dev, dtype=flat.dtype)
-                grad[idx] = g_gt.to(device=dev, dtype=flat.dtype)
+                grad[idx, :self._dim] = g_gt.to(device=dev, dtype=flat.dtype)
         val = _restore(val, lead, (), dtype, self.device)
-        grad = _restore(grad, lead, (3,), dtype, self.device)
+        grad = _restore(grad[:, :self._dim], lead, (self._dim,), dtype, self.device)
         if self.debug_check_sdf:
             val_gt = self.gt_sdf(points_in_object_frame)[0].to(device=val.device, dtype=val.dtype)
             within = self.voxels.get_valid_values(points_in_object_frame).to(val.device)
@@ -500,7 +533,7 @@ class CachedSDF(ObjectFrameSDF):
     def outside_surface(self, points_in_object_frame, surface_level=0):
         """sdf.py:593-602"""
         lib = _lib.load()
-        flat, lead, _, _ = _lib.as_query_points(points_in_object_frame, self._packed.device, keep_f64=True)
+        flat, lead, _, _ = _lib.as_query_points(self._lift(points_in_object_frame), self._packed.device, keep_f64=True)
         out = torch.empty((flat.shape[0],), dtype=torch.uint8, device=flat.device)
         desc = self._grid_desc()
         entry = lib.pvamd_cached_outside_f64 if flat.dtype == torch.float64 else lib.pvamd_cached_outside
@@ -589,7 +622,7 @@ class ComposedSDF(ObjectFrameSDF):
     # ---- fused path ----
     def _fusable(self):
         return len(self.sdfs) > 0 and getattr(self, "_rigid", True) and all(
-            isinstance(s, CachedSDF) and s.out_of_bounds_strategy == OutOfBoundsStrategy.BOUNDING_BOX
+            isinstance(s, CachedSDF) and s._dim == 3 and s.out_of_bounds_strategy == OutOfBoundsStrategy.BOUNDING_BOX
             for s in self.sdfs)
 
     bucket_points = "auto"  # True / False / "auto": sort the query points spatially before the fused kernel (see __call__)

@@ -230,3 +230,66 @@ def test_index_fast_path_agrees_with_exact_division_at_rounding_boundaries(f64):
     assert np.array_equal(key, okey)
     # the sample really straddles the rounding boundary: both neighbours occur
     assert ((okey == k).any() and (okey == k + 1).any())
+
+
+class CircleSDF(pv.ObjectFrameSDF):
+    """Planar ground truth: a circle of radius r at the origin (what SphereSDF is in two dimensions)."""
+
+    def __init__(self, r):
+        self.r = r
+
+    def __call__(self, p):
+        n = torch.linalg.norm(p, dim=-1)
+        return n - self.r, p / (n.unsqueeze(-1) + 1e-12)
+
+    def surface_bounding_box(self, padding=0., padding_ratio=0.):
+        e = self.r + padding + padding_ratio * self.r
+        return torch.tensor([[-e, e], [-e, e]])
+
+
+@pytest.mark.parametrize("numpy_range", [True, False])
+def test_planar_cache_two_dimensional_points(numpy_range):
+    """ObjectFrameSDF is d-dimensional, d = 2 or 3 (sdf.py:222).  A planar CachedSDF answers (..., 2) points with (...,)
+    values and (..., 2) gradients: in range the nearest cell of the planar grid (x slowest, y fastest), out of range the
+    planar bounding-box statements of sdf.py:559-571."""
+    gt = CircleSDF(0.3)
+    rng = np.array([[-0.5, 0.5], [-0.4, 0.6]]) if numpy_range else [(-0.5, 0.5), (-0.4, 0.6)]
+    c = pv.CachedSDF("circle", 0.05, rng, gt, device="cuda", cache_path=None)
+    assert c.voxels.shape == (21, 21) and c._view.index_f64 == numpy_range
+    g = torch.Generator().manual_seed(0)
+    pts = torch.rand(3, 5000, 2, generator=g) * 1.6 - 0.8
+    val, grad = c(pts.cuda())
+    assert val.shape == (3, 5000) and grad.shape == (3, 5000, 2)
+    p = pts.reshape(-1, 2).double().numpy()
+    lo = np.array([r[0] for r in c.ranges], dtype=np.float64)
+    hi = np.array([r[1] for r in c.ranges], dtype=np.float64)
+    if not numpy_range:
+        lo, hi = lo.astype(np.float32).astype(np.float64), hi.astype(np.float32).astype(np.float64)
+    inside = ((p >= lo) & (p <= hi)).all(axis=1)
+    assert np.array_equal(c.voxels.get_valid_values(pts.cuda()).cpu().numpy().reshape(-1), inside)
+    coords, centres = pv.get_coordinates_and_points_in_grid(0.05, c.ranges)
+    ref_val, ref_grad = gt(centres)
+    cells = c._packed.cpu().reshape(21, 21, 2, 4)
+    assert torch.equal(cells[:, :, 0], cells[:, :, 1]) and not cells[..., 3].any()      # two identical layers, no z slope
+    cell_val, cell_grad = cells[:, :, 0, 0].reshape(-1), cells[:, :, 0, 1:3].reshape(-1, 2)
+    # the cache evaluates the ground truth on the device (sdf.py:510): same cells up to the device's norm rounding
+    assert torch.allclose(cell_val, ref_val, atol=1e-6) and torch.allclose(cell_grad, ref_grad, atol=1e-5)
+    key = c.voxels.ensure_index_key(pts.cuda()).cpu().reshape(-1, 2)
+    flat = c.voxels.ravel_multi_index(key, c.voxels.shape)
+    # away from the half-cell planes the index is unambiguous: nearest cell centre
+    res = (hi - lo) / 20
+    t = (p - lo) / res
+    clear = inside & (np.abs(t - np.floor(t) - 0.5) > 1e-3).all(axis=1)
+    assert np.array_equal(key.numpy()[clear], np.rint(t[clear]).astype(np.int64))
+    v, gr = val.cpu().reshape(-1), grad.cpu().reshape(-1, 2)
+    assert torch.equal(v[clear], cell_val[flat[clear]]) and torch.equal(gr[clear], cell_grad[flat[clear]])
+    assert torch.equal(c.voxels.raw_data.cpu(), cell_val)
+    # out of range: distance to the (unpadded) bounding box of the circle, unit gradient pointing away from it
+    bb = gt.surface_bounding_box().double().numpy()
+    d = np.maximum(bb[:, 0] - p, 0) + np.maximum(p - bb[:, 1], 0)
+    oob = ~inside
+    assert np.allclose(v.numpy()[oob], np.linalg.norm(d[oob], axis=1), atol=1e-6)
+    assert np.allclose(np.linalg.norm(gr.numpy()[oob], axis=1), 1.0, atol=1e-5)
+    assert torch.equal(c.outside_surface(pts.cuda(), 0.0).cpu().reshape(-1)[clear], (cell_val[flat[clear]] > 0))
+    with pytest.raises(ValueError):
+        c(torch.zeros(4, 3).cuda())
