@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define PVAMD_ABI_VERSION 5
+#define PVAMD_ABI_VERSION 6
 
 #define PVAMD_E_NULL      (-1)  /* a required pointer is NULL            */
 #define PVAMD_E_SHAPE     (-2)  /* a size/shape argument is out of range */
@@ -76,8 +76,9 @@ typedef struct pvamd_grid {
  * One triangle mesh = the read-only state of an ObjectFactory after precompute_sdf (sdf.py:97-120), prepared for the
  * kernels by pvamd_mesh_prepare().
  * normal:  device [F][3] fp32 unit face normals (sdf.py:119-120), indexed by ORIGINAL face id
- * rec:     device [F][PVAMD_TRI_REC] per-triangle records written by pvamd_mesh_prepare, in the (spatially sorted)
- *          order the caller chose; each record carries its original face id
+ * rec:     device float[PVAMD_REC_FLOATS(F)] per-triangle records written by pvamd_mesh_prepare, in the (spatially
+ *          sorted) order the caller chose, stored in whole tiles of PVAMD_TRI_TILE records (opaque layout: six float4
+ *          planes per tile); each record carries its original face id
  * tiles:   device float[PVAMD_TILES_FLOATS(F)]: [T][4] bounding sphere (cx, cy, cz, r) of each run of PVAMD_TRI_TILE
  *          records (T = ceil(F/PVAMD_TRI_TILE)), followed by [T][PVAMD_TRI_TILE/PVAMD_TRI_GROUP][4] spheres of each run
  *          of PVAMD_TRI_GROUP records
@@ -87,8 +88,9 @@ typedef struct pvamd_grid {
  *          because the reference adds its jitter in float64 before rounding to float32 (sdf.py:149-150).
  */
 #define PVAMD_TRI_REC   24   /* floats per prepared triangle record */
-#define PVAMD_TRI_TILE  256  /* triangles per LDS tile / per tile sphere */
+#define PVAMD_TRI_TILE  256  /* triangles per tile / per tile sphere */
 #define PVAMD_TRI_GROUP 16   /* triangles per group sphere */
+#define PVAMD_REC_FLOATS(F) ((((F) + PVAMD_TRI_TILE - 1) / PVAMD_TRI_TILE) * PVAMD_TRI_TILE * PVAMD_TRI_REC)
 #define PVAMD_TILES_FLOATS(F) ((((F) + PVAMD_TRI_TILE - 1) / PVAMD_TRI_TILE) * (4 + 4 * (PVAMD_TRI_TILE / PVAMD_TRI_GROUP)))
 typedef struct pvamd_mesh {
     const float* normal;     /* device */
@@ -221,7 +223,8 @@ int pvamd_composed_query_bucketed(const pvamd_grid_t* grids, int32_t S, const fl
  * (e.g. Morton order of centroids) is what makes the skipping effective.
  * tri: device [F][3][3] fp32 soup in the order to process.  face_id: device [F] int32 original ids, or NULL for 0..F-1.
  * abs_margin: absolute slack, >= 1e-6 * (largest |vertex coordinate| + bounding-box diagonal).
- * rec_out: device [F][PVAMD_TRI_REC] (16-byte aligned).  tiles_out: device float[PVAMD_TILES_FLOATS(F)].
+ * rec_out: device float[PVAMD_REC_FLOATS(F)] (16-byte aligned).  tiles_out: device float[PVAMD_TILES_FLOATS(F)]
+ * (16-byte aligned).  F <= 2^26.
  * rec_of_face_out: device [F] int32.                                                                            */
 int pvamd_mesh_prepare(const float* tri, const int32_t* face_id, int32_t F, float abs_margin, float* rec_out,
                        float* tiles_out, int32_t* rec_of_face_out, void* stream);

@@ -11,13 +11,18 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("PVAMD_LIB") or os.path.join(_HERE, "csrc", "libpvamd.so")  # PVAMD_LIB: A/B builds (tools/)
 
-ABI_VERSION = 5
+ABI_VERSION = 6
 OOB_LOOKUP_GT_SDF = 0
 OOB_BOUNDING_BOX = 1
 COMPOSED_INLINE_EXACT = 1
 TRI_REC = 24
 TRI_TILE = 256
 TRI_GROUP = 16
+
+
+def rec_floats(F):
+    """PVAMD_REC_FLOATS(F): records are stored in whole tiles."""
+    return ((F + TRI_TILE - 1) // TRI_TILE) * TRI_TILE * TRI_REC
 
 
 def tiles_floats(F):

@@ -19,6 +19,7 @@
 //    in parallel (instead of a per-lane test in front of every visit).
 #include "common.h"
 #include "grid_lookup.h"
+#include "wave_ops.h"
 
 namespace pvamd {
 
@@ -178,21 +179,6 @@ PVAMD_DEV void build_cull_spheres(const pvamd_grid_t* __restrict__ grids, int S,
         cull[s][6] = cull[s][7] = 0.f;
     }
 }
-
-// wave64 min over lanes: v_min_f32 with a DPP source (butterfly within rows of 16, then row broadcasts); the result is
-// read from lane 63.  One vector instruction per step; the s_nop covers the VALU-write -> DPP-read hazard, which the
-// compiler does not track through inline assembly.  NaN inputs are ignored (v_min_f32 returns the other operand).
-#define PVAMD_DPP_MIN(v, ctrl) asm volatile("s_nop 1\n\tv_min_f32_dpp %0, %0, %0 " ctrl : "+v"(v))
-PVAMD_DEV float wave_min(float v) {
-    PVAMD_DPP_MIN(v, "quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf");
-    PVAMD_DPP_MIN(v, "quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf");
-    PVAMD_DPP_MIN(v, "row_half_mirror row_mask:0xf bank_mask:0xf");
-    PVAMD_DPP_MIN(v, "row_mirror row_mask:0xf bank_mask:0xf");
-    PVAMD_DPP_MIN(v, "row_bcast:15 row_mask:0xa bank_mask:0xf");
-    PVAMD_DPP_MIN(v, "row_bcast:31 row_mask:0xc bank_mask:0xf");
-    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
-}
-PVAMD_DEV float wave_max(float v) { return -wave_min(-v); }
 
 // Leaves (bit s of the result) that some point of the wave's 256-point tile may need.  lane = leaf.  `lower` (lane s)
 // = a lower bound of leaf s's value over the whole tile when the tile is entirely outside the leaf's range, -inf

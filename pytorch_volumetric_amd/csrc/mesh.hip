@@ -5,10 +5,12 @@
 //
 // fp32-VALU bound, not HBM bound.  Structure (details at "The scan" below):
 //   * pvamd_mesh_prepare turns the soup into 96-byte records (bounding sphere, in-plane bounding rectangle, corners,
-//     original face id) + one bounding sphere per group of 16 and per tile of 256 records.
-//   * a block owns 64 points (one per lane) and SLICES waves; a tile of records is staged into LDS once per block and
-//     its groups are dealt round-robin to the waves (small P -> many slices so the 1024 SIMDs still fill; very small
-//     P -> the tiles of a point group are spread over several blocks as well).
+//     original face id), stored per tile of 256 as six planes of float4, + one bounding sphere per group of 16 and per
+//     tile of 256 records.
+//   * a block owns 64 neighbouring points (one per lane) and SLICES waves; every wave walks its own share of the tiles
+//     without barriers.  The broad phase runs with lanes = tiles, then lanes = records, against a sphere around the
+//     block's points: 64 bounds per vector instruction instead of one; only the few records that survive are tested
+//     per point (very small P -> the tiles of a point group are spread over several blocks as well).
 //   * conservative culling, tile -> group -> record sphere -> rectangle: a record is skipped when it provably cannot
 //     lower a lane's best d^2 nor be hit by its ray.  The survivors are queued as (record, point) pairs and the exact
 //     tests (the oracle's operation sequences) run densely over the queue.  Bit-identical to the plain double loop of
@@ -17,21 +19,30 @@
 #include "common.h"
 #include "mesh_math.h"
 #include "morton.h"
+#include "wave_ops.h"
 
 namespace pvamd {
 
 constexpr int kRec = PVAMD_TRI_REC;      // floats per record
-constexpr int kTile = PVAMD_TRI_TILE;    // records per tile: 256 * 96 B = 24 KB of LDS
+constexpr int kTile = PVAMD_TRI_TILE;    // records per tile: 256 * 96 B = 24 KB
 constexpr int kGroup = PVAMD_TRI_GROUP;  // records per group: own bounding sphere
 constexpr int kGroupsPerTile = kTile / kGroup;
-// record layout (float index):
-//   0-2 ctr, 3 r       bounding sphere (ctr = centre of the in-plane bounding rectangle)
-//   4-6 u,   7 hu      unit vector along the longest edge, half extent of the triangle along it (about ctr)
-//   8-10 v, 11 hv      unit in-plane vector across it, half extent
-//  12-14 a, 15 face id (bits)
-//  16-18 b, 19 m0      m0: absolute slack of the rectangle test (plane fit + rounding of the frame)
-//  20-22 c, 23 0
+static_assert(kTile == 256 && kGroup == 16 && kRec == 24, "the scan is written for 256-record tiles of six float4 planes");
+// A record is six float4s; a tile stores them plane by plane ([plane][256] float4, 24 KB, whole tiles allocated), so that
+// 64 lanes reading the same plane of 64 consecutive records move one contiguous KB:
+//   plane 0  ctr, r       bounding sphere (ctr = centre of the in-plane bounding rectangle)
+//   plane 1  u,   hu      unit vector along the longest edge, half extent of the triangle along it (about ctr)
+//   plane 2  v,   hv      unit in-plane vector across it, half extent
+//   plane 3  a,   face id (bits)
+//   plane 4  b,   m0      m0: absolute slack of the rectangle test (plane fit + rounding of the frame)
+//   plane 5  c,   0
 // `tiles` buffer: [ntiles][4] tile spheres, then [ntiles][16][4] group spheres.
+enum { kPlaneSphere = 0, kPlaneU = 1, kPlaneV = 2, kPlaneA = 3, kPlaneB = 4, kPlaneC = 5 };
+constexpr int kTileFloats = kTile * kRec;
+PVAMD_DEV const f32x4* tile_plane(const float* rec, int tile, int plane) {
+    return reinterpret_cast<const f32x4*>(rec + (int64_t)tile * kTileFloats + plane * (kTile * 4));
+}
+PVAMD_DEV f32x4 record_plane(const float* rec, int j, int plane) { return tile_plane(rec, j / kTile, plane)[j % kTile]; }
 
 struct MeshArgs {
     const float* normal;
@@ -60,8 +71,13 @@ PVAMD_DEV double dmin3(double a, double b, double c) { return fmin(a, fmin(b, c)
 
 __global__ __launch_bounds__(256) void mesh_prepare_records(const float* __restrict__ tri, const int* __restrict__ face_id,
                                                             int F, float abs_margin, float* __restrict__ rec) {
-    const int f = blockIdx.x * blockDim.x + threadIdx.x;
-    if (f >= F) return;
+    const int f = blockIdx.x * blockDim.x + threadIdx.x;  // one block per tile
+    f32x4* o = reinterpret_cast<f32x4*>(rec + (int64_t)blockIdx.x * kTileFloats) + threadIdx.x;
+    if (f >= F) {  // padding of the last tile: never a candidate (the kernels mask by F), but defined memory
+        const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+        for (int pl = 0; pl < 6; ++pl) o[pl * kTile] = zero;
+        return;
+    }
     const float* t = tri + 9 * (int64_t)f;
     const D3 A = d3(t[0], t[1], t[2]), B = d3(t[3], t[4], t[5]), C = d3(t[6], t[7], t[8]);
     // frame: u along the longest edge, n the plane normal, v = n x u
@@ -94,13 +110,12 @@ __global__ __launch_bounds__(256) void mesh_prepare_records(const float* __restr
     const double hv = dmax3(fabs(ddot(Vf, qa)), fabs(ddot(Vf, qb)), fabs(ddot(Vf, qc)));
     const double sl = dmax3(fabs(ddot(Nf, qa)), fabs(ddot(Nf, qb)), fabs(ddot(Nf, qc)));
     const double r = sqrt(dmax3(ddot(qa, qa), ddot(qb, qb), ddot(qc, qc)));
-    float* o = rec + (int64_t)kRec * f;
-    o[0] = cf[0]; o[1] = cf[1]; o[2] = cf[2]; o[3] = (float)(r * 1.00001) + abs_margin;
-    o[4] = uf[0]; o[5] = uf[1]; o[6] = uf[2]; o[7] = (float)(hu * 1.00001) + abs_margin;
-    o[8] = vf[0]; o[9] = vf[1]; o[10] = vf[2]; o[11] = (float)(hv * 1.00001) + abs_margin;
-    o[12] = t[0]; o[13] = t[1]; o[14] = t[2]; o[15] = __int_as_float(face_id ? face_id[f] : f);
-    o[16] = t[3]; o[17] = t[4]; o[18] = t[5]; o[19] = (float)(1.01e6 * sl * sl) + abs_margin * abs_margin;
-    o[20] = t[6]; o[21] = t[7]; o[22] = t[8]; o[23] = 0.f;
+    o[kPlaneSphere * kTile] = f32x4{cf[0], cf[1], cf[2], (float)(r * 1.00001) + abs_margin};
+    o[kPlaneU * kTile] = f32x4{uf[0], uf[1], uf[2], (float)(hu * 1.00001) + abs_margin};
+    o[kPlaneV * kTile] = f32x4{vf[0], vf[1], vf[2], (float)(hv * 1.00001) + abs_margin};
+    o[kPlaneA * kTile] = f32x4{t[0], t[1], t[2], __int_as_float(face_id ? face_id[f] : f)};
+    o[kPlaneB * kTile] = f32x4{t[3], t[4], t[5], (float)(1.01e6 * sl * sl) + abs_margin * abs_margin};
+    o[kPlaneC * kTile] = f32x4{t[6], t[7], t[8], 0.f};
 }
 
 // sphere around the mean of `width` consecutive lanes' record centres, radius = max(|c_i - mean| + r_i), inflated
@@ -129,8 +144,8 @@ __global__ __launch_bounds__(256) void mesh_prepare_tiles(const float* __restric
     const int tile = blockIdx.x, ntiles = gridDim.x;
     const int f = tile * kTile + threadIdx.x;
     const bool live = f < F;
-    const float* o = rec + (int64_t)kRec * (live ? f : (F - 1));
-    const float cx = o[0], cy = o[1], cz = o[2], r = o[3];
+    const f32x4 o = tile_plane(rec, tile, kPlaneSphere)[live ? threadIdx.x : 0];
+    const float cx = o.x, cy = o.y, cz = o.z, r = o.w;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     float g[4];
     enclose(live, cx, cy, cz, r, kGroup, abs_margin, g);
@@ -204,12 +219,12 @@ PVAMD_DEV bool sphere_may_hit(float dist2, float tp, float r) {
 // the corners from the frame's plane (m0 = 1e6 s^2: 2|w|s <= 1e-6 |w|^2 + 1e6 s^2); hu, hv and m0 were computed in
 // float64 for exactly the rounded ctr/u/v stored here (mesh_prepare_records).  Unlike the sphere this stays tight for
 // long, thin and large triangles.  Any NaN/inf makes the comparison false: the pair is kept.
-PVAMD_DEV bool rect_may_improve(const LaneState& s, V3 w, float dist2, const float* __restrict__ o) {
-    const float u = dot(v3(o[4], o[5], o[6]), w), v = dot(v3(o[8], o[9], o[10]), w);
+PVAMD_DEV bool rect_may_improve(const LaneState& s, V3 w, float dist2, V3 fu, float hu, V3 fv, float hv, float m0) {
+    const float u = dot(fu, w), v = dot(fv, w);
     const float h2 = fmaxf(fmaf(-v, v, fmaf(-u, u, dist2)), 0.f);
-    const float du = fmaxf(fabsf(u) - o[7], 0.f), dv = fmaxf(fabsf(v) - o[11], 0.f);
+    const float du = fmaxf(fabsf(u) - hu, 0.f), dv = fmaxf(fabsf(v) - hv, 0.f);
     const float lb2 = fmaf(dv, dv, fmaf(du, du, h2));
-    return !(lb2 > fmaf(8e-6f, dist2, s.reach2m + o[19]));
+    return !(lb2 > fmaf(8e-6f, dist2, s.reach2m + m0));
 }
 
 #ifdef PVAMD_MESH_STATS
@@ -225,64 +240,151 @@ extern "C" int pvamd_debug_stats(unsigned long long* out, int reset) {
 #endif
 
 // ---------------------------------------------------------------------------------------------------------------
-// The scan.  One block = 64 points (one per lane) x SLICES waves that all hold the same 64 points.
-//   seed    every wave bounds the distance to the mesh from its share of the tile spheres (min over tiles of
-//           |p - ctr| + r: each sphere contains a whole triangle); the merged bound seeds `reach`, and the tiles
-//           nearest to lane 0 / lane 63 (the two ends of a Morton-sorted run of points) are visited first, which
-//           tightens reach to about the true distance before anything else is looked at.
-//   vote    one pass over the remaining tile spheres, split across the waves, flags the tiles some lane still needs
-//           (closer than reach, or crossed by the lane's ray) in an LDS bit mask; unflagged tiles cost nothing more.
-//   visit   a flagged tile is staged into LDS by the whole block (2 barriers); groups of 16 records are dealt
-//           round-robin to the waves; group sphere, then record spheres, wave-uniform (LDS broadcast reads).
-//   narrow  the broad phase only QUEUES (record, point) pairs -- per wave, in LDS, one queue for closest-point pairs
-//           and one for ray pairs.  Whenever 64 are waiting the wave runs them densely: lane i takes pair i, whichever
-//           point and record that is (typically ~10-60 % of the lanes of a wave need a given record, so running the
-//           exact test per record would idle the rest).  Results fold into per-point LDS slots shared by all waves:
-//           a 64-bit atomicMin on (d2 bits << 32 | face id) IS the lexicographic "smallest d2, lowest original face
-//           id" rule (d2 >= +0, so its bit pattern orders like the float; a NaN sorts above +inf and never wins), hit
-//           counts by atomicAdd.  After a drain every lane tightens its reach from the shared slot, so the waves help
-//           each other cull.
+// The scan.  One block = 64 points (one per lane; the caller passes a Morton order, so they are neighbours in space) x
+// SLICES waves that all hold the same 64 points.  Wave w walks the tiles ti % SLICES == w on its own -- no barrier between
+// the one that publishes the rays and the one before the results are read; the waves only meet in the per-point result
+// slots (LDS atomics), from which each keeps pulling the others' finds, and every wave-uniform quantity sits in SGPRs.  (A
+// point group near the medial axis needs most of the mesh; spreading its tiles over the waves bounds that tail.)
+//   bound   the wave keeps a sphere (c, rho) around its live points and Q = max reach + rho.  Whatever a lane still
+//           needs lies within Q of c: |p - ctr| >= |c - ctr| - rho, and the distance to a rectangle is 1-Lipschitz in p.
+//           The same holds for the rays: all lanes shoot within `chord` of one direction, so a sphere missed by the
+//           axis ray through c by more than r + rho + 2 chord (|w| + rho) is missed by every lane's ray.
+//   tiles   lanes = TILES (64 tile spheres per pass): one evaluation of the sphere test at (c, Q) answers "does any
+//           lane need this tile" for 64 tiles at once; the nearest tile is visited first, which brings every reach
+//           down to about the true distance, then the flagged tiles in index order, re-flagged after every visit.
+//   records lanes = RECORDS (64 per pass, 4 passes per tile, skipped per pass through the 16 group spheres): sphere
+//           test + rectangle test at (c, Q) + ray test about the axis, on coalesced 16-byte loads of the tile's planes.
+//           Only the survivors (typically a few per cent) are looked at per point: their filter data goes through a
+//           wave-private LDS slice and is read back wave-uniformly (LDS broadcast), one survivor at a time, for the
+//           per-lane sphere / rectangle / ray tests, lanes = POINTS.
+//   narrow  the per-point tests only QUEUE (record, point) pairs -- per wave, in LDS, one queue for closest-point pairs
+//           and one for ray pairs, entries = global record index << 6 | owner lane, so a queue outlives the tile it was
+//           filled from.  Whenever 64 are waiting the wave runs them densely: lane i takes pair i, gathers the three
+//           corners from the record planes and its owner's point through ds_bpermute.  Results fold into per-point LDS
+//           slots: a 64-bit atomicMin on (d2 bits << 32 | face id) IS the lexicographic "smallest d2, lowest original
+//           face id" rule (d2 >= +0, so its bit pattern orders like the float; a NaN sorts above +inf and never wins),
+//           hit counts by atomicAdd.  After a drain every lane tightens its reach and the wave its Q.
 // A skipped record provably cannot lower a lane's best d^2 nor be hit by its ray, min and + are order-free, so the
-// results are bit-identical to the plain double loop of oracle/pvamd_oracle.c.
+// results are bit-identical to the plain double loop of oracle/pvamd_oracle.c.  A point with a NaN or infinite
+// coordinate can neither find a finite d^2 nor hit anything (every product with it is inf or NaN): such lanes are
+// "dead", take no part in the bounds and come out as (no face, 0 hits), as they do from the double loop.
 // ---------------------------------------------------------------------------------------------------------------
-constexpr int kQueueCap = 128;     // entries per queue per wave (uint16: record << 6 | owner lane); < 64 + 64 in use
-constexpr int kVoteTiles = 2048;   // tiles per vote pass (64 mask words)
+constexpr int kQueueCap = 128;       // entries per queue (u32: record << 6 | owner lane); < 64 + 64 in use
 constexpr unsigned long long kBestInit = 0x7F80000000000000ull;  // (+inf, face 0): a finite candidate always wins
 
-struct MeshShared {
-    float tile[kTile * kRec];  // doubles as [SLICES][64] u64 scratch for the seed merge before the first tile
-    float group[kGroupsPerTile * 4];
+template <bool WITH_RAY>
+struct WaveLocal {                      // private to one wave
+    f32x4 sphere[64], fu[64], fv[64];   // filter planes of the current pass of 64 records
+    float m0[64];
+    unsigned qc[kQueueCap];
+    unsigned qr[WITH_RAY ? kQueueCap : 1];
+};
+template <bool WITH_RAY>
+struct GroupShared {                    // the per-point slots all waves of the point group fold into
     unsigned long long best[64];
-    int hits[64];
-    float pt[64 * 3];
-    float dir[64 * 3];  // jittered ray direction (exact test)
-    float dn[64 * 3];   // its unit vector (sphere tests)
-    unsigned mask[kVoteTiles / 32];
+    int hits[WITH_RAY ? 64 : 1];
+    float dir[WITH_RAY ? 192 : 1];      // jittered ray direction (exact test), computed once by wave 0
+    float dn[WITH_RAY ? 192 : 1];       // its unit vector (sphere tests)
+};
+template <int SLICES, bool WITH_RAY>
+struct MeshShared {
+    GroupShared<WITH_RAY> g;
+    WaveLocal<WITH_RAY> w[SLICES];
 };
 
+PVAMD_DEV float uniform(float v) { return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v))); }
+PVAMD_DEV V3 xyz(f32x4 v) { return v3(v.x, v.y, v.z); }
+
+struct WaveBound {   // wave-uniform
+    LaneState q;     // p = c (centre of the live points' box), reach = Q = (max reach + rho), inflated
+    float rho;       // max |p - c| over the live lanes, inflated
+    V3 dn0;          // unit axis of the rays
+    float k, rho_k;  // 2.001 * max |dn_lane - dn0|;  rho * (1 + k)
+};
+
+template <bool WITH_RAY>
+struct Wave {
+    LaneState s;  // per lane
+    bool live;
+    V3 dn, dir;   // unit / exact ray direction (WITH_RAY)
+    WaveBound wb;
+    int nc, nr;   // queue fills (wave-uniform)
+};
+
+template <bool WITH_RAY>
+PVAMD_DEV void refresh_bound(Wave<WITH_RAY>& wv) {
+    const float rmax = wave_max(wv.live ? wv.s.reach : 0.f);
+    set_reach(wv.wb.q, uniform((rmax + wv.wb.rho) * 1.00001f));
+}
+
+// tighten this lane's reach from its result slot (other waves' finds included), then the wave's bound
+template <bool WITH_RAY>
+PVAMD_DEV void pull_reach(const GroupShared<WITH_RAY>& g, Wave<WITH_RAY>& wv) {
+    const float d2 = __int_as_float((int)(unsigned)(g.best[threadIdx.x & 63] >> 32));
+    const float reach = fast_sqrt(d2) * 1.00001f + 1.1e-19f;  // 1 ulp + the flushed denormals; inf while nothing was found
+    if (reach < wv.s.reach) set_reach(wv.s, reach);
+    refresh_bound(wv);
+}
+
+// per-wave setup once the lanes hold their points (and rays): dead lanes, (c, rho), the ray axis
+template <bool WITH_RAY>
+PVAMD_DEV bool wave_setup(const MeshArgs& m, Wave<WITH_RAY>& wv) {
+    const V3 p = wv.s.p;
+    wv.live = fabsf(p.x) < INFINITY && fabsf(p.y) < INFINITY && fabsf(p.z) < INFINITY;
+    wv.nc = wv.nr = 0;
+    set_reach(wv.s, INFINITY);
+    if (__ballot(wv.live) == 0ull) return false;
+    const float lx = wave_min(wv.live ? p.x : INFINITY), hx = wave_max(wv.live ? p.x : -INFINITY);
+    const float ly = wave_min(wv.live ? p.y : INFINITY), hy = wave_max(wv.live ? p.y : -INFINITY);
+    const float lz = wave_min(wv.live ? p.z : INFINITY), hz = wave_max(wv.live ? p.z : -INFINITY);
+    wv.wb.q.p = v3(uniform(0.5f * lx + 0.5f * hx), uniform(0.5f * ly + 0.5f * hy), uniform(0.5f * lz + 0.5f * hz));
+    const V3 d = v3(p.x - wv.wb.q.p.x, p.y - wv.wb.q.p.y, p.z - wv.wb.q.p.z);
+    wv.wb.rho = uniform(wave_max(wv.live ? fast_sqrt(dot(d, d)) : 0.f) * 1.00001f + 1.1e-19f);
+    wv.wb.dn0 = v3(0.f, 0.f, 0.f);
+    wv.wb.k = wv.wb.rho_k = 0.f;
+    if (WITH_RAY) {
+        const V3 a = v3((float)m.ray_dir[0], (float)m.ray_dir[1], (float)m.ray_dir[2]);
+        const float inv = 1.f / sqrt_rn(dot(a, a));
+        wv.wb.dn0 = v3(uniform(a.x * inv), uniform(a.y * inv), uniform(a.z * inv));
+        const V3 e = v3(wv.dn.x - wv.wb.dn0.x, wv.dn.y - wv.wb.dn0.y, wv.dn.z - wv.wb.dn0.z);
+        const float chord = wave_max(wv.live ? fast_sqrt(dot(e, e)) : 0.f);  // a NaN (zero direction) is ignored: it hits nothing
+        wv.wb.k = uniform(2.001f * chord + 2e-6f);
+        wv.wb.rho_k = uniform(wv.wb.rho * (1.f + wv.wb.k) * 1.00001f);
+    }
+    set_reach(wv.wb.q, INFINITY);
+    return true;
+}
+
+// may the axis ray, widened by everything the lanes' own rays can differ from it, cross the sphere (w = ctr - c, r)?
+PVAMD_DEV bool axis_may_hit(const WaveBound& wb, V3 w, float dist2, float r) {
+    const float dist = fast_sqrt(dist2) * 1.00001f + 1.1e-19f;
+    return sphere_may_hit(dist2, dot(w, wb.dn0), fmaf(wb.k, dist, r + wb.rho_k));
+}
+
 // enqueue the lanes of `mask` for record j (wave-uniform j): the k-th set lane writes slot n + k
-PVAMD_DEV void enqueue(unsigned short* q, int& n, unsigned long long mask, bool mine, int j) {
+PVAMD_DEV void enqueue(unsigned* q, int& n, unsigned long long mask, bool mine, int j) {
     const int lane = threadIdx.x & 63;
-    if (mine) q[n + __popcll(mask & ((1ull << lane) - 1ull))] = (unsigned short)((j << 6) | lane);
+    if (mine) q[n + __popcll(mask & ((1ull << lane) - 1ull))] = ((unsigned)j << 6) | (unsigned)lane;
     n += __popcll(mask);
 }
 
-// Run fn(entry) densely over the queue: always the first (up to) 64 entries; the remainder (n - 64 < 64 by
+// Run fn(count, entries) densely over the queue: always the first (up to) 64 entries; the remainder (n - 64 < 64 by
 // construction) too when `everything`, else it moves to the front and waits for more company.
 template <class Fn>
-PVAMD_DEV void drain(unsigned short* q, int& n, bool everything, Fn&& fn) {
+PVAMD_DEV void drain(unsigned* q, int& n, bool everything, Fn&& fn) {
     const int lane = threadIdx.x & 63;
     PVAMD_WAVE_SYNC();  // entries were written by other lanes
     STAT(6, 1);
-    if (lane < n) fn((unsigned)q[lane]);
+    fn(n < 64 ? n : 64, q);
     if (n > 64) {
         const int rem = n - 64;
-        const unsigned v = lane < rem ? (unsigned)q[64 + lane] : 0u;
         if (everything) {
-            if (lane < rem) fn(v);
+            STAT(6, 1);
+            fn(rem, q + 64);
             n = 0;
         } else {
-            if (lane < rem) q[lane] = (unsigned short)v;
+            const unsigned v = lane < rem ? q[64 + lane] : 0u;
+            if (lane < rem) q[lane] = v;
             n = rem;
         }
     } else {
@@ -291,204 +393,251 @@ PVAMD_DEV void drain(unsigned short* q, int& n, bool everything, Fn&& fn) {
     PVAMD_WAVE_SYNC();
 }
 
-PVAMD_DEV void drain_closest(MeshShared& sh, unsigned short* q, int& n, bool everything, LaneState& s) {
-    if (n == 0) return;
-    drain(q, n, everything, [&](unsigned e) {
-        const float* o = sh.tile + kRec * (e >> 6);
-        const int owner = e & 63;
-        const V3 p = v3(sh.pt[3 * owner], sh.pt[3 * owner + 1], sh.pt[3 * owner + 2]);
-        const V3 c = closest_point_triangle(p, v3(o[12], o[13], o[14]), v3(o[16], o[17], o[18]), v3(o[20], o[21], o[22]));
-        const V3 g = sub(c, p);
-        const float d2 = dot(g, g);
-        atomicMin(&sh.best[owner],
-                  ((unsigned long long)(unsigned)__float_as_int(d2) << 32) | (unsigned)__float_as_int(o[15]));
-    });
-    // tighten this lane's reach from the block-shared slot (other waves' finds included)
-    const float d2 = __int_as_float((int)(unsigned)(sh.best[threadIdx.x & 63] >> 32));
-    const float reach = sqrt_rn(d2) * 1.00001f;
-    if (reach < s.reach) set_reach(s, reach);
-}
-
-PVAMD_DEV void drain_rays(MeshShared& sh, unsigned short* q, int& n, bool everything) {
-    if (n == 0) return;
-    drain(q, n, everything, [&](unsigned e) {
-        const float* o = sh.tile + kRec * (e >> 6);
-        const int owner = e & 63;
-        const V3 p = v3(sh.pt[3 * owner], sh.pt[3 * owner + 1], sh.pt[3 * owner + 2]);
-        const V3 d = v3(sh.dir[3 * owner], sh.dir[3 * owner + 1], sh.dir[3 * owner + 2]);
-        if (ray_hits_triangle(p, d, v3(o[12], o[13], o[14]), v3(o[16], o[17], o[18]), v3(o[20], o[21], o[22])))
-            atomicAdd(&sh.hits[owner], 1);
-    });
-}
-
-// does any lane of this wave still need tile ti?  (ti wave-uniform: scalar loads)
 template <bool WITH_RAY>
-PVAMD_DEV bool wave_needs_tile(const MeshArgs& m, int ti, const LaneState& s, V3 dn) {
-    const float* ts = m.tiles + 4 * (int64_t)ti;
-    const V3 wt = v3(ts[0] - s.p.x, ts[1] - s.p.y, ts[2] - s.p.z);
-    const float tdist2 = dot(wt, wt);
-    bool need = sphere_may_improve(s, tdist2, ts[3]);
-    if (WITH_RAY) need = need || sphere_may_hit(tdist2, dot(wt, dn), ts[3]);
-    return __any(need);
+PVAMD_DEV void drain_closest(const MeshArgs& m, GroupShared<WITH_RAY>& g, WaveLocal<WITH_RAY>& wl, Wave<WITH_RAY>& wv, bool everything) {
+    if (wv.nc == 0) return;
+    const int lane = threadIdx.x & 63;
+    drain(wl.qc, wv.nc, everything, [&](int count, const unsigned* q) {
+        const unsigned e = lane < count ? q[lane] : 0u;
+        const int owner = e & 63;
+        const V3 p = v3(__shfl(wv.s.p.x, owner, 64), __shfl(wv.s.p.y, owner, 64), __shfl(wv.s.p.z, owner, 64));
+        if (lane < count) {
+            const int j = (int)(e >> 6);
+            const f32x4 A = record_plane(m.rec, j, kPlaneA), B = record_plane(m.rec, j, kPlaneB), C = record_plane(m.rec, j, kPlaneC);
+            const V3 qp = sub(closest_point_triangle(p, xyz(A), xyz(B), xyz(C)), p);
+            const float d2 = dot(qp, qp);
+            atomicMin(&g.best[owner], ((unsigned long long)(unsigned)__float_as_int(d2) << 32) | (unsigned)__float_as_int(A.w));
+        }
+    });
+    pull_reach(g, wv);
 }
 
-// Stage tile ti into LDS and run this wave's share of it.  Entry: nobody still reads the previous tile.  Exit: ditto.
-template <int SLICES, bool WITH_RAY>
-PVAMD_DEV void visit_tile(const MeshArgs& m, MeshShared& sh, int ti, int wave, unsigned short* qc, unsigned short* qr,
-                          LaneState& s, V3 dn) {
-    STAT(1, wave == 0);
+template <bool WITH_RAY>
+PVAMD_DEV void drain_rays(const MeshArgs& m, GroupShared<WITH_RAY>& g, WaveLocal<WITH_RAY>& wl, Wave<WITH_RAY>& wv, bool everything) {
+    if (wv.nr == 0) return;
+    const int lane = threadIdx.x & 63;
+    drain(wl.qr, wv.nr, everything, [&](int count, const unsigned* q) {
+        const unsigned e = lane < count ? q[lane] : 0u;
+        const int owner = e & 63;
+        const V3 p = v3(__shfl(wv.s.p.x, owner, 64), __shfl(wv.s.p.y, owner, 64), __shfl(wv.s.p.z, owner, 64));
+        const V3 d = v3(__shfl(wv.dir.x, owner, 64), __shfl(wv.dir.y, owner, 64), __shfl(wv.dir.z, owner, 64));
+        if (lane < count) {
+            const int j = (int)(e >> 6);
+            const f32x4 A = record_plane(m.rec, j, kPlaneA), B = record_plane(m.rec, j, kPlaneB), C = record_plane(m.rec, j, kPlaneC);
+            if (ray_hits_triangle(p, d, xyz(A), xyz(B), xyz(C))) atomicAdd(&g.hits[owner], 1);
+        }
+    });
+}
+
+// One tile: group spheres -> record passes at (c, Q) -> survivors per point -> queues.
+template <bool WITH_RAY>
+PVAMD_DEV void visit_tile(const MeshArgs& m, GroupShared<WITH_RAY>& g, WaveLocal<WITH_RAY>& wl, Wave<WITH_RAY>& wv, int ti,
+                          int pass_lo = 0, int pass_hi = kTile / 64) {
+    const int lane = threadIdx.x & 63;
+    const int ntiles = (m.F + kTile - 1) / kTile;
     const int n = min(kTile, m.F - ti * kTile);
+    STAT(1, 1);
+    unsigned gm = 0u;
     {
-        const f32x4* src = reinterpret_cast<const f32x4*>(m.rec + (int64_t)kRec * kTile * ti);
-        f32x4_alias* dst = reinterpret_cast<f32x4_alias*>(sh.tile);
-        for (int k = threadIdx.x; k < n * (kRec / 4); k += 64 * SLICES) dst[k] = src[k];
-        if (threadIdx.x < kGroupsPerTile * 4)
-            sh.group[threadIdx.x] = m.tiles[4 * (int64_t)((m.F + kTile - 1) / kTile) + (int64_t)ti * kGroupsPerTile * 4 + threadIdx.x];
-    }
-    __syncthreads();
-    if (wave_needs_tile<WITH_RAY>(m, ti, s, dn)) {  // reach may have tightened since the vote
-        STAT(2, 1);
-        int nc = 0, nr = 0;
-        for (int g0 = wave * kGroup; g0 < n; g0 += SLICES * kGroup) {
-            const float* og = sh.group + 4 * (g0 / kGroup);  // wave-uniform addresses below: LDS broadcast reads
-            const V3 wg = v3(og[0] - s.p.x, og[1] - s.p.y, og[2] - s.p.z);
-            const float rg = og[3];
-            const float gdist2 = dot(wg, wg);
-            bool gneed = sphere_may_improve(s, gdist2, rg);
-            if (WITH_RAY) gneed = gneed || sphere_may_hit(gdist2, dot(wg, dn), rg);
+        // lanes = groups: the 16 group spheres at (c, Q) ...
+        const bool gv = lane < kGroupsPerTile && lane * kGroup < n;
+        const f32x4 gs = reinterpret_cast<const f32x4*>(m.tiles)[ntiles + ti * kGroupsPerTile + (gv ? lane : 0)];
+        const V3 wc = v3(gs.x - wv.wb.q.p.x, gs.y - wv.wb.q.p.y, gs.z - wv.wb.q.p.z);
+        const float dc2 = dot(wc, wc);
+        bool coarse = sphere_may_improve(wv.wb.q, dc2, gs.w);
+        if (WITH_RAY) coarse = coarse || axis_may_hit(wv.wb, wc, dc2, gs.w);
+        unsigned todo = (unsigned)__ballot(coarse && gv);
+        todo &= ((1u << (pass_hi * (64 / kGroup))) - 1u) & ~((1u << (pass_lo * (64 / kGroup))) - 1u);  // this wave's passes
+        // ... then, for the ones that pass, lanes = points: does any lane need the group?  (sphere of group b from lane b)
+        while (todo != 0u) {
+            const int b = __builtin_ctz(todo);
+            todo &= todo - 1u;
+            const V3 ctr = v3(__int_as_float(__builtin_amdgcn_readlane(__float_as_int(gs.x), b)),
+                              __int_as_float(__builtin_amdgcn_readlane(__float_as_int(gs.y), b)),
+                              __int_as_float(__builtin_amdgcn_readlane(__float_as_int(gs.z), b)));
+            const float r = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(gs.w), b));
+            const V3 w = v3(ctr.x - wv.s.p.x, ctr.y - wv.s.p.y, ctr.z - wv.s.p.z);
+            const float dist2 = dot(w, w);
+            bool need = sphere_may_improve(wv.s, dist2, r);
+            if (WITH_RAY) need = need || sphere_may_hit(dist2, dot(w, wv.dn), r);
             STAT(9, 1);
-            if (!__any(gneed)) continue;
-            const int g1 = min(g0 + kGroup, n);
-            for (int j = g0; j < g1; ++j) {
-                const float* o = sh.tile + kRec * j;
-                const V3 w = v3(o[0] - s.p.x, o[1] - s.p.y, o[2] - s.p.z);
-                const float r = o[3];
-                const float dist2 = dot(w, w);
-                const bool near_c = sphere_may_improve(s, dist2, r);
-                STAT(3, 1);
+            if (__any(need && wv.live)) gm |= 1u << b;
+        }
+    }
+    const f32x4* P0 = tile_plane(m.rec, ti, kPlaneSphere);
+    const f32x4* P1 = tile_plane(m.rec, ti, kPlaneU);
+    const f32x4* P2 = tile_plane(m.rec, ti, kPlaneV);
+    const f32x4* P4 = tile_plane(m.rec, ti, kPlaneB);
+    for (int pass = pass_lo; pass < pass_hi; ++pass) {
+        if (((gm >> (pass * (64 / kGroup))) & ((1u << (64 / kGroup)) - 1u)) == 0u) continue;
+        STAT(2, 1);
+        const int idx = pass * 64 + lane;
+        const f32x4 a0 = P0[idx], a1 = P1[idx], a2 = P2[idx];
+        const float am0 = P4[idx].w;
+        bool keep_c, keep_r = false;
+        {
+            const bool valid = idx < n && ((gm >> (idx / kGroup)) & 1u);
+            const V3 w = v3(a0.x - wv.wb.q.p.x, a0.y - wv.wb.q.p.y, a0.z - wv.wb.q.p.z);
+            const float dist2 = dot(w, w);
+            keep_c = valid && sphere_may_improve(wv.wb.q, dist2, a0.w) &&
+                     rect_may_improve(wv.wb.q, w, dist2, xyz(a1), a1.w, xyz(a2), a2.w, am0);
+            if (WITH_RAY) keep_r = valid && axis_may_hit(wv.wb, w, dist2, a0.w);
+        }
+        const unsigned long long mc = __ballot(keep_c), mr = WITH_RAY ? __ballot(keep_r) : 0ull;
+        unsigned long long todo = mc | mr;
+        if (todo == 0ull) continue;
+        PVAMD_WAVE_SYNC();  // the previous pass's broadcast reads are done
+        wl.sphere[lane] = a0;
+        wl.fu[lane] = a1;
+        wl.fv[lane] = a2;
+        wl.m0[lane] = am0;
+        PVAMD_WAVE_SYNC();
+        const int j0 = ti * kTile + pass * 64;
+        while (todo != 0ull) {
+            const int b = __builtin_ctzll(todo);
+            todo &= todo - 1ull;
+            STAT(3, 1);
+            const f32x4 o = wl.sphere[b];  // wave-uniform address: LDS broadcast
+            const V3 w = v3(o.x - wv.s.p.x, o.y - wv.s.p.y, o.z - wv.s.p.z);
+            const float dist2 = dot(w, w);
+            if ((mc >> b) & 1ull) {
+                const bool near_c = wv.live && sphere_may_improve(wv.s, dist2, o.w);
                 if (__any(near_c)) {
-                    STAT(10, 1);
-                    const bool need_c = near_c && rect_may_improve(s, w, dist2, o);
-                    const unsigned long long mc = __ballot(need_c);
-                    if (mc) {
-                        STAT(4, __popcll(mc)); STAT(7, 1);
-                        enqueue(qc, nc, mc, need_c, j);
-                        if (nc >= 64) drain_closest(sh, qc, nc, false, s);
-                    }
-                }
-                if (WITH_RAY) {
-                    const bool need_r = sphere_may_hit(dist2, dot(w, dn), r);
-                    const unsigned long long mr = __ballot(need_r);
-                    if (mr) {
-                        STAT(5, __popcll(mr)); STAT(8, 1);
-                        enqueue(qr, nr, mr, need_r, j);
-                        if (nr >= 64) drain_rays(sh, qr, nr, false);
+                    STAT(7, 1);
+                    const f32x4 u = wl.fu[b], v = wl.fv[b];
+                    const bool need_c = near_c && rect_may_improve(wv.s, w, dist2, xyz(u), u.w, xyz(v), v.w, wl.m0[b]);
+                    const unsigned long long mk = __ballot(need_c);
+                    if (mk) {
+                        STAT(4, __popcll(mk)); STAT(8, 1);
+                        enqueue(wl.qc, wv.nc, mk, need_c, j0 + b);
+                        if (wv.nc >= 64) drain_closest(m, g, wl, wv, false);
                     }
                 }
             }
+            if (WITH_RAY && ((mr >> b) & 1ull)) {
+                const bool need_r = wv.live && sphere_may_hit(dist2, dot(w, wv.dn), o.w);
+                const unsigned long long mk = __ballot(need_r);
+                if (mk) {
+                    STAT(5, __popcll(mk)); STAT(8, 1);
+                    enqueue(wl.qr, wv.nr, mk, need_r, j0 + b);
+                    if (wv.nr >= 64) drain_rays(m, g, wl, wv, false);
+                }
+            }
         }
-        // the tile is about to be replaced: finish everything that points into it
-        drain_closest(sh, qc, nc, true, s);
-        if (WITH_RAY) drain_rays(sh, qr, nr, true);
     }
-    __syncthreads();
 }
 
-// seed (see above): sets s.reach, returns the two tiles to visit first.  On entry: s.p set by every wave; wave 0 has
-// filled sh.pt / sh.dir / sh.dn (no barrier needed yet).  Initialises sh.best / sh.hits; two barriers inside.
-template <int SLICES, bool WITH_RAY>
-PVAMD_DEV void scan_seed(const MeshArgs& m, MeshShared& sh, LaneState& s, V3& dn, int& first0, int& first1) {
+// Upper bound on every live lane's distance to the mesh from the tile spheres (each contains whole triangles):
+// min over ALL tiles of |c - ctr| + r, plus rho.  Returns the nearest of the wave's OWN tiles (ti % nparts == part) -- the
+// one it visits first -- or -1 when it owns none.
+template <bool WITH_RAY>
+PVAMD_DEV int scan_seed(const MeshArgs& m, Wave<WITH_RAY>& wv, int part, int nparts) {
     const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int ntiles = (m.F + kTile - 1) / kTile;
-    {
-        float bound = INFINITY;
-        int nearest = 0;
-        for (int ti = wave; ti < ntiles; ti += SLICES) {
-            const float* ts = m.tiles + 4 * (int64_t)ti;
-            const V3 w = v3(ts[0] - s.p.x, ts[1] - s.p.y, ts[2] - s.p.z);
-            const float b = fast_sqrt(dot(w, w)) * 1.00001f + (ts[3] + 1.1e-19f);  // slack: 1 ulp + the flushed denormals
-            if (b < bound) {  // a NaN point never passes: keeps INFINITY / tile 0
-                bound = b;
+    const f32x4* tiles4 = reinterpret_cast<const f32x4*>(m.tiles);
+    float bound = INFINITY, own = INFINITY;
+    int nearest = -1;
+    for (int base = 0; base < ntiles; base += 64) {
+        const int ti = base + lane;
+        if (ti < ntiles) {
+            const f32x4 ts = tiles4[ti];
+            const V3 w = v3(ts.x - wv.wb.q.p.x, ts.y - wv.wb.q.p.y, ts.z - wv.wb.q.p.z);
+            const float b = fast_sqrt(dot(w, w)) * 1.00001f + (ts.w + 1.1e-19f);  // slack: 1 ulp + the flushed denormals
+            bound = fminf(bound, b);  // a NaN never lowers it
+            if ((nparts == 1 || (ti % nparts) == part) && (b < own || nearest < 0)) {
+                own = b < own ? b : own;
                 nearest = ti;
             }
         }
-        unsigned long long* scratch = reinterpret_cast<unsigned long long*>(sh.tile);
-        scratch[wave * 64 + lane] = ((unsigned long long)(unsigned)__float_as_int(bound) << 32) | (unsigned)nearest;
-        if (wave == 0) {
-            sh.best[lane] = kBestInit;
-            sh.hits[lane] = 0;
+    }
+    const float lowest = wave_min(bound);
+    set_reach(wv.s, (lowest + wv.wb.rho) * 1.00001f);
+    refresh_bound(wv);
+    const float mine = wave_min(own);
+    unsigned long long at = __ballot(nearest >= 0 && own == mine);
+    if (at == 0ull) at = __ballot(nearest >= 0);  // only NaN bounds: any own tile
+    return at ? __builtin_amdgcn_readlane(nearest, __builtin_ctzll(at)) : -1;
+}
+
+// the tiles ti with ti % nparts == part, `skip` excepted (it was visited before), flagged 64 at a time
+template <bool WITH_RAY>
+PVAMD_DEV void scan_tiles(const MeshArgs& m, GroupShared<WITH_RAY>& g, WaveLocal<WITH_RAY>& wl, Wave<WITH_RAY>& wv, int skip,
+                          int part, int nparts, int pass_lo = 0, int pass_hi = kTile / 64) {
+    const int lane = threadIdx.x & 63;
+    const int ntiles = (m.F + kTile - 1) / kTile;
+    const f32x4* tiles4 = reinterpret_cast<const f32x4*>(m.tiles);
+    for (int base = 0; base < ntiles; base += 64) {
+        const int ti = base + lane;
+        const bool mine = ti < ntiles && ti != skip && (nparts == 1 || (ti % nparts) == part);
+        const f32x4 ts = tiles4[mine ? ti : 0];
+        const V3 w = v3(ts.x - wv.wb.q.p.x, ts.y - wv.wb.q.p.y, ts.z - wv.wb.q.p.z);
+        const float dist2 = dot(w, w);
+        const bool ray = WITH_RAY && mine && axis_may_hit(wv.wb, w, dist2, ts.w);
+        STAT(0, 1);
+        unsigned long long open = ~0ull;  // tiles of this pass not yet decided
+        for (;;) {
+            pull_reach(g, wv);  // what the other waves found in the meantime
+            const bool need = mine && (ray || sphere_may_improve(wv.wb.q, dist2, ts.w));  // Q only ever shrinks
+            const unsigned long long todo = __ballot(need) & open;
+            if (todo == 0ull) break;
+            const int t = __builtin_ctzll(todo);
+            open = t == 63 ? 0ull : (~0ull << (t + 1));
+            visit_tile<WITH_RAY>(m, g, wl, wv, base + t, pass_lo, pass_hi);
+        }
+    }
+}
+
+template <bool WITH_RAY>
+PVAMD_DEV void scan_finish(const MeshArgs& m, GroupShared<WITH_RAY>& g, WaveLocal<WITH_RAY>& wl, Wave<WITH_RAY>& wv) {
+    drain_closest(m, g, wl, wv, true);
+    if (WITH_RAY) drain_rays(m, g, wl, wv, true);
+}
+
+// Block prologue: wave 0 publishes the result slots (and the rays); on return every wave holds its rays and bounds.
+// False when no lane has a finite point (uniform over the block: every wave holds the same points).
+template <bool WITH_RAY>
+PVAMD_DEV bool scan_begin(const MeshArgs& m, GroupShared<WITH_RAY>& g, Wave<WITH_RAY>& wv, int wave, uint64_t seed,
+                          int64_t jitter_index, const unsigned long long* start) {
+    const int lane = threadIdx.x & 63;
+    if (wave == 0) {
+        g.best[lane] = start ? *start : kBestInit;
+        if (WITH_RAY) {
+            g.hits[lane] = 0;
+            const V3 dir = jitter_dir(m.ray_dir, seed, jitter_index);
+            const float inv_len = 1.f / sqrt_rn(dot(dir, dir));
+            g.dir[3 * lane] = dir.x; g.dir[3 * lane + 1] = dir.y; g.dir[3 * lane + 2] = dir.z;
+            g.dn[3 * lane] = dir.x * inv_len; g.dn[3 * lane + 1] = dir.y * inv_len; g.dn[3 * lane + 2] = dir.z * inv_len;
         }
     }
     __syncthreads();
-    {
-        const unsigned long long* scratch = reinterpret_cast<const unsigned long long*>(sh.tile);
-        unsigned long long lo = scratch[lane];
-#pragma unroll
-        for (int w = 1; w < SLICES; ++w) {
-            const unsigned long long v = scratch[w * 64 + lane];
-            lo = v < lo ? v : lo;  // bound >= 0: bit order = float order; ties -> lowest tile index
-        }
-        set_reach(s, __int_as_float((int)(unsigned)(lo >> 32)) * 1.00001f);
-        first0 = __shfl((int)(unsigned)lo, 0, 64);
-        first1 = __shfl((int)(unsigned)lo, 63, 64);
-        if (WITH_RAY) dn = v3(sh.dn[3 * lane], sh.dn[3 * lane + 1], sh.dn[3 * lane + 2]);
+    wv.dir = wv.dn = v3(0.f, 0.f, 0.f);
+    if (WITH_RAY) {
+        wv.dir = v3(g.dir[3 * lane], g.dir[3 * lane + 1], g.dir[3 * lane + 2]);
+        wv.dn = v3(g.dn[3 * lane], g.dn[3 * lane + 1], g.dn[3 * lane + 2]);
     }
-    __syncthreads();  // scratch consumed: the tile buffer may be overwritten
+    return wave_setup(m, wv);
 }
 
-// vote + visit over the tiles ti with ti % nparts == part, first0 / first1 excepted (they were visited before)
+// The whole scan of one block.  On exit (after a barrier): g.best[lane] / g.hits[lane] = result for point `lane`.
 template <int SLICES, bool WITH_RAY>
-PVAMD_DEV void scan_rest(const MeshArgs& m, MeshShared& sh, unsigned short* qc, unsigned short* qr, LaneState& s, V3 dn,
-                         int first0, int first1, int part, int nparts) {
-    const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int ntiles = (m.F + kTile - 1) / kTile;
-    for (int base = 0; base < ntiles; base += kVoteTiles) {
-        const int nwords = (min(kVoteTiles, ntiles - base) + 31) / 32;
-        if (threadIdx.x < kVoteTiles / 32) sh.mask[threadIdx.x] = 0u;
-        __syncthreads();
-        for (int word = 0; word < nwords; ++word) {
-            unsigned bits = 0u;
-            for (int t = wave; t < 32; t += SLICES) {
-                const int ti = base + 32 * word + t;
-                if (ti >= ntiles || ti == first0 || ti == first1) continue;
-                if (nparts > 1 && (ti % nparts) != part) continue;
-                STAT(0, 1);
-                if (wave_needs_tile<WITH_RAY>(m, ti, s, dn)) bits |= 1u << t;
-            }
-            if (bits != 0u && lane == 0) atomicOr(&sh.mask[word], bits);
+PVAMD_DEV void scan_mesh(const MeshArgs& m, MeshShared<SLICES, WITH_RAY>& sh, Wave<WITH_RAY>& wv, int wave, uint64_t seed,
+                         int64_t jitter_index) {
+    if (scan_begin(m, sh.g, wv, wave, seed, jitter_index, nullptr) && m.F > 0) {
+        const int first = scan_seed(m, wv, wave, SLICES);
+        if (first >= 0) {
+            visit_tile<WITH_RAY>(m, sh.g, sh.w[wave], wv, first);
+            drain_closest(m, sh.g, sh.w[wave], wv, true);  // publish what the nearest tile gave before looking further
+            scan_tiles<WITH_RAY>(m, sh.g, sh.w[wave], wv, first, wave, SLICES);
+            scan_finish(m, sh.g, sh.w[wave], wv);
         }
-        __syncthreads();
-        for (int word = 0; word < nwords; ++word) {
-            unsigned todo = __builtin_amdgcn_readfirstlane(sh.mask[word]);
-            while (todo != 0u) {
-                const int t = __ffs(todo) - 1;
-                todo &= todo - 1u;
-                visit_tile<SLICES, WITH_RAY>(m, sh, base + 32 * word + t, wave, qc, qr, s, dn);
-            }
-        }
-        if (base + kVoteTiles < ntiles) __syncthreads();  // every wave has read the mask before it is cleared again
     }
-}
-
-// The whole scan in one block.  On exit (after a barrier): sh.best[lane] / sh.hits[lane] = result for point `lane`.
-template <int SLICES, bool WITH_RAY>
-PVAMD_DEV void scan_mesh(const MeshArgs& m, MeshShared& sh, unsigned short* qc, unsigned short* qr, LaneState& s) {
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    V3 dn = s.p;
-    int first0, first1;
-    scan_seed<SLICES, WITH_RAY>(m, sh, s, dn, first0, first1);
-    if (m.F <= 0) return;
-    visit_tile<SLICES, WITH_RAY>(m, sh, first0, wave, qc, qr, s, dn);
-    if (first1 != first0) visit_tile<SLICES, WITH_RAY>(m, sh, first1, wave, qc, qr, s, dn);
-    scan_rest<SLICES, WITH_RAY>(m, sh, qc, qr, s, dn, first0, first1, 0, 1);
+    __syncthreads();
 }
 
 // the closest point on the winning face, recomputed from its corners (same operations as during the scan)
-PVAMD_DEV V3 closest_on_face(const MeshArgs& m, const float* __restrict__ tri_of_face, V3 p) {
-    const float* o = tri_of_face;
-    return closest_point_triangle(p, v3(o[12], o[13], o[14]), v3(o[16], o[17], o[18]), v3(o[20], o[21], o[22]));
+PVAMD_DEV V3 closest_on_record(const MeshArgs& m, int j, V3 p) {
+    return closest_point_triangle(p, xyz(record_plane(m.rec, j, kPlaneA)), xyz(record_plane(m.rec, j, kPlaneB)),
+                                  xyz(record_plane(m.rec, j, kPlaneC)));
 }
 
 struct QueryOut {
@@ -499,33 +648,17 @@ struct QueryOut {
     float* normal;
 };
 
-// the point this lane owns and (wave 0) the per-point LDS tables incl. the jittered ray
-PVAMD_DEV int64_t load_query_point(const MeshArgs& m, MeshShared& sh, const int* __restrict__ order,
-                                   const float* __restrict__ pts, int64_t P, uint64_t seed, int64_t index_base, bool with_ray,
-                                   LaneState& s) {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int64_t k = (int64_t)blockIdx.x * 64 + lane;  // position in processing order
+// the index (caller order) of the point at position `k` of the processing order
+PVAMD_DEV int64_t point_index(const int* __restrict__ order, int64_t k, int64_t P) {
     const int64_t kk = k < P ? k : (P - 1);
-    const int64_t i = order ? (int64_t)order[kk] : kk;  // spatially sorted processing; outputs stay in caller order
-    s.p = v3(pts[3 * i], pts[3 * i + 1], pts[3 * i + 2]);
-    set_reach(s, INFINITY);
-    if (wave == 0) {  // the other waves read these from LDS
-        sh.pt[3 * lane] = s.p.x; sh.pt[3 * lane + 1] = s.p.y; sh.pt[3 * lane + 2] = s.p.z;
-        if (with_ray) {
-            const V3 dir = jitter_dir(m.ray_dir, seed, index_base + i);
-            const float inv_len = 1.f / sqrt_rn(dot(dir, dir));
-            sh.dir[3 * lane] = dir.x; sh.dir[3 * lane + 1] = dir.y; sh.dir[3 * lane + 2] = dir.z;
-            sh.dn[3 * lane] = dir.x * inv_len; sh.dn[3 * lane + 1] = dir.y * inv_len; sh.dn[3 * lane + 2] = dir.z * inv_len;
-        }
-    }
-    return i;
+    return order ? (int64_t)order[kk] : kk;  // spatially sorted processing; outputs stay in caller order
 }
 
 // sdf.py:139-171 from the winning (d2, face) and the hit count
 PVAMD_DEV void write_query(const MeshArgs& m, const QueryOut& out, int64_t i, V3 p, unsigned long long found, int hits) {
     const int f = (unsigned)(found >> 32) == 0x7F800000u ? -1 : (int)(unsigned)found;
     V3 q = v3(NAN, NAN, NAN);
-    if (f >= 0) q = closest_on_face(m, m.rec + (int64_t)kRec * m.rec_of_face[f], p);
+    if (f >= 0) q = closest_on_record(m, m.rec_of_face[f], p);
     V3 g = sub(q, p);                            // sdf.py:139
     float d = norm3_unfused(g);                  // :141
     if (d > 0.f) g = v3(div_rn(g.x, d), div_rn(g.y, d), div_rn(g.z, d));  // :143-144
@@ -551,26 +684,30 @@ PVAMD_DEV void write_query(const MeshArgs& m, const QueryOut& out, int64_t i, V3
     }
 }
 
+// grid: x = groups of 64 points
 template <int SLICES>
 __global__ __launch_bounds__(64 * SLICES) void mesh_query_kernel(MeshArgs m, const int* __restrict__ order,
                                                                 const float* __restrict__ pts, int64_t P,
                                                                 uint64_t seed, int64_t index_base, QueryOut out) {
-    __shared__ __attribute__((aligned(16))) MeshShared sh;
-    __shared__ unsigned short queue_c[SLICES][kQueueCap], queue_r[SLICES][kQueueCap];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    LaneState s;
-    const int64_t i = load_query_point(m, sh, order, pts, P, seed, index_base, true, s);
-    scan_mesh<SLICES, true>(m, sh, queue_c[wave], queue_r[wave], s);
-    if (wave != 0 || (int64_t)blockIdx.x * 64 + lane >= P) return;
-    write_query(m, out, i, s.p, sh.best[lane], sh.hits[lane]);
+    __shared__ __attribute__((aligned(16))) MeshShared<SLICES, true> sh;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int64_t k = (int64_t)blockIdx.x * 64 + lane;
+    const int64_t i = point_index(order, k, P);
+    Wave<true> wv;
+    wv.s.p = v3(pts[3 * i], pts[3 * i + 1], pts[3 * i + 2]);
+    scan_mesh<SLICES, true>(m, sh, wv, wave, seed, index_base + i);
+    if (wave != 0 || k >= P) return;
+    write_query(m, out, i, wv.s.p, sh.g.best[lane], sh.g.hits[lane]);
 }
 
 // ---- few points: the tiles of one point group are spread over several blocks --------------------------------
-// A block of 64 points walks its flagged tiles one after the other; with only a few hundred blocks in flight that
-// serial walk, not throughput, sets the time.  Three launches instead:
-//   first   (one block per group)      seed + the two nearest tiles -> (d2, face), hit count, first0/first1 to scratch
-//   rest    (nparts blocks per group)  start from the scratch values, vote + visit the tiles ti % nparts == part,
-//                                      fold into scratch with global atomicMin / atomicAdd
+// A wave walks its flagged tiles one after the other; with only a few hundred point groups that serial walk, not
+// throughput, sets the time.  Three launches instead:
+//   first   (one block per group)      seed + the nearest tile, one 64-record pass per wave -> (d2, face), hit count and
+//                                      that tile's index to scratch
+//   rest    (nparts blocks per group)  start from the scratch values; wave w of block y takes the tiles
+//                                      ti % (SLICES * nparts) == y * SLICES + w, the nearest excepted;
+//                                      folds into scratch with global atomicMin / atomicAdd
 //   finish  (one wave per group)       outputs from the scratch values
 // scratch: u64 best[G*64], int hits[G*64], int firsts[G*2], G = ceil(P/64) groups, indexed by processing position.
 struct SplitScratch {
@@ -586,59 +723,51 @@ PVAMD_DEV SplitScratch split_scratch(void* scratch, int64_t groups) {
     return r;
 }
 
-template <int SLICES>
-__global__ __launch_bounds__(64 * SLICES) void mesh_query_first_kernel(MeshArgs m, const int* __restrict__ order,
-                                                                      const float* __restrict__ pts, int64_t P,
-                                                                      uint64_t seed, int64_t index_base, void* scratch) {
-    __shared__ __attribute__((aligned(16))) MeshShared sh;
-    __shared__ unsigned short queue_c[SLICES][kQueueCap], queue_r[SLICES][kQueueCap];
+__global__ __launch_bounds__(64 * (kTile / 64)) void mesh_query_first_kernel(MeshArgs m, const int* __restrict__ order,
+                                                                            const float* __restrict__ pts, int64_t P,
+                                                                            uint64_t seed, int64_t index_base, void* scratch) {
+    constexpr int SLICES = kTile / 64;  // one wave per pass of the tile
+    __shared__ __attribute__((aligned(16))) MeshShared<SLICES, true> sh;
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    LaneState s;
-    load_query_point(m, sh, order, pts, P, seed, index_base, true, s);
-    V3 dn = s.p;
-    int first0, first1;
-    scan_seed<SLICES, true>(m, sh, s, dn, first0, first1);
-    visit_tile<SLICES, true>(m, sh, first0, wave, queue_c[wave], queue_r[wave], s, dn);
-    if (first1 != first0) visit_tile<SLICES, true>(m, sh, first1, wave, queue_c[wave], queue_r[wave], s, dn);
+    const int64_t k = (int64_t)blockIdx.x * 64 + lane;
+    const int64_t i = point_index(order, k, P);
+    Wave<true> wv;
+    wv.s.p = v3(pts[3 * i], pts[3 * i + 1], pts[3 * i + 2]);
+    int first = -1;
+    if (scan_begin(m, sh.g, wv, wave, seed, index_base + i, nullptr)) {
+        first = scan_seed(m, wv, 0, 1);
+        visit_tile<true>(m, sh.g, sh.w[wave], wv, first, wave, wave + 1);
+        scan_finish(m, sh.g, sh.w[wave], wv);
+    }
+    __syncthreads();
     if (wave != 0) return;
     const SplitScratch sc = split_scratch(scratch, gridDim.x);
-    const int64_t k = (int64_t)blockIdx.x * 64 + lane;
-    sc.best[k] = sh.best[lane];
-    sc.hits[k] = sh.hits[lane];
-    if (lane == 0) {
-        sc.firsts[2 * blockIdx.x] = first0;
-        sc.firsts[2 * blockIdx.x + 1] = first1;
-    }
+    sc.best[k] = sh.g.best[lane];
+    sc.hits[k] = sh.g.hits[lane];
+    if (lane == 0) sc.firsts[2 * blockIdx.x] = first;
 }
 
-template <int SLICES>
-__global__ __launch_bounds__(64 * SLICES) void mesh_query_rest_kernel(MeshArgs m, const int* __restrict__ order,
-                                                                     const float* __restrict__ pts, int64_t P,
-                                                                     uint64_t seed, int64_t index_base, void* scratch) {
-    __shared__ __attribute__((aligned(16))) MeshShared sh;
-    __shared__ unsigned short queue_c[SLICES][kQueueCap], queue_r[SLICES][kQueueCap];
+// grid: x = groups of 64 points, y = part; wave w takes the w-th 64-record pass of the block's tiles
+__global__ __launch_bounds__(64 * (kTile / 64)) void mesh_query_rest_kernel(MeshArgs m, const int* __restrict__ order,
+                                                                           const float* __restrict__ pts, int64_t P,
+                                                                           uint64_t seed, int64_t index_base, void* scratch) {
+    constexpr int SLICES = kTile / 64;
+    __shared__ __attribute__((aligned(16))) MeshShared<SLICES, true> sh;
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    LaneState s;
-    load_query_point(m, sh, order, pts, P, seed, index_base, true, s);
-    const SplitScratch sc = split_scratch(scratch, gridDim.x);
     const int64_t k = (int64_t)blockIdx.x * 64 + lane;
+    const int64_t i = point_index(order, k, P);
+    Wave<true> wv;
+    wv.s.p = v3(pts[3 * i], pts[3 * i + 1], pts[3 * i + 2]);
+    const SplitScratch sc = split_scratch(scratch, gridDim.x);
     const unsigned long long start = sc.best[k];
-    if (wave == 0) {
-        sh.best[lane] = start;
-        sh.hits[lane] = 0;
+    if (scan_begin(m, sh.g, wv, wave, seed, index_base + i, &start)) {
+        scan_tiles<true>(m, sh.g, sh.w[wave], wv, sc.firsts[2 * blockIdx.x], (int)blockIdx.y, (int)gridDim.y, wave, wave + 1);
+        scan_finish(m, sh.g, sh.w[wave], wv);
     }
-    {
-        const float reach = sqrt_rn(__int_as_float((int)(unsigned)(start >> 32))) * 1.00001f;  // inf while nothing found
-        set_reach(s, reach);
-    }
-    __syncthreads();
-    const V3 dn = v3(sh.dn[3 * lane], sh.dn[3 * lane + 1], sh.dn[3 * lane + 2]);
-    scan_rest<SLICES, true>(m, sh, queue_c[wave], queue_r[wave], s, dn, sc.firsts[2 * blockIdx.x], sc.firsts[2 * blockIdx.x + 1],
-                            (int)blockIdx.y, (int)gridDim.y);
     __syncthreads();
     if (wave != 0) return;
-    if (sh.best[lane] < start) atomicMin(&sc.best[k], sh.best[lane]);
-    if (sh.hits[lane] != 0) atomicAdd(&sc.hits[k], sh.hits[lane]);
+    if (sh.g.best[lane] < start) atomicMin(&sc.best[k], sh.g.best[lane]);
+    if (sh.g.hits[lane] != 0) atomicAdd(&sc.hits[k], sh.g.hits[lane]);
 }
 
 __global__ __launch_bounds__(64) void mesh_query_finish_kernel(MeshArgs m, const int* __restrict__ order,
@@ -651,36 +780,32 @@ __global__ __launch_bounds__(64) void mesh_query_finish_kernel(MeshArgs m, const
     write_query(m, out, i, v3(pts[3 * i], pts[3 * i + 1], pts[3 * i + 2]), sc.best[k], sc.hits[k]);
 }
 
-// grid: x = tiles of 64 points, y = transform b
+// grid: x = groups of 64 points, y = transform b
 template <int SLICES>
 __global__ __launch_bounds__(64 * SLICES) void chamfer_mesh_kernel(MeshArgs m, const int* __restrict__ order,
                                                                   const float* __restrict__ W,
                                                                   const float* __restrict__ pts, int64_t N, float scale,
                                                                   double* __restrict__ out_sum) {
-    __shared__ __attribute__((aligned(16))) MeshShared sh;
-    __shared__ unsigned short queue_c[SLICES][kQueueCap];
+    __shared__ __attribute__((aligned(16))) MeshShared<SLICES, false> sh;
     const float* M = W + 16 * (int64_t)blockIdx.y;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int64_t k = (int64_t)blockIdx.x * 64 + lane;
     const bool live = k < N;
-    const int64_t kk = live ? k : (N - 1);
-    const int64_t ii = order ? (int64_t)order[kk] : kk;
+    const int64_t ii = point_index(order, k, N);
     const float px = pts[3 * ii], py = pts[3 * ii + 1], pz = pts[3 * ii + 2];
-    LaneState s;
+    Wave<false> wv;
     // chamfer.py:81-82 transform_points, k-ordered fma chain
-    s.p = v3(add_rn(fmaf(M[2], pz, fmaf(M[1], py, mul_rn(M[0], px))), M[3]),
-             add_rn(fmaf(M[6], pz, fmaf(M[5], py, mul_rn(M[4], px))), M[7]),
-             add_rn(fmaf(M[10], pz, fmaf(M[9], py, mul_rn(M[8], px))), M[11]));
-    set_reach(s, INFINITY);
-    if (wave == 0) { sh.pt[3 * lane] = s.p.x; sh.pt[3 * lane + 1] = s.p.y; sh.pt[3 * lane + 2] = s.p.z; }
-    scan_mesh<SLICES, false>(m, sh, queue_c[wave], queue_c[wave], s);
+    wv.s.p = v3(add_rn(fmaf(M[2], pz, fmaf(M[1], py, mul_rn(M[0], px))), M[3]),
+                add_rn(fmaf(M[6], pz, fmaf(M[5], py, mul_rn(M[4], px))), M[7]),
+                add_rn(fmaf(M[10], pz, fmaf(M[9], py, mul_rn(M[8], px))), M[11]));
+    scan_mesh<SLICES, false>(m, sh, wv, wave, 0, 0);
     if (wave != 0) return;
-    const unsigned long long found = sh.best[lane];
+    const unsigned long long found = sh.g.best[lane];
     const int best_f = (unsigned)(found >> 32) == 0x7F800000u ? -1 : (int)(unsigned)found;
     double acc = 0.0;
     if (live && best_f >= 0) {
-        const V3 q = closest_on_face(m, m.rec + (int64_t)kRec * m.rec_of_face[best_f], s.p);
-        const float sd = mul_rn(scale, norm3_unfused(sub(q, s.p)));  // chamfer.py:92
+        const V3 q = closest_on_record(m, m.rec_of_face[best_f], wv.s.p);
+        const float sd = mul_rn(scale, norm3_unfused(sub(q, wv.s.p)));  // chamfer.py:92
         acc = (double)mul_rn(sd, sd);
     }
 #pragma unroll
@@ -752,7 +877,7 @@ __global__ void zero_f64_kernel(double* p, int n) {
 // rec_of_face[original id] = position of that face's record (records may be stored in any order)
 __global__ void invert_face_order_kernel(const float* __restrict__ rec, int F, int* __restrict__ rec_of_face) {
     const int k = blockIdx.x * blockDim.x + threadIdx.x;
-    if (k < F) rec_of_face[__float_as_int(rec[(int64_t)kRec * k + 15])] = k;
+    if (k < F) rec_of_face[__float_as_int(record_plane(rec, k, kPlaneA).w)] = k;
 }
 
 static MeshArgs mesh_args(const pvamd_mesh_t& mesh) {
@@ -766,21 +891,35 @@ static MeshArgs mesh_args(const pvamd_mesh_t& mesh) {
     return m;
 }
 
-// How many waves share one 64-point group.
-//   few point groups      -> 16 (then 8), so that the 1024 SIMDs still fill;
-//   many groups           -> 4: the least replicated point-side work (A/B at 2 M points on the 62-tile drill: grid 5.4 ->
-//                            3.3 ms, random box 2.7 -> 1.9 ms, near-surface chamfer 2.0 -> 1.6 ms against 8; 2 is slower);
-//   many groups AND tiles -> 8: the work per group is heavy-tailed (a point near the medial axis is equidistant to much
-//                            of the surface and walks most tiles), and on a mesh of hundreds of tiles the slowest
-//                            groups, not the throughput, set the kernel time (C5, 389 tiles: 8.2 ms with 8, 9.5 with 4,
-//                            16 with 2; 45 ms with one wave per group in the first version of the scan).
-static int pick_slices(int64_t point_tiles, int mesh_tiles) {
-#ifdef PVAMD_FORCE_SLICES
-    return PVAMD_FORCE_SLICES;
+constexpr int kMaxFaces = 1 << 26;  // queue entries are record << 6 | lane
+#ifndef PVAMD_MESH_FILL_WAVES
+#define PVAMD_MESH_FILL_WAVES 32768
 #endif
-    if (point_tiles < (int64_t)kNumCU * 4) return 16;
-    if (point_tiles < (int64_t)kNumCU * 16) return 8;  // 100k random points on the drill: 0.65 (16) / 0.56 (8) / 0.60 ms (4)
-    return mesh_tiles > 128 ? 8 : 4;
+#ifndef PVAMD_MESH_MAX_SLICES
+#define PVAMD_MESH_MAX_SLICES 8
+#endif
+constexpr int kFillWaves = PVAMD_MESH_FILL_WAVES;  // 4 x (256 CUs x 4 SIMDs x 8 waves): short waves, several rounds
+#ifndef PVAMD_MESH_MIN_PARTS
+#define PVAMD_MESH_MIN_PARTS 10
+#endif
+constexpr int kMinParts = PVAMD_MESH_MIN_PARTS;     // below this the single launch wins (A/B on the drill: 30k points 0.27 vs
+                                                    // 0.34 ms with 17 parts; 100k points 0.51 vs 0.39 ms with 5)
+
+// How many waves share one 64-point group (every wave needs tiles of its own: ti % slices == wave).
+//   many groups           -> 2: the least replicated per-wave work (2 M points on the 62-tile drill: 1.9 ms with 2, 2.05
+//                            with 4, 2.4 with 1, 3.1 with 8);
+//   fewer groups          -> 4, 8, so that the 1024 SIMDs still fill (100k points on the drill: 0.40 ms with 8, 0.47 with
+//                            4, 0.79 with 2);
+//   many tiles            -> 8: the work per group is heavy-tailed (a point near the medial axis is equidistant to much of
+//                            the surface and needs most tiles), and on a mesh of hundreds of tiles the slowest groups
+//                            set the kernel time (C5, 389 tiles: 5.9 ms with 8, 7.7 with 4).
+static int pick_slices(int64_t groups, int mesh_tiles) {
+    int s = 2;
+    while (s < 8 && (int64_t)s * groups < 16384) s <<= 1;
+    if (mesh_tiles > 128) s = 8;
+    if (s > PVAMD_MESH_MAX_SLICES) s = PVAMD_MESH_MAX_SLICES;
+    while (s > 1 && s > mesh_tiles) s >>= 1;
+    return s;
 }
 
 }  // namespace pvamd
@@ -820,7 +959,7 @@ extern "C" int pvamd_mesh_prepare(const float* tri, const int32_t* face_id, int3
     if (!aligned_to(rec_out, 16)) return PVAMD_E_ALIGN;
     if (!(abs_margin >= 0.f)) return PVAMD_E_SHAPE;
     hipStream_t s = (hipStream_t)stream;
-    hipLaunchKernelGGL(mesh_prepare_records, dim3((F + 255) / 256), dim3(256), 0, s, tri, face_id, F, abs_margin, rec_out);
+    hipLaunchKernelGGL(mesh_prepare_records, dim3((F + kTile - 1) / kTile), dim3(kTile), 0, s, tri, face_id, F, abs_margin, rec_out);
     hipLaunchKernelGGL(mesh_prepare_tiles, dim3((F + kTile - 1) / kTile), dim3(256), 0, s, rec_out, F, abs_margin, tiles_out);
     hipLaunchKernelGGL(invert_face_order_kernel, dim3((F + 255) / 256), dim3(256), 0, s, rec_out, F, rec_of_face_out);
     return (int)hipGetLastError();
@@ -835,31 +974,29 @@ extern "C" int pvamd_mesh_query(const pvamd_mesh_t* mesh, const float* points, c
     if (mesh->F < 0) return PVAMD_E_SHAPE;
     if (!points || (mesh->F > 0 && (!mesh->rec || !mesh->tiles || !mesh->normal || !mesh->rec_of_face))) return PVAMD_E_NULL;
     if (scratch && !aligned_to(scratch, 8)) return PVAMD_E_ALIGN;
+    if (mesh->F > kMaxFaces) return PVAMD_E_SHAPE;
     const MeshArgs m = mesh_args(*mesh);
-    const int64_t ptiles = (P + 63) / 64;
-    if (ptiles > 0x7fffffff) return PVAMD_E_SHAPE;
+    const int64_t groups = (P + 63) / 64;
+    if (groups > 0x7fffffff) return PVAMD_E_SHAPE;
     hipStream_t s = (hipStream_t)stream;
     const QueryOut out{out_closest, out_dist, out_grad, out_face, out_normal};
     const int ntiles = (mesh->F + kTile - 1) / kTile;
-    // few point groups, many tiles: spread each group's tiles over `parts` blocks (see mesh_query_first_kernel)
-    // (A/B on the drill, 3k..60k random points: 16 waves x <=16 parts 0.175 / 0.222 / 0.391 / 0.539 ms; 8 waves x <=31 parts
-    // 0.164 / 0.183 / 0.331 / 0.405; 4 waves x <=31 parts 0.227 / 0.214 / 0.281 / 0.394)
-    const int split_waves = ptiles >= 256 ? 4 : (ptiles >= 32 ? 8 : 16);  // (1k points: 69 us with 16 waves, 87 with 8)
-    int parts = (int)((int64_t)kNumCU * (split_waves == 4 ? 32 : 16) / ptiles);
-    if (parts > 31) parts = 31;
-    if (parts > ntiles / 4) parts = ntiles / 4;
-    if (scratch && parts >= 2 && ptiles <= (int64_t)kNumCU * 8) {  // beyond ~130k points the single launch wins
-        hipLaunchKernelGGL((mesh_query_first_kernel<16>), dim3((unsigned)ptiles), dim3(1024), 0, s, m, order, points, P, jitter_seed, index_base, scratch);
-        if (split_waves == 4) hipLaunchKernelGGL((mesh_query_rest_kernel<4>), dim3((unsigned)ptiles, (unsigned)parts), dim3(256), 0, s, m, order, points, P, jitter_seed, index_base, scratch);
-        else if (split_waves == 8) hipLaunchKernelGGL((mesh_query_rest_kernel<8>), dim3((unsigned)ptiles, (unsigned)parts), dim3(512), 0, s, m, order, points, P, jitter_seed, index_base, scratch);
-        else hipLaunchKernelGGL((mesh_query_rest_kernel<16>), dim3((unsigned)ptiles, (unsigned)parts), dim3(1024), 0, s, m, order, points, P, jitter_seed, index_base, scratch);
-        hipLaunchKernelGGL(mesh_query_finish_kernel, dim3((unsigned)ptiles), dim3(64), 0, s, m, order, points, P, scratch, out);
+    const int slices = pick_slices(groups, ntiles);
+    // few point groups, many tiles: spread each group's tiles over `parts` blocks of four waves, one per 64-record pass
+    // (see mesh_query_first_kernel)
+    int parts = (int)((int64_t)kFillWaves / (groups * (kTile / 64)));
+    if (parts > ntiles) parts = ntiles;
+    if (scratch && parts >= kMinParts) {
+        hipLaunchKernelGGL(mesh_query_first_kernel, dim3((unsigned)groups), dim3(kTile), 0, s, m, order, points, P, jitter_seed, index_base, scratch);
+        hipLaunchKernelGGL(mesh_query_rest_kernel, dim3((unsigned)groups, (unsigned)parts), dim3(kTile), 0, s, m, order, points, P, jitter_seed, index_base, scratch);
+        hipLaunchKernelGGL(mesh_query_finish_kernel, dim3((unsigned)groups), dim3(64), 0, s, m, order, points, P, scratch, out);
         return (int)hipGetLastError();
     }
-    switch (pick_slices(ptiles, ntiles)) {
-        case 8: hipLaunchKernelGGL((mesh_query_kernel<8>), dim3((unsigned)ptiles), dim3(512), 0, s, m, order, points, P, jitter_seed, index_base, out); break;
-        case 4: hipLaunchKernelGGL((mesh_query_kernel<4>), dim3((unsigned)ptiles), dim3(256), 0, s, m, order, points, P, jitter_seed, index_base, out); break;
-        default: hipLaunchKernelGGL((mesh_query_kernel<16>), dim3((unsigned)ptiles), dim3(1024), 0, s, m, order, points, P, jitter_seed, index_base, out); break;
+    switch (slices) {
+        case 8: hipLaunchKernelGGL((mesh_query_kernel<8>), dim3((unsigned)groups), dim3(512), 0, s, m, order, points, P, jitter_seed, index_base, out); break;
+        case 4: hipLaunchKernelGGL((mesh_query_kernel<4>), dim3((unsigned)groups), dim3(256), 0, s, m, order, points, P, jitter_seed, index_base, out); break;
+        case 2: hipLaunchKernelGGL((mesh_query_kernel<2>), dim3((unsigned)groups), dim3(128), 0, s, m, order, points, P, jitter_seed, index_base, out); break;
+        default: hipLaunchKernelGGL((mesh_query_kernel<1>), dim3((unsigned)groups), dim3(64), 0, s, m, order, points, P, jitter_seed, index_base, out); break;
     }
     return (int)hipGetLastError();
 }
@@ -874,16 +1011,20 @@ extern "C" int pvamd_chamfer_mesh(const pvamd_mesh_t* mesh, const float* W, int3
     hipLaunchKernelGGL(zero_f64_kernel, dim3((B + 255) / 256), dim3(256), 0, s, out_sum, B);
     if (N == 0 || mesh->F == 0) return (int)hipGetLastError();
     if (!W || !points || !mesh->rec || !mesh->tiles || !mesh->rec_of_face) return PVAMD_E_NULL;
+    if (mesh->F > kMaxFaces) return PVAMD_E_SHAPE;
     const MeshArgs m = mesh_args(*mesh);
-    const int64_t ptiles = (N + 63) / 64;
-    if (ptiles > 0x7fffffff) return PVAMD_E_SHAPE;
+    const int64_t groups = (N + 63) / 64;
+    if (groups > 0x7fffffff) return PVAMD_E_SHAPE;
+    const int slices = pick_slices(groups * (int64_t)B, (mesh->F + kTile - 1) / kTile);
     // y-dimension of a HIP grid is limited to 65535: walk B in slabs
     for (int32_t b0 = 0; b0 < B; b0 += 65535) {
         const int32_t nb = (B - b0) < 65535 ? (B - b0) : 65535;
-        switch (pick_slices(ptiles * nb, (mesh->F + kTile - 1) / kTile)) {
-            case 8: hipLaunchKernelGGL((chamfer_mesh_kernel<8>), dim3((unsigned)ptiles, nb), dim3(512), 0, s, m, order, W + 16 * (int64_t)b0, points, N, scale, out_sum + b0); break;
-            case 4: hipLaunchKernelGGL((chamfer_mesh_kernel<4>), dim3((unsigned)ptiles, nb), dim3(256), 0, s, m, order, W + 16 * (int64_t)b0, points, N, scale, out_sum + b0); break;
-            default: hipLaunchKernelGGL((chamfer_mesh_kernel<16>), dim3((unsigned)ptiles, nb), dim3(1024), 0, s, m, order, W + 16 * (int64_t)b0, points, N, scale, out_sum + b0); break;
+        const dim3 grid((unsigned)groups, nb);
+        switch (slices) {
+            case 8: hipLaunchKernelGGL((chamfer_mesh_kernel<8>), grid, dim3(512), 0, s, m, order, W + 16 * (int64_t)b0, points, N, scale, out_sum + b0); break;
+            case 4: hipLaunchKernelGGL((chamfer_mesh_kernel<4>), grid, dim3(256), 0, s, m, order, W + 16 * (int64_t)b0, points, N, scale, out_sum + b0); break;
+            case 2: hipLaunchKernelGGL((chamfer_mesh_kernel<2>), grid, dim3(128), 0, s, m, order, W + 16 * (int64_t)b0, points, N, scale, out_sum + b0); break;
+            default: hipLaunchKernelGGL((chamfer_mesh_kernel<1>), grid, dim3(64), 0, s, m, order, W + 16 * (int64_t)b0, points, N, scale, out_sum + b0); break;
         }
     }
     return (int)hipGetLastError();

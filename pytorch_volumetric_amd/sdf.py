@@ -128,7 +128,7 @@ class ObjectFactory(abc.ABC):
             self._tri_dev = torch.from_numpy(np.ascontiguousarray(soup[order])).to(dev)
             face_id = torch.from_numpy(order.astype(np.int32)).to(dev)
             self._normal_dev = torch.from_numpy(np.ascontiguousarray(self._face_normals.astype(np.float32))).to(dev)
-            self._rec_dev = torch.empty((max(F, 1), _lib.TRI_REC), dtype=torch.float32, device=dev)
+            self._rec_dev = torch.empty((max(_lib.rec_floats(F), 4),), dtype=torch.float32, device=dev)
             self._tiles_dev = torch.empty((max(_lib.tiles_floats(F), 4),), dtype=torch.float32,
                                           device=dev)
             self._rec_of_face_dev = torch.empty((max(F, 1),), dtype=torch.int32, device=dev)
