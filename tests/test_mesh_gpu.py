@@ -60,8 +60,8 @@ def test_c1_drill_10k_grid_points_match_oracle(tile_split):
 
 @pytest.mark.parametrize("n", [1, 63, 64, 65, 1000, 12_000, 40_000, 131_072])
 def test_tile_split_path_for_every_group_count(n):
-    """Partial last group, a single point, both wave counts of the `rest` kernel (8 below 256 point groups, 4 from there
-    on) and the largest count that still splits."""
+    """Partial last group, a single point, counts on both sides of the size where the three-launch path hands over to the
+    single launch, and every waves-per-group choice of the latter."""
     obj = factory("ycb_power_drill.npz")
     bb = obj.bounding_box(padding_ratio=0.3)
     pts = H.uniform_points(n, bb[:, 0], bb[:, 1], seed=100 + n)
