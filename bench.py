@@ -223,8 +223,8 @@ def read_traffic(P):
 def leg_c4(torch, dist, Wk, pv, timer, rank, world, steps, padding, with_gather, small=False, use_pg=False):
     """BASELINE configs[3]: RobotSDF (7-DOF, 8 links), A=200 joint configurations x P=262,144 points, the POINTS
     sharded over the ranks (strong scaling: the total work is fixed).  Leg 1 leaves (val, grad) sharded -- no
-    collective; leg 2 times ShardedSDF.__call__: query + RCCL all-gather of val and grad + the strided copy back to
-    (A, P[, 3]) order (model_to_sdf.py:117-125 on every rank's slice)."""
+    collective; leg 2 times ShardedSDF.__call__: query into packed records + ONE RCCL all-gather + the unpack kernel that
+    writes (A, P[, 3]) order (model_to_sdf.py:117-125 on every rank's slice)."""
     A, P = (8, 1 << 14) if small else (200, 1 << 18)
     robot = Wk.build_c4(resolution=0.02, padding=padding)
     robot.set_joint_configuration(Wk.c4_joint_configs(A))
@@ -274,9 +274,13 @@ def leg_c4(torch, dist, Wk, pv, timer, rank, world, steps, padding, with_gather,
 
         sharded(pts)
         tg = timer(gather_steps)
+        ref = robot(pts[:65536])  # after timing: the gathered result against the unsharded call, bit for bit
+        same = bool(torch.equal(full[0][:, :65536], ref[0]) and torch.equal(full[1][:, :65536], ref[1]))
         out["gathered"] = {"gather": True, "value": A * P * gsteps / tg, "ms_per_step": tg / gsteps * 1e3, "steps": gsteps,
-                           "collective": f"all_gather_into_tensor x2 ({dist.get_backend()}), "
-                                         f"{A * P * 16 * (world - 1) // world} B received per rank per step",
+                           "collective": f"packed (val, grad) records, all_gather_into_tensor x1 ({dist.get_backend()}), "
+                                         f"{A * (-(-chunk // 256) * 256) * 16 * (world - 1)} B received per rank per step, "
+                                         "unpack kernel writes (A, P) / (A, P, 3)",
+                           "path": getattr(sharded, "last_path", None), "equals_unsharded_call": same,
                            "output_shape": [list(full[0].shape), list(full[1].shape)]}
     else:
         out["gathered"] = None if world > 1 else {"gather": True, "note": "single rank: nothing to gather, same as `sharded`"}

@@ -215,6 +215,17 @@ int pvamd_composed_query_bucketed(const pvamd_grid_t* grids, int32_t S, const fl
                                   const float* sorted_points, const int32_t* inv, int64_t P, int64_t Pp,
                                   float* scratch, float* out_val, float* out_grad, int32_t flags, void* stream);
 
+/* The two halves of the above, for callers that move the packed records themselves (a query sharded over GPUs gathers
+ * ONE buffer of records instead of val and grad, then unpacks straight into the final layout):
+ * pvamd_composed_query_packed: out_rec[a][k] = (val, gx, gy, gz) of configuration a at points[k].  points: device [Pp][3],
+ *   Pp a multiple of 256, 16-byte aligned.  out_rec: device, A * Pp * 16 bytes, 16-byte aligned.  A <= 65535.
+ * pvamd_unpack_records: out_val[a][j] / out_grad[a][j] = rec[a * stride + index[j]] for j < P (index[j] may point
+ *   anywhere in the buffer, e.g. into another rank's slab).  rec: device float4 records.  index: device [P] int32.   */
+int pvamd_composed_query_packed(const pvamd_grid_t* grids, int32_t S, const float* tf, int32_t A, const float* points,
+                                int64_t Pp, float* out_rec, int32_t flags, void* stream);
+int pvamd_unpack_records(const float* rec, const int32_t* index, int64_t P, int64_t stride, int32_t A, float* out_val,
+                         float* out_grad, void* stream);
+
 /* Prepare a mesh for the query kernels: per-triangle records (corners, original face id, bounding sphere, and the
  * triangle's in-plane bounding rectangle: centre, two unit axes, half extents) plus one bounding sphere per run of
  * PVAMD_TRI_GROUP and of PVAMD_TRI_TILE records.  The bounds only ever SKIP work that provably cannot change a result

@@ -527,37 +527,54 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void composed_unpermute_kernel
 
 using namespace pvamd;
 
-extern "C" int pvamd_composed_query_bucketed(const pvamd_grid_t* grids, int32_t S, const float* tf, int32_t A,
-                                             const float* sorted_points, const int32_t* inv, int64_t P, int64_t Pp,
-                                             float* scratch, float* out_val, float* out_grad, int32_t flags,
-                                             void* stream) {
-    if (S < 1 || A < 1 || P < 1 || Pp < P || Pp % kTilePoints != 0 || S >= kUnnormalised) return PVAMD_E_SHAPE;
-    if (!grids || !tf || !sorted_points || !inv || !scratch || !out_val || !out_grad) return PVAMD_E_NULL;
-    if (!aligned_to(grids, 8) || !aligned_to(tf, 4) || !aligned_to(sorted_points, 16) || !aligned_to(scratch, 16) ||
-        !aligned_to(inv, 4) || !aligned_to(out_val, 16) || !aligned_to(out_grad, 16))
-        return PVAMD_E_ALIGN;
+extern "C" int pvamd_composed_query_packed(const pvamd_grid_t* grids, int32_t S, const float* tf, int32_t A,
+                                           const float* points, int64_t Pp, float* out_rec, int32_t flags, void* stream) {
+    if (S < 1 || A < 1 || Pp < 1 || Pp % kTilePoints != 0 || S >= kUnnormalised) return PVAMD_E_SHAPE;
+    if (!grids || !tf || !points || !out_rec) return PVAMD_E_NULL;
+    if (!aligned_to(grids, 8) || !aligned_to(tf, 4) || !aligned_to(points, 16) || !aligned_to(out_rec, 16)) return PVAMD_E_ALIGN;
     hipStream_t s = (hipStream_t)stream;
     const int64_t ntiles = Pp / kTilePoints;
     const int64_t tile_blocks = (ntiles + kWavesPerBlock - 1) / kWavesPerBlock;
     constexpr int kSlab = 65535;  // gridDim.y of the query kernel = tile blocks
-    if (tile_blocks > kSlab) return PVAMD_E_SHAPE;  // > 67 M points per call: use the direct entry point
-    const f32x4* p4 = reinterpret_cast<const f32x4*>(sorted_points);
-    // One query launch, one un-permute launch.  (Alternating the two over chunks of configurations small enough for the
-    // packed records to stay in the 256 MB Infinity Cache was slower: README-size C4 1.66 ms unchunked, 1.89 / 2.10 / 3.29
-    // ms with 192 / 96 / 32 MB chunks -- the query kernel lives off the L2 reuse between MANY configurations of a tile.)
+    if (tile_blocks > kSlab || A > kSlab) return PVAMD_E_SHAPE;  // > 67 M points per call: use the direct entry point
+    const f32x4* p4 = reinterpret_cast<const f32x4*>(points);
     if (flags & PVAMD_COMPOSED_INLINE_EXACT)
         hipLaunchKernelGGL((composed_query_wave<PVAMD_COMPOSED_PPP, kInlineExact, true>), dim3(A, (unsigned)tile_blocks),
-                           dim3(kWavesPerBlock * 64), 0, s, grids, S, tf, A, p4, ntiles, Pp, scratch, nullptr, nullptr, 0);
+                           dim3(kWavesPerBlock * 64), 0, s, grids, S, tf, A, p4, ntiles, Pp, out_rec, nullptr, nullptr, 0);
     else
         hipLaunchKernelGGL((composed_query_wave<PVAMD_COMPOSED_PPP, kEstimate, true>), dim3(A, (unsigned)tile_blocks),
-                           dim3(kWavesPerBlock * 64), 0, s, grids, S, tf, A, p4, ntiles, Pp, scratch, nullptr, nullptr, 0);
+                           dim3(kWavesPerBlock * 64), 0, s, grids, S, tf, A, p4, ntiles, Pp, out_rec, nullptr, nullptr, 0);
+    return (int)hipGetLastError();
+}
+
+extern "C" int pvamd_unpack_records(const float* rec, const int32_t* index, int64_t P, int64_t stride, int32_t A,
+                                    float* out_val, float* out_grad, void* stream) {
+    if (A < 1 || P < 1 || stride < 1) return PVAMD_E_SHAPE;
+    if (!rec || !index || !out_val || !out_grad) return PVAMD_E_NULL;
+    if (!aligned_to(rec, 16) || !aligned_to(index, 4) || !aligned_to(out_val, 16) || !aligned_to(out_grad, 16)) return PVAMD_E_ALIGN;
+    const int64_t ntiles = (P + kTilePoints - 1) / kTilePoints;
+    const int64_t tile_blocks = (ntiles + kWavesPerBlock - 1) / kWavesPerBlock;
     const int64_t groups = ((int64_t)A + 7) / 8;
     const int64_t ublocks = (tile_blocks + kUnpermuteTiles - 1) / kUnpermuteTiles;
     const int64_t blocks = groups * 8 * ublocks;
     if (blocks > 0x7fffffffLL) return PVAMD_E_SHAPE;
-    hipLaunchKernelGGL(composed_unpermute_kernel, dim3((unsigned)blocks), dim3(kWavesPerBlock * 64), 0, s,
-                       reinterpret_cast<const f32x4*>(scratch), inv, P, Pp, A, ublocks, out_val, out_grad);
+    hipLaunchKernelGGL(composed_unpermute_kernel, dim3((unsigned)blocks), dim3(kWavesPerBlock * 64), 0, (hipStream_t)stream,
+                       reinterpret_cast<const f32x4*>(rec), index, P, stride, A, ublocks, out_val, out_grad);
     return (int)hipGetLastError();
+}
+
+// One query launch, one un-permute launch.  (Alternating the two over chunks of configurations small enough for the
+// packed records to stay in the 256 MB Infinity Cache was slower: README-size C4 1.66 ms unchunked, 1.89 / 2.10 / 3.29
+// ms with 192 / 96 / 32 MB chunks -- the query kernel lives off the L2 reuse between MANY configurations of a tile.)
+extern "C" int pvamd_composed_query_bucketed(const pvamd_grid_t* grids, int32_t S, const float* tf, int32_t A,
+                                             const float* sorted_points, const int32_t* inv, int64_t P, int64_t Pp,
+                                             float* scratch, float* out_val, float* out_grad, int32_t flags,
+                                             void* stream) {
+    if (P < 1 || Pp < P) return PVAMD_E_SHAPE;
+    if (!inv || !out_val || !out_grad) return PVAMD_E_NULL;
+    const int rc = pvamd_composed_query_packed(grids, S, tf, A, sorted_points, Pp, scratch, flags, stream);
+    if (rc != 0) return rc;
+    return pvamd_unpack_records(scratch, inv, P, Pp, A, out_val, out_grad, stream);
 }
 
 extern "C" int pvamd_composed_query(const pvamd_grid_t* grids, int32_t S, const float* tf, int32_t A,

@@ -1,12 +1,19 @@
 """Multi-GPU sharding of SDF queries: one process per GPU, query points split across ranks, one all-gather
-(RCCL over xGMI when the backend is "nccl") to reassemble (sdf_val, sdf_grad).
+(RCCL over xGMI when the backend is "nccl") to reassemble (sdf_val, sdf_grad).  For a composition of cached grids
+(RobotSDF / ComposedSDF, the C4 case) the kernel writes packed (val, grad) records straight into the send buffer, ONE
+all-gather moves them, and one unpack kernel writes the final (A, P) / (A, P, 3) layout: no second collective and no
+strided copy of the gathered tensors.
 
 Every query point is independent (reference sdf.py:535-591, 392-433, 122-172 have no cross-point term), the
 read-only state (voxel grids, meshes, transforms) is small and replicated on every GPU, so the only communication
 is the gather of the outputs -- or none at all with gather=False, when the consumer can use sharded results.
 """
+import math
+
 import torch
 import torch.distributed as dist
+
+from pytorch_volumetric_amd import _lib
 
 
 def shard_range(num_points, world_size, rank):
@@ -58,10 +65,14 @@ class ShardedSDF:
         flat = points_in_object_frame.reshape(-1, 3)
         P = flat.shape[0]
         start, stop, chunk = shard_range(P, world, rank)
+        packed = self._packed_call(flat, lead, world, start, stop, chunk)
+        if packed is not None:
+            return packed
         mine = flat[start:stop]
         if mine.shape[0] < chunk:  # pad the tail so every rank contributes the same count (all-gather needs it)
             pad = flat[:1].expand(chunk - mine.shape[0], 3) if P > 0 else flat.new_zeros((chunk, 3))
             mine = torch.cat((mine, pad), dim=0)
+        self.last_path = "generic"
         val, grad = self._query(mine, start)
         # leaf / composed-without-batch: val (chunk,), grad (chunk,3); with a configuration batch: (A..., chunk[,3])
         if not self.gather:
@@ -75,6 +86,44 @@ class ShardedSDF:
         if self._returns_flat():
             return val.reshape(*batch, -1), grad.reshape(*batch, -1, 3)
         return val.reshape(*batch, *lead), grad.reshape(*batch, *lead, 3)
+
+    def _packed_call(self, flat, lead, world, start, stop, chunk):
+        """The one-collective path (module docstring); None when it does not apply."""
+        inner = getattr(self.sdf, "sdf", self.sdf)  # RobotSDF -> its ComposedSDF
+        P = flat.shape[0]
+        if not (self.gather and P > 0 and hasattr(inner, "query_packed") and inner._fusable() and torch.is_tensor(flat)
+                and flat.dtype == torch.float32 and torch.cuda.is_available()):
+            return None
+        dev = inner._owner_device()
+        if self.compute_device is not None and torch.device(self.compute_device).type != "cuda":
+            return None
+        A = math.prod(inner.tsf_batch) if inner.tsf_batch is not None else 1
+        Pp = -(-chunk // 256) * 256
+        if world * A * Pp >= 2 ** 31 or A > 65535:
+            return None
+        self.last_path = "packed"
+        mine = flat[start:stop].to(dev)
+        if mine.shape[0] < Pp:  # whole 256-point tiles: pad with copies of a point (their records are never unpacked)
+            mine = torch.cat((mine, flat[:1].to(dev).expand(Pp - mine.shape[0], 3)), dim=0)
+        rec = inner.query_packed(mine.contiguous())
+        gathered = torch.empty((world, A, Pp, 4), dtype=torch.float32, device=dev)
+        try:
+            dist.all_gather_into_tensor(gathered, rec, group=self.group)
+        except (RuntimeError, NotImplementedError):
+            dist.all_gather([gathered[r] for r in range(world)], rec, group=self.group)
+        key = (P, chunk, A, Pp, str(dev))
+        if getattr(self, "_index_key", None) != key:  # caller point j sits in rank j // chunk's slab, at j % chunk
+            j = torch.arange(P, device=dev, dtype=torch.int64)
+            self._index = ((j // chunk) * (A * Pp) + j % chunk).to(torch.int32)
+            self._index_key = key
+        val = torch.empty((A, P), dtype=torch.float32, device=dev)
+        grad = torch.empty((A, P, 3), dtype=torch.float32, device=dev)
+        with _lib.on_device(dev):
+            _lib.check(_lib.load().pvamd_unpack_records(_lib.ptr(gathered), _lib.ptr(self._index), P, Pp, A, _lib.ptr(val),
+                                                        _lib.ptr(grad), _lib.stream_ptr()), "pvamd_unpack_records")
+        if inner.tsf_batch is None:
+            return val.reshape(-1), grad.reshape(-1, 3)
+        return val.reshape(*inner.tsf_batch, *lead), grad.reshape(*inner.tsf_batch, *lead, 3)
 
     def _returns_flat(self):
         """A ComposedSDF (or RobotSDF) WITHOUT a transform batch returns flat (P,) / (P,3) even for batched points

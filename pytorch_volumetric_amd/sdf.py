@@ -713,6 +713,29 @@ class ComposedSDF(ObjectFrameSDF):
             val, grad = val.reshape(-1), grad.reshape(-1, 3)
         return val.to(device=out_device, dtype=dtype), grad.to(device=out_device, dtype=dtype)
 
+    def query_packed(self, points, out=None):
+        """Fused query that leaves one (val, gx, gy, gz) record per (configuration, point): (A, P, 4) fp32 for contiguous
+        fp32 (P, 3) GPU points, P a multiple of 256.  What a query sharded over GPUs gathers (one buffer instead of two,
+        unpacked straight into the final layout: dist.ShardedSDF); same bits as __call__."""
+        if not self._fusable():
+            raise ValueError("query_packed needs every leaf to be a CachedSDF with the BOUNDING_BOX strategy")
+        A = math.prod(self.tsf_batch) if self.tsf_batch is not None else 1
+        P = points.shape[0]
+        if not (points.is_cuda and points.dtype == torch.float32 and points.is_contiguous() and points.shape == (P, 3)) \
+                or P % 256 != 0 or P == 0:
+            raise ValueError("query_packed needs contiguous fp32 (P,3) points on the GPU, P a positive multiple of 256")
+        dev = points.device
+        if dev != self._owner_device():
+            raise _lib.PvamdError(f"query_packed: the leaf grids live on {self._owner_device()}; points are on {dev}")
+        if out is None:
+            out = torch.empty((A, P, 4), dtype=torch.float32, device=dev)
+        with _lib.on_device(dev):
+            grids = self._leaf_grids(dev)
+            _lib.check(_lib.load().pvamd_composed_query_packed(_lib.ptr(grids), len(self.sdfs), _lib.ptr(self._tf_device(dev)),
+                                                               A, _lib.ptr(points), P, _lib.ptr(out), self._query_flags,
+                                                               _lib.stream_ptr()), "pvamd_composed_query_packed")
+        return out
+
     def query_into(self, points, out_val, out_grad):
         """Allocation-free fused query for inner loops / graph capture: contiguous fp32 (P,3) GPU points, results into
         the caller's fp32 (A,P) / (A,P,3) buffers (A = number of configurations, 1 without a transform batch).  Needs

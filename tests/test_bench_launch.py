@@ -50,6 +50,7 @@ def test_two_ranks_share_the_gpu_and_every_leg_reports():
         assert legs[name]["scaling"] == "strong" and legs[name]["n_gpus"] == 2
     assert legs["c4"]["sharded"]["gather"] is False and legs["c4"]["gathered"]["gather"] is True
     assert legs["c4"]["gathered"]["output_shape"] == [[8, 16384], [8, 16384, 3]]
+    assert legs["c4"]["gathered"]["path"] == "packed" and legs["c4"]["gathered"]["equals_unsharded_call"] is True
     assert legs["c5"]["rel_err_vs_analytic"] < 1e-3
 
 
@@ -70,7 +71,7 @@ def test_single_rank_line_has_the_contract_fields():
 def test_rccl_calls_of_the_legs_run_on_one_rank():
     """The 8-GPU run belongs to the driver; what can be checked on a 1-GPU box is that every torch.distributed call of the
     multi-rank path is valid against the nccl (= RCCL) backend: process group with device_id, barrier, MAX all-reduce of the
-    timing, ShardedSDF's all_gather_into_tensor x2, sharded_chamfer's all-reduces -- with a single rank (--force-pg)."""
+    timing, ShardedSDF's all_gather_into_tensor of packed records, sharded_chamfer's all-reduces -- with a single rank (--force-pg)."""
     line = run_bench("--steps", "5", "--warmup", "2", "--points", "65536", "--small-legs", "--no-large", "--no-cpu-baseline",
                      "--force-pg")
     assert line["config"]["backend"] == "nccl"
@@ -79,4 +80,5 @@ def test_rccl_calls_of_the_legs_run_on_one_rank():
         assert "error" not in legs[name], legs[name]
     assert legs["c4"]["gathered"]["gather"] is True and "nccl" in legs["c4"]["gathered"]["collective"]
     assert legs["c4"]["gathered"]["output_shape"] == [[8, 16384], [8, 16384, 3]]
+    assert legs["c4"]["gathered"]["path"] == "packed" and legs["c4"]["gathered"]["equals_unsharded_call"] is True
     assert "nccl" in legs["c5"]["collective"] and legs["c5"]["rel_err_vs_analytic"] < 1e-3

@@ -178,6 +178,19 @@ def test_sharded_sdf_over_rccl_single_rank():
         sv, sg = pv.ShardedSDF(c)(pts.reshape(73, 137, 3))
         assert sv.shape == (73, 137) and sv.is_cuda
         assert torch.equal(sv.reshape(-1), v) and torch.equal(sg.reshape(-1, 3).nan_to_num(3.), g.nan_to_num(3.))
+        # a composition of cached grids goes out as packed records through ONE collective and an unpack kernel
+        scene = pv.ComposedSDF([c, c, c], pv.Translate(0.05, 0, 0).stack(pv.Translate(-0.1, 0, 0.1), pv.Translate(0, 0.2, 0)))
+        for batch in (None, 5):
+            if batch is not None:
+                t = torch.randn(3 * batch, 3, generator=torch.Generator().manual_seed(1)) * 0.05
+                scene.set_transforms(pv.Translate(t), batch_dim=(batch,))
+            dv, dg = scene(pts)
+            sh = pv.ShardedSDF(scene)
+            gv, gg = sh(pts)
+            assert sh.last_path == "packed" and gv.shape == dv.shape and gg.shape == dg.shape
+            assert torch.equal(gv, dv) and torch.equal(gg.nan_to_num(3.), dg.nan_to_num(3.))
+            gv2, gg2 = sh(pts.reshape(73, 137, 3))
+            assert torch.equal(gv2.reshape(dv.shape), dv) and torch.equal(gg2.reshape(dg.shape).nan_to_num(3.), dg.nan_to_num(3.))
     finally:
         dist.destroy_process_group()
 
