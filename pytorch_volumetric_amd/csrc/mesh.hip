@@ -703,13 +703,13 @@ __global__ __launch_bounds__(64 * SLICES) void mesh_query_kernel(MeshArgs m, con
 // ---- few points: the tiles of one point group are spread over several blocks --------------------------------
 // A wave walks its flagged tiles one after the other; with only a few hundred point groups that serial walk, not
 // throughput, sets the time.  Three launches instead:
-//   first   (one block per group)      seed + the nearest tile, one 64-record pass per wave -> (d2, face), hit count and
-//                                      that tile's index to scratch
-//   rest    (nparts blocks per group)  start from the scratch values; wave w of block y takes the tiles
-//                                      ti % (SLICES * nparts) == y * SLICES + w, the nearest excepted;
-//                                      folds into scratch with global atomicMin / atomicAdd
-//   finish  (one wave per group)       outputs from the scratch values
-// scratch: u64 best[G*64], int hits[G*64], int firsts[G*2], G = ceil(P/64) groups, indexed by processing position.
+//   fill    scratch = (no face, 0 hits)
+//   rest    (nparts blocks of four waves per group)  block y takes the tiles ti % nparts == y, wave w the w-th 64-record
+//           pass of each; starts from the tile-sphere bound; folds into scratch with global atomicMin / atomicAdd
+//   finish  (one wave per group)  outputs from the scratch values
+// (A `first` launch that visited the nearest tile and handed its bound to `rest` cost what it saved: C1 0.159 vs 0.158 ms,
+// 1000 points 0.089 vs 0.063 ms without it.)
+// scratch: u64 best[G*64], int hits[G*64], int spare[G*2], G = ceil(P/64) groups, indexed by processing position.
 struct SplitScratch {
     unsigned long long* best;
     int* hits;
@@ -721,30 +721,6 @@ PVAMD_DEV SplitScratch split_scratch(void* scratch, int64_t groups) {
     r.hits = reinterpret_cast<int*>(r.best + groups * 64);
     r.firsts = r.hits + groups * 64;
     return r;
-}
-
-__global__ __launch_bounds__(64 * (kTile / 64)) void mesh_query_first_kernel(MeshArgs m, const int* __restrict__ order,
-                                                                            const float* __restrict__ pts, int64_t P,
-                                                                            uint64_t seed, int64_t index_base, void* scratch) {
-    constexpr int SLICES = kTile / 64;  // one wave per pass of the tile
-    __shared__ __attribute__((aligned(16))) MeshShared<SLICES, true> sh;
-    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int64_t k = (int64_t)blockIdx.x * 64 + lane;
-    const int64_t i = point_index(order, k, P);
-    Wave<true> wv;
-    wv.s.p = v3(pts[3 * i], pts[3 * i + 1], pts[3 * i + 2]);
-    int first = -1;
-    if (scan_begin(m, sh.g, wv, wave, seed, index_base + i, nullptr)) {
-        first = scan_seed(m, wv, 0, 1);
-        visit_tile<true>(m, sh.g, sh.w[wave], wv, first, wave, wave + 1);
-        scan_finish(m, sh.g, sh.w[wave], wv);
-    }
-    __syncthreads();
-    if (wave != 0) return;
-    const SplitScratch sc = split_scratch(scratch, gridDim.x);
-    sc.best[k] = sh.g.best[lane];
-    sc.hits[k] = sh.g.hits[lane];
-    if (lane == 0) sc.firsts[2 * blockIdx.x] = first;
 }
 
 // grid: x = groups of 64 points, y = part; wave w takes the w-th 64-record pass of the block's tiles
@@ -761,13 +737,21 @@ __global__ __launch_bounds__(64 * (kTile / 64)) void mesh_query_rest_kernel(Mesh
     const SplitScratch sc = split_scratch(scratch, gridDim.x);
     const unsigned long long start = sc.best[k];
     if (scan_begin(m, sh.g, wv, wave, seed, index_base + i, &start)) {
-        scan_tiles<true>(m, sh.g, sh.w[wave], wv, sc.firsts[2 * blockIdx.x], (int)blockIdx.y, (int)gridDim.y, wave, wave + 1);
+        scan_seed(m, wv, 0, 1);  // the bound from the tile spheres; the other blocks' finds arrive through scratch only at the end
+        scan_tiles<true>(m, sh.g, sh.w[wave], wv, -1, (int)blockIdx.y, (int)gridDim.y, wave, wave + 1);
         scan_finish(m, sh.g, sh.w[wave], wv);
     }
     __syncthreads();
     if (wave != 0) return;
     if (sh.g.best[lane] < start) atomicMin(&sc.best[k], sh.g.best[lane]);
     if (sh.g.hits[lane] != 0) atomicAdd(&sc.hits[k], sh.g.hits[lane]);
+}
+
+__global__ __launch_bounds__(64) void mesh_scratch_fill_kernel(void* scratch) {
+    const SplitScratch sc = split_scratch(scratch, gridDim.x);
+    const int64_t k = (int64_t)blockIdx.x * 64 + threadIdx.x;
+    sc.best[k] = kBestInit;
+    sc.hits[k] = 0;
 }
 
 __global__ __launch_bounds__(64) void mesh_query_finish_kernel(MeshArgs m, const int* __restrict__ order,
@@ -900,8 +884,12 @@ constexpr int kMaxFaces = 1 << 26;  // queue entries are record << 6 | lane
 #endif
 constexpr int kFillWaves = PVAMD_MESH_FILL_WAVES;  // 4 x (256 CUs x 4 SIMDs x 8 waves): short waves, several rounds
 #ifndef PVAMD_MESH_MIN_PARTS
-#define PVAMD_MESH_MIN_PARTS 10
+#define PVAMD_MESH_MIN_PARTS 6
 #endif
+#ifndef PVAMD_MESH_MAX_PARTS
+#define PVAMD_MESH_MAX_PARTS 32
+#endif
+constexpr int kMaxParts = PVAMD_MESH_MAX_PARTS;     // C1 (157 groups): 0.143 ms with 26-39 parts, 0.155 with 52, 0.17 with 104
 constexpr int kMinParts = PVAMD_MESH_MIN_PARTS;     // below this the single launch wins (A/B on the drill: 30k points 0.27 vs
                                                     // 0.34 ms with 17 parts; 100k points 0.51 vs 0.39 ms with 5)
 
@@ -983,11 +971,16 @@ extern "C" int pvamd_mesh_query(const pvamd_mesh_t* mesh, const float* points, c
     const int ntiles = (mesh->F + kTile - 1) / kTile;
     const int slices = pick_slices(groups, ntiles);
     // few point groups, many tiles: spread each group's tiles over `parts` blocks of four waves, one per 64-record pass
-    // (see mesh_query_first_kernel)
+    // (see mesh_query_rest_kernel)
     int parts = (int)((int64_t)kFillWaves / (groups * (kTile / 64)));
     if (parts > ntiles) parts = ntiles;
+    {   // cap, but never below what fills the chip twice over (1000 points: 0.061 ms with 62 parts, 0.080 with 32)
+        const int64_t fill = 16384 / (groups * (kTile / 64));
+        const int cap = fill > kMaxParts ? (int)fill : kMaxParts;
+        if (parts > cap) parts = cap;
+    }
     if (scratch && parts >= kMinParts) {
-        hipLaunchKernelGGL(mesh_query_first_kernel, dim3((unsigned)groups), dim3(kTile), 0, s, m, order, points, P, jitter_seed, index_base, scratch);
+        hipLaunchKernelGGL(mesh_scratch_fill_kernel, dim3((unsigned)groups), dim3(64), 0, s, scratch);
         hipLaunchKernelGGL(mesh_query_rest_kernel, dim3((unsigned)groups, (unsigned)parts), dim3(kTile), 0, s, m, order, points, P, jitter_seed, index_base, scratch);
         hipLaunchKernelGGL(mesh_query_finish_kernel, dim3((unsigned)groups), dim3(64), 0, s, m, order, points, P, scratch, out);
         return (int)hipGetLastError();

@@ -9,7 +9,7 @@ g = torch.Generator().manual_seed(0)
 pts = grid_pts[torch.randperm(len(grid_pts), generator=g)[:10_000]].cuda()
 bb = drill.bounding_box(padding=0.05)
 print(os.environ.get("PVAMD_LIB", "product"), "C1 %.3f ms (min %.3f)" % gpu_ms(lambda: sdf(pts), reps=30), end=" | ")
-for n in (1000, 30000, 100000):
+for n in (1000, 3000, 30000, 60000, 100000):
     rnd = Wk.uniform_points_device(n, bb[:, 0], bb[:, 1], 5)
     print(f"{n}: %.3f (min %.3f)" % gpu_ms(lambda: sdf(rnd)), end=" | ")
 print()
