@@ -7,12 +7,19 @@ rocprofv3 --kernel-trace --stats -d $O/kt -o bench --output-format csv -- python
 rocprofv3 --pmc FETCH_SIZE -d $O/fetch -o bench --output-format csv -- python bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline --no-large --no-legs > $O/fetch.log 2>&1
 rocprofv3 --pmc WRITE_SIZE -d $O/write -o bench --output-format csv -- python bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline --no-large --no-legs > $O/write.log 2>&1
 python - <<PY > $O/kernel_stats.md
-import csv, glob
-print("| kernel | calls | total us | avg us | min us | max us | % |")
-print("|---|---|---|---|---|---|---|")
-for f in glob.glob("$O/kt/**/*kernel_stats.csv", recursive=True):
-    for r in list(csv.DictReader(open(f)))[:30]:
-        print("| \`%s\` | %s | %.1f | %.2f | %.2f | %.2f | %s |" % (r["Name"][:110], r["Calls"], float(r["TotalDurationNs"]) / 1e3, float(r["AverageNs"]) / 1e3, float(r["MinNs"]) / 1e3, float(r["MaxNs"]) / 1e3, r["Percentage"]))
+# per (kernel, launch geometry): the same template instantiation serves the 1M-point steps and the 8M / 64M-point legs
+import csv, glob, collections
+rows = collections.defaultdict(list)
+for f in glob.glob("$O/kt/**/*kernel_trace.csv", recursive=True):
+    for r in csv.DictReader(open(f)):
+        grid = r.get("Grid_Size_X") or r.get("Grid_Size") or "?"
+        wg = r.get("Workgroup_Size_X") or r.get("Workgroup_Size") or "?"
+        rows[(r["Kernel_Name"][:96], grid, wg)].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
+total = sum(sum(v) for v in rows.values())
+print("| kernel | grid (threads) x workgroup | calls | total us | avg us | min us | max us | % |")
+print("|---|---|---|---|---|---|---|---|")
+for (name, grid, wg), v in sorted(rows.items(), key=lambda kv: -sum(kv[1]))[:32]:
+    print("| \`%s\` | %s x %s | %d | %.1f | %.2f | %.2f | %.2f | %.2f |" % (name, grid, wg, len(v), sum(v), sum(v) / len(v), min(v), max(v), 100 * sum(v) / total))
 PY
 F=$(find $O/fetch -name "*counter_collection.csv" | head -1); W=$(find $O/write -name "*counter_collection.csv" | head -1)
 python tools/pmc_summary.py $F $W cached_query_wave 1048576 > $O/traffic.json
