@@ -574,14 +574,28 @@ PVAMD_DEV void scan_tiles(const MeshArgs& m, GroupShared<WITH_RAY>& g, WaveLocal
         const float dist2 = dot(w, w);
         const bool ray = WITH_RAY && mine && axis_may_hit(wv.wb, w, dist2, ts.w);
         STAT(0, 1);
-        unsigned long long open = ~0ull;  // tiles of this pass not yet decided
+        // nearest flagged tile of the pass first (the sooner the reaches are final, the fewer pairs get queued), and a
+        // per-point look at its sphere before paying for the visit
+        const float lower = mine ? fast_sqrt(dist2) - ts.w : INFINITY;  // ordering only
+        unsigned long long done = 0ull;
         for (;;) {
             pull_reach(g, wv);  // what the other waves found in the meantime
             const bool need = mine && (ray || sphere_may_improve(wv.wb.q, dist2, ts.w));  // Q only ever shrinks
-            const unsigned long long todo = __ballot(need) & open;
+            const unsigned long long todo = __ballot(need) & ~done;
             if (todo == 0ull) break;
-            const int t = __builtin_ctzll(todo);
-            open = t == 63 ? 0ull : (~0ull << (t + 1));
+            const float key = ((todo >> lane) & 1ull) ? lower : INFINITY;
+            const unsigned long long at = __ballot(key == wave_min(key)) & todo;
+            const int t = __builtin_ctzll(at ? at : todo);
+            done |= 1ull << t;
+            const V3 ctr = v3(__int_as_float(__builtin_amdgcn_readlane(__float_as_int(ts.x), t)),
+                              __int_as_float(__builtin_amdgcn_readlane(__float_as_int(ts.y), t)),
+                              __int_as_float(__builtin_amdgcn_readlane(__float_as_int(ts.z), t)));
+            const float r = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(ts.w), t));
+            const V3 wl_ = v3(ctr.x - wv.s.p.x, ctr.y - wv.s.p.y, ctr.z - wv.s.p.z);
+            const float d2 = dot(wl_, wl_);
+            bool mine_too = sphere_may_improve(wv.s, d2, r);
+            if (WITH_RAY) mine_too = mine_too || sphere_may_hit(d2, dot(wl_, wv.dn), r);
+            if (!__any(mine_too && wv.live)) continue;
             visit_tile<WITH_RAY>(m, g, wl, wv, base + t, pass_lo, pass_hi);
         }
     }
