@@ -267,10 +267,12 @@ int pvamd_morton_order(const float* points, int64_t P, int32_t* order_out, int32
  * np.random.randn (sdf.py:149); index_base = global index of points[0], so that a query sharded across GPUs
  * draws the jitter an unsharded one would.  out_closest: device [P][3] or NULL.  out_dist: device [P].  out_grad: device
  * [P][3].  out_face: device [P] int32 or NULL.  out_normal: device [P][3] or NULL (compute_normal=True).
- * scratch: device, PVAMD_MESH_SCRATCH_BYTES(P) bytes, 8-byte aligned, or NULL.  With it, a query of few points
- * against a mesh of many tiles spreads each 64-point group's tiles over several workgroups (three launches that meet
- * in scratch); results are the same bits either way.  Contents on return are unspecified.                       */
-#define PVAMD_MESH_SCRATCH_BYTES(P) ((((P) + 63) / 64) * (64 * 12 + 8))
+ * scratch: device, PVAMD_MESH_SCRATCH_BYTES(P) bytes, 8-byte aligned, or NULL.  With it, the tiles of a 64-point group
+ * are spread over several workgroups where one group's serial walk would set the time -- every group of a query of few
+ * points, and the heavy groups of a large one (points about equidistant to much of a mesh of >= 128 tiles) -- in three
+ * launches that meet in scratch; results are the same bits either way.  Contents on return are unspecified.      */
+#define PVAMD_MESH_SCRATCH_GROUPS 2048  /* point groups (of 64) a scratch buffer has slots for, at most */
+#define PVAMD_MESH_SCRATCH_BYTES(P) (64 + ((((P) + 63) / 64) < PVAMD_MESH_SCRATCH_GROUPS ? (((P) + 63) / 64) : PVAMD_MESH_SCRATCH_GROUPS) * (int64_t)(64 * 12 + 8))
 int pvamd_mesh_query(const pvamd_mesh_t* mesh, const float* points, const int32_t* order, int64_t P,
                      uint64_t jitter_seed, int64_t index_base, float* out_closest, float* out_dist, float* out_grad, int32_t* out_face,
                      float* out_normal, void* scratch, void* stream);
@@ -288,9 +290,11 @@ int pvamd_sample_surface(const float* tri, const double* cdf, int32_t F, int64_t
  * N points, unsigned distance to the mesh, accumulate sum_n (scale*d)^2.  The caller divides by the GLOBAL N
  * (after an all-reduce when the points are sharded across GPUs).
  * W: device [B][4][4].  points: device [N][3].  order: as for pvamd_mesh_query, or NULL.
- * out_sum: device [B] float64, ZEROED by this call.                                                          */
+ * out_sum: device [B] float64, ZEROED by this call.  scratch: device, PVAMD_MESH_SCRATCH_BYTES(N) bytes, 8-byte aligned,
+ * or NULL (as for pvamd_mesh_query: heavy point groups are spread over several workgroups; same sums up to the order of
+ * the float64 additions).                                                                                     */
 int pvamd_chamfer_mesh(const pvamd_mesh_t* mesh, const float* W, int32_t B, const float* points,
-                       const int32_t* order, int64_t N, float scale, double* out_sum, void* stream);
+                       const int32_t* order, int64_t N, float scale, double* out_sum, void* scratch, void* stream);
 
 /* Same against a cached grid (obj_sdf branch, chamfer.py:84-85).  grid: host.                            */
 int pvamd_chamfer_grid(const pvamd_grid_t* grid, const float* W, int32_t B, const float* points, int64_t N,

@@ -30,12 +30,12 @@ def tiles_floats(F):
     return ((F + TRI_TILE - 1) // TRI_TILE) * (4 + 4 * (TRI_TILE // TRI_GROUP))
 
 
+MESH_SCRATCH_GROUPS = 2048
+
+
 def mesh_scratch_bytes(P):
     """PVAMD_MESH_SCRATCH_BYTES(P)"""
-    return ((P + 63) // 64) * (64 * 12 + 8)
-
-
-MESH_SCRATCH_MAX_POINTS = 1 << 17  # above this the kernel never spreads a group's tiles: no scratch needed
+    return 64 + min((P + 63) // 64, MESH_SCRATCH_GROUPS) * (64 * 12 + 8)
 
 
 _c_float_p = ctypes.POINTER(ctypes.c_float)
@@ -146,7 +146,8 @@ SIGNATURES = {
     "pvamd_sample_surface": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int32, ctypes.c_int64, ctypes.c_uint64,
                                             ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]),
     "pvamd_chamfer_mesh": (ctypes.c_int, [ctypes.POINTER(MeshDesc), ctypes.c_void_p, ctypes.c_int32, ctypes.c_void_p,
-                                          ctypes.c_void_p, ctypes.c_int64, ctypes.c_float, ctypes.c_void_p, ctypes.c_void_p]),
+                                          ctypes.c_void_p, ctypes.c_int64, ctypes.c_float, ctypes.c_void_p, ctypes.c_void_p,
+                                          ctypes.c_void_p]),
     "pvamd_chamfer_grid": (ctypes.c_int, [ctypes.POINTER(GridDesc), ctypes.c_void_p, ctypes.c_int32, ctypes.c_void_p,
                                           ctypes.c_int64, ctypes.c_float, ctypes.c_void_p, ctypes.c_void_p]),
     "pvamd_chain_fk": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int32, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,

@@ -67,9 +67,11 @@ def batch_chamfer_dist(world_to_object: torch.tensor, model_points_world_frame_e
         else:
             desc = obj_factory._mesh_desc()
             order = _lib.morton_order(pts)
+            # slots for the point groups the kernel hands over (those about equidistant to much of the mesh)
+            scratch = torch.empty((_lib.mesh_scratch_bytes(N) // 8,), dtype=torch.int64, device=dev)
             _lib.check(lib.pvamd_chamfer_mesh(ctypes.byref(desc), _lib.ptr(Wd), B, _lib.ptr(pts), _lib.ptr(order), N,
-                                              float(scale),
-                                              _lib.ptr(sums), _lib.stream_ptr()), "pvamd_chamfer_mesh")
+                                              float(scale), _lib.ptr(sums), _lib.ptr(scratch), _lib.stream_ptr()),
+                       "pvamd_chamfer_mesh")
     total_n = N
     if reduce_group is not None:
         import torch.distributed as dist

@@ -283,6 +283,7 @@ template <bool WITH_RAY>
 struct GroupShared {                    // the per-point slots all waves of the point group fold into
     unsigned long long best[64];
     int hits[WITH_RAY ? 64 : 1];
+    int handed;                         // the group was handed over (see scan_mesh)
     float dir[WITH_RAY ? 192 : 1];      // jittered ray direction (exact test), computed once by wave 0
     float dn[WITH_RAY ? 192 : 1];       // its unit vector (sphere tests)
 };
@@ -632,20 +633,109 @@ PVAMD_DEV bool scan_begin(const MeshArgs& m, GroupShared<WITH_RAY>& g, Wave<WITH
     return wave_setup(m, wv);
 }
 
-// The whole scan of one block.  On exit (after a barrier): g.best[lane] / g.hits[lane] = result for point `lane`.
+// ---- point groups that are handed over -----------------------------------------------------------------------
+// The work per point group is heavy-tailed: a group near the medial axis is about equidistant to much of the surface and
+// needs most of the mesh (C5: the group around the sphere's centre runs 5.8 ms on its own 8 waves while the other
+// 32,767 groups are done in 4.4 ms).  Such a group -- after its nearest tiles, with the reaches about final, it still
+// flags most of the tiles -- is HANDED OVER: it appends itself to a list in the caller's scratch and stops; a
+// second launch spreads the tiles of every listed group over kHeavyParts blocks of four waves (one per 64-record pass),
+// folding into the group's scratch slots with global atomicMin / atomicAdd, and a third writes the listed groups'
+// outputs.  The few-points path (below) is the same three launches with EVERY group listed up front.
+// scratch: int count | int entries[cap][2] (point group, transform) | u64 best[cap][64] | int hits[cap][64]
+struct HandOver {
+    int* count;
+    int* entries;
+    unsigned long long* best;
+    int* hits;
+    int cap;  // 0: nothing is handed over
+};
+constexpr int kHandOverHeader = 64;  // bytes
+static __host__ __device__ inline HandOver hand_over(void* scratch, int cap) {
+    HandOver h;
+    char* base = reinterpret_cast<char*>(scratch);
+    h.count = reinterpret_cast<int*>(base);
+    h.entries = reinterpret_cast<int*>(base + kHandOverHeader);
+    h.best = reinterpret_cast<unsigned long long*>(base + kHandOverHeader + (size_t)cap * 8);
+    h.hits = reinterpret_cast<int*>(base + kHandOverHeader + (size_t)cap * 8 + (size_t)cap * 64 * 8);
+    h.cap = scratch ? cap : 0;
+    return h;
+}
+#ifndef PVAMD_MESH_HEAVY_EIGHTHS
+#define PVAMD_MESH_HEAVY_EIGHTHS 5
+#endif
+#ifndef PVAMD_MESH_HEAVY_PARTS
+#define PVAMD_MESH_HEAVY_PARTS 32
+#endif
+// heavy = still flags this many eighths of the tiles (of at least kHeavyMinTiles) once its reaches are about final.  C5
+// (389 tiles, 32,768 groups), groups listed / ms: 96 tiles 1739 / 5.54, 192: 394 / 5.41, 256: 201 / 5.20, 300: 103 / 5.17
+// (16 -> 32 parts: -0.2 ms; 64: -0.05 more); nothing handed over: 5.9
+constexpr int kHeavyEighths = PVAMD_MESH_HEAVY_EIGHTHS;
+constexpr int kHeavyMinTiles = 128;
+constexpr int kHeavyParts = PVAMD_MESH_HEAVY_PARTS;
+constexpr int kHandOverCap = PVAMD_MESH_SCRATCH_GROUPS;
+
+// tiles some lane may still need, counted with lanes = tiles at (c, Q)
+template <bool WITH_RAY>
+PVAMD_DEV int flagged_tiles(const MeshArgs& m, const Wave<WITH_RAY>& wv) {
+    const int lane = threadIdx.x & 63;
+    const int ntiles = (m.F + kTile - 1) / kTile;
+    const f32x4* tiles4 = reinterpret_cast<const f32x4*>(m.tiles);
+    int n = 0;
+    for (int base = 0; base < ntiles; base += 64) {
+        const int ti = base + lane;
+        const f32x4 ts = tiles4[ti < ntiles ? ti : 0];
+        const V3 w = v3(ts.x - wv.wb.q.p.x, ts.y - wv.wb.q.p.y, ts.z - wv.wb.q.p.z);
+        const float dist2 = dot(w, w);
+        bool need = sphere_may_improve(wv.wb.q, dist2, ts.w);
+        if (WITH_RAY) need = need || axis_may_hit(wv.wb, w, dist2, ts.w);
+        n += __popcll(__ballot(need && ti < ntiles));
+    }
+    return n;
+}
+
+// The whole scan of one block.  On exit (after a barrier): g.best[lane] / g.hits[lane] = result for point `lane` --
+// unless the group was handed over (returns true): then the block has nothing to report.
 template <int SLICES, bool WITH_RAY>
-PVAMD_DEV void scan_mesh(const MeshArgs& m, MeshShared<SLICES, WITH_RAY>& sh, Wave<WITH_RAY>& wv, int wave, uint64_t seed,
-                         int64_t jitter_index) {
+PVAMD_DEV bool scan_mesh(const MeshArgs& m, MeshShared<SLICES, WITH_RAY>& sh, Wave<WITH_RAY>& wv, int wave, uint64_t seed,
+                         int64_t jitter_index, const HandOver& ho, int group, int transform) {
+    const int lane = threadIdx.x & 63;
+    bool handed = false;
     if (scan_begin(m, sh.g, wv, wave, seed, jitter_index, nullptr) && m.F > 0) {
         const int first = scan_seed(m, wv, wave, SLICES);
         if (first >= 0) {
             visit_tile<WITH_RAY>(m, sh.g, sh.w[wave], wv, first);
             drain_closest(m, sh.g, sh.w[wave], wv, true);  // publish what the nearest tile gave before looking further
+        }
+        if (ho.cap > 0 && (m.F + kTile - 1) / kTile >= kHeavyMinTiles) {  // uniform over the block
+            __syncthreads();  // every wave's nearest tile is in the slots
+            if (wave == 0) {
+                pull_reach(sh.g, wv);
+                int slot = -1;
+                if (flagged_tiles(m, wv) * 8 >= ((m.F + kTile - 1) / kTile) * kHeavyEighths) {
+                    if (lane == 0) slot = atomicAdd(ho.count, 1);
+                    slot = __builtin_amdgcn_readfirstlane(slot);
+                    if (slot >= ho.cap) slot = -1;  // list full: this block does the work itself
+                }
+                if (slot >= 0) {
+                    if (lane == 0) {
+                        ho.entries[2 * slot] = group;
+                        ho.entries[2 * slot + 1] = transform;
+                    }
+                    ho.best[(int64_t)slot * 64 + lane] = sh.g.best[lane];  // a bound to start from; the hits are counted afresh
+                    if (WITH_RAY) ho.hits[(int64_t)slot * 64 + lane] = 0;
+                }
+                if (lane == 0) sh.g.handed = slot >= 0 ? 1 : 0;
+            }
+            __syncthreads();
+            handed = sh.g.handed != 0;
+        }
+        if (!handed && first >= 0) {
             scan_tiles<WITH_RAY>(m, sh.g, sh.w[wave], wv, first, wave, SLICES);
             scan_finish(m, sh.g, sh.w[wave], wv);
         }
     }
     __syncthreads();
+    return handed;
 }
 
 // the closest point on the winning face, recomputed from its corners (same operations as during the scan)
@@ -699,116 +789,156 @@ PVAMD_DEV void write_query(const MeshArgs& m, const QueryOut& out, int64_t i, V3
 }
 
 // grid: x = groups of 64 points
+// waves per SIMD the allocator is held to (it would settle for 6): 8 fit beside the LDS of an 8-wave block (C5 query with
+// sign 7.4 -> 6.2 ms), 7 beside that of the smaller ones (2.16 M-point cache build 1.84 -> 1.73 ms; 8 spill: 1.85)
 template <int SLICES>
-__global__ __launch_bounds__(64 * SLICES) void mesh_query_kernel(MeshArgs m, const int* __restrict__ order,
+__global__ __launch_bounds__(64 * SLICES, SLICES == 8 ? 8 : (SLICES == 1 ? 6 : 7)) void mesh_query_kernel(MeshArgs m, const int* __restrict__ order,
                                                                 const float* __restrict__ pts, int64_t P,
-                                                                uint64_t seed, int64_t index_base, QueryOut out) {
+                                                                uint64_t seed, int64_t index_base, QueryOut out, HandOver ho) {
     __shared__ __attribute__((aligned(16))) MeshShared<SLICES, true> sh;
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int64_t k = (int64_t)blockIdx.x * 64 + lane;
     const int64_t i = point_index(order, k, P);
     Wave<true> wv;
     wv.s.p = v3(pts[3 * i], pts[3 * i + 1], pts[3 * i + 2]);
-    scan_mesh<SLICES, true>(m, sh, wv, wave, seed, index_base + i);
+    if (scan_mesh<SLICES, true>(m, sh, wv, wave, seed, index_base + i, ho, (int)blockIdx.x, 0)) return;
     if (wave != 0 || k >= P) return;
     write_query(m, out, i, wv.s.p, sh.g.best[lane], sh.g.hits[lane]);
 }
 
-// ---- few points: the tiles of one point group are spread over several blocks --------------------------------
-// A wave walks its flagged tiles one after the other; with only a few hundred point groups that serial walk, not
-// throughput, sets the time.  Three launches instead:
-//   fill    scratch = (no face, 0 hits)
-//   rest    (nparts blocks of four waves per group)  block y takes the tiles ti % nparts == y, wave w the w-th 64-record
-//           pass of each; starts from the tile-sphere bound; folds into scratch with global atomicMin / atomicAdd
-//   finish  (one wave per group)  outputs from the scratch values
-// (A `first` launch that visited the nearest tile and handed its bound to `rest` cost what it saved: C1 0.159 vs 0.158 ms,
-// 1000 points 0.089 vs 0.063 ms without it.)
-// scratch: u64 best[G*64], int hits[G*64], int spare[G*2], G = ceil(P/64) groups, indexed by processing position.
-struct SplitScratch {
-    unsigned long long* best;
-    int* hits;
-    int* firsts;
-};
-PVAMD_DEV SplitScratch split_scratch(void* scratch, int64_t groups) {
-    SplitScratch r;
-    r.best = reinterpret_cast<unsigned long long*>(scratch);
-    r.hits = reinterpret_cast<int*>(r.best + groups * 64);
-    r.firsts = r.hits + groups * 64;
-    return r;
+// chamfer.py:81-82 transform_points, k-ordered fma chain
+PVAMD_DEV V3 chamfer_point(const float* __restrict__ M, const float* __restrict__ pts, int64_t i) {
+    const float px = pts[3 * i], py = pts[3 * i + 1], pz = pts[3 * i + 2];
+    return v3(add_rn(fmaf(M[2], pz, fmaf(M[1], py, mul_rn(M[0], px))), M[3]),
+              add_rn(fmaf(M[6], pz, fmaf(M[5], py, mul_rn(M[4], px))), M[7]),
+              add_rn(fmaf(M[10], pz, fmaf(M[9], py, mul_rn(M[8], px))), M[11]));
 }
 
-// grid: x = groups of 64 points, y = part; wave w takes the w-th 64-record pass of the block's tiles
-__global__ __launch_bounds__(64 * (kTile / 64)) void mesh_query_rest_kernel(MeshArgs m, const int* __restrict__ order,
-                                                                           const float* __restrict__ pts, int64_t P,
-                                                                           uint64_t seed, int64_t index_base, void* scratch) {
-    constexpr int SLICES = kTile / 64;
-    __shared__ __attribute__((aligned(16))) MeshShared<SLICES, true> sh;
-    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int64_t k = (int64_t)blockIdx.x * 64 + lane;
-    const int64_t i = point_index(order, k, P);
-    Wave<true> wv;
-    wv.s.p = v3(pts[3 * i], pts[3 * i + 1], pts[3 * i + 2]);
-    const SplitScratch sc = split_scratch(scratch, gridDim.x);
-    const unsigned long long start = sc.best[k];
-    if (scan_begin(m, sh.g, wv, wave, seed, index_base + i, &start)) {
-        scan_seed(m, wv, 0, 1);  // the bound from the tile spheres; the other blocks' finds arrive through scratch only at the end
-        scan_tiles<true>(m, sh.g, sh.w[wave], wv, -1, (int)blockIdx.y, (int)gridDim.y, wave, wave + 1);
-        scan_finish(m, sh.g, sh.w[wave], wv);
-    }
-    __syncthreads();
-    if (wave != 0) return;
-    if (sh.g.best[lane] < start) atomicMin(&sc.best[k], sh.g.best[lane]);
-    if (sh.g.hits[lane] != 0) atomicAdd(&sc.hits[k], sh.g.hits[lane]);
-}
-
-__global__ __launch_bounds__(64) void mesh_scratch_fill_kernel(void* scratch) {
-    const SplitScratch sc = split_scratch(scratch, gridDim.x);
-    const int64_t k = (int64_t)blockIdx.x * 64 + threadIdx.x;
-    sc.best[k] = kBestInit;
-    sc.hits[k] = 0;
-}
-
-__global__ __launch_bounds__(64) void mesh_query_finish_kernel(MeshArgs m, const int* __restrict__ order,
-                                                               const float* __restrict__ pts, int64_t P, const void* scratch,
-                                                               QueryOut out) {
-    const int64_t k = (int64_t)blockIdx.x * 64 + threadIdx.x;
-    if (k >= P) return;
-    const SplitScratch sc = split_scratch(const_cast<void*>(scratch), gridDim.x);
-    const int64_t i = order ? (int64_t)order[k] : k;
-    write_query(m, out, i, v3(pts[3 * i], pts[3 * i + 1], pts[3 * i + 2]), sc.best[k], sc.hits[k]);
-}
-
-// grid: x = groups of 64 points, y = transform b
-template <int SLICES>
-__global__ __launch_bounds__(64 * SLICES) void chamfer_mesh_kernel(MeshArgs m, const int* __restrict__ order,
-                                                                  const float* __restrict__ W,
-                                                                  const float* __restrict__ pts, int64_t N, float scale,
-                                                                  double* __restrict__ out_sum) {
-    __shared__ __attribute__((aligned(16))) MeshShared<SLICES, false> sh;
-    const float* M = W + 16 * (int64_t)blockIdx.y;
-    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int64_t k = (int64_t)blockIdx.x * 64 + lane;
-    const bool live = k < N;
-    const int64_t ii = point_index(order, k, N);
-    const float px = pts[3 * ii], py = pts[3 * ii + 1], pz = pts[3 * ii + 2];
-    Wave<false> wv;
-    // chamfer.py:81-82 transform_points, k-ordered fma chain
-    wv.s.p = v3(add_rn(fmaf(M[2], pz, fmaf(M[1], py, mul_rn(M[0], px))), M[3]),
-                add_rn(fmaf(M[6], pz, fmaf(M[5], py, mul_rn(M[4], px))), M[7]),
-                add_rn(fmaf(M[10], pz, fmaf(M[9], py, mul_rn(M[8], px))), M[11]));
-    scan_mesh<SLICES, false>(m, sh, wv, wave, 0, 0);
-    if (wave != 0) return;
-    const unsigned long long found = sh.g.best[lane];
+// one wave's share of sum((scale * d)^2) from the winning (d2, face) of each of its points
+PVAMD_DEV void chamfer_accumulate(const MeshArgs& m, V3 p, bool live, unsigned long long found, float scale, double* __restrict__ sum) {
     const int best_f = (unsigned)(found >> 32) == 0x7F800000u ? -1 : (int)(unsigned)found;
     double acc = 0.0;
     if (live && best_f >= 0) {
-        const V3 q = closest_on_record(m, m.rec_of_face[best_f], wv.s.p);
-        const float sd = mul_rn(scale, norm3_unfused(sub(q, wv.s.p)));  // chamfer.py:92
+        const V3 q = closest_on_record(m, m.rec_of_face[best_f], p);
+        const float sd = mul_rn(scale, norm3_unfused(sub(q, p)));  // chamfer.py:92
         acc = (double)mul_rn(sd, sd);
     }
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off, 64);
-    if (lane == 0) atomicAdd(out_sum + blockIdx.y, acc);
+    if ((threadIdx.x & 63) == 0) atomicAdd(sum, acc);
+}
+
+// grid: x = groups of 64 points, y = transform b (b0 = the slab's first transform)
+template <int SLICES>
+__global__ __launch_bounds__(64 * SLICES) void chamfer_mesh_kernel(MeshArgs m, const int* __restrict__ order,
+                                                                  const float* __restrict__ W, int b0,
+                                                                  const float* __restrict__ pts, int64_t N, float scale,
+                                                                  double* __restrict__ out_sum, HandOver ho) {
+    __shared__ __attribute__((aligned(16))) MeshShared<SLICES, false> sh;
+    const int b = b0 + (int)blockIdx.y;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int64_t k = (int64_t)blockIdx.x * 64 + lane;
+    Wave<false> wv;
+    wv.s.p = chamfer_point(W + 16 * (int64_t)b, pts, point_index(order, k, N));
+    if (scan_mesh<SLICES, false>(m, sh, wv, wave, 0, 0, ho, (int)blockIdx.x, b)) return;
+    if (wave != 0) return;
+    chamfer_accumulate(m, wv.s.p, k < N, sh.g.best[lane], scale, out_sum + b);
+}
+
+// ---- the listed groups: tiles spread over blocks ----------------------------------------------------------------
+// A wave walks its flagged tiles one after the other; for a heavy group, or with only a few hundred point groups in
+// the whole query, that serial walk -- not throughput -- sets the time.
+//   list    few points: every group is listed up front, slots = (no face, 0 hits); otherwise the scan above lists the
+//           heavy ones as it finds them
+//   parts   (nparts blocks of four waves per listed group)  block y takes the tiles ti % nparts == y, wave w the w-th
+//           64-record pass of each; starts from the slot's bound; folds into the slots with global atomicMin / atomicAdd
+//   finish  (one wave per listed group)  outputs from the slots
+// (A `first` launch that visited the nearest tile and handed its bound on cost what it saved in the few-points path: C1
+// 0.159 vs 0.158 ms, 1000 points 0.089 vs 0.063 ms without it.)
+__global__ __launch_bounds__(64) void hand_over_all_kernel(HandOver ho, int groups) {
+    const int g = blockIdx.x;
+    ho.best[(int64_t)g * 64 + threadIdx.x] = kBestInit;
+    ho.hits[(int64_t)g * 64 + threadIdx.x] = 0;
+    if (threadIdx.x == 0) {
+        ho.entries[2 * g] = g;
+        ho.entries[2 * g + 1] = 0;
+        if (g == 0) *ho.count = groups;
+    }
+}
+__global__ void hand_over_none_kernel(HandOver ho) { *ho.count = 0; }
+
+#ifndef PVAMD_MESH_PARTS_WAVES
+#define PVAMD_MESH_PARTS_WAVES 7  // waves per SIMD the parts kernels are held to (C1: 0.165 ms at the allocator's 5, 0.144 at 6-7;
+                                  // 30k points 0.201 / 0.190 / 0.207 ms at 6 / 7 / 8)
+#endif
+// one listed group in one block: wave w takes the w-th 64-record pass of the tiles ti % gridDim.y == blockIdx.y
+template <bool WITH_RAY>
+PVAMD_DEV void parts_of_group(const MeshArgs& m, MeshShared<kTile / 64, WITH_RAY>& sh, const int* __restrict__ order,
+                              const float* __restrict__ M, const float* __restrict__ pts, int64_t P, uint64_t seed,
+                              int64_t index_base, const HandOver& ho, int slot, int group) {
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int64_t i = point_index(order, (int64_t)group * 64 + lane, P);
+    Wave<WITH_RAY> wv;
+    wv.s.p = M ? chamfer_point(M, pts, i) : v3(pts[3 * i], pts[3 * i + 1], pts[3 * i + 2]);
+    const unsigned long long start = ho.best[(int64_t)slot * 64 + lane];
+    if (scan_begin(m, sh.g, wv, wave, seed, index_base + i, &start)) {
+        scan_seed(m, wv, 0, 1);  // the bound from the tile spheres (the slot's own bound is pulled in scan_tiles)
+        scan_tiles<WITH_RAY>(m, sh.g, sh.w[wave], wv, -1, (int)blockIdx.y, (int)gridDim.y, wave, wave + 1);
+        scan_finish(m, sh.g, sh.w[wave], wv);
+    }
+    __syncthreads();
+    if (wave == 0) {
+        if (sh.g.best[lane] < start) atomicMin(&ho.best[(int64_t)slot * 64 + lane], sh.g.best[lane]);
+        if (WITH_RAY && sh.g.hits[lane] != 0) atomicAdd(&ho.hits[(int64_t)slot * 64 + lane], sh.g.hits[lane]);
+    }
+}
+
+// few points: grid x = point groups (slot g = group g), y = part
+__global__ __launch_bounds__(64 * (kTile / 64), PVAMD_MESH_PARTS_WAVES) void mesh_parts_all_kernel(MeshArgs m, const int* __restrict__ order,
+                                                                          const float* __restrict__ pts, int64_t P,
+                                                                          uint64_t seed, int64_t index_base, HandOver ho) {
+    __shared__ __attribute__((aligned(16))) MeshShared<kTile / 64, true> sh;
+    parts_of_group<true>(m, sh, order, nullptr, pts, P, seed, index_base, ho, (int)blockIdx.x, (int)blockIdx.x);
+}
+
+// the listed groups: grid x = slots (strided over the list), y = part
+template <bool WITH_RAY>
+__global__ __launch_bounds__(64 * (kTile / 64), PVAMD_MESH_PARTS_WAVES) void mesh_parts_kernel(MeshArgs m, const int* __restrict__ order,
+                                                                      const float* __restrict__ W,
+                                                                      const float* __restrict__ pts, int64_t P,
+                                                                      uint64_t seed, int64_t index_base, HandOver ho) {
+    __shared__ __attribute__((aligned(16))) MeshShared<kTile / 64, WITH_RAY> sh;
+    const int listed = min(*ho.count, ho.cap);
+    for (int slot = blockIdx.x; slot < listed; slot += gridDim.x) {
+        parts_of_group<WITH_RAY>(m, sh, order, W ? W + 16 * (int64_t)ho.entries[2 * slot + 1] : nullptr, pts, P, seed, index_base,
+                                 ho, slot, ho.entries[2 * slot]);
+        __syncthreads();  // the slots in LDS are reused by the next listed group
+    }
+}
+
+__global__ __launch_bounds__(64) void mesh_query_finish_kernel(MeshArgs m, const int* __restrict__ order,
+                                                               const float* __restrict__ pts, int64_t P, HandOver ho,
+                                                               int known, QueryOut out) {
+    const int listed = known >= 0 ? known : min(*ho.count, ho.cap);
+    for (int slot = blockIdx.x; slot < listed; slot += gridDim.x) {
+        const int64_t k = (int64_t)(known >= 0 ? slot : ho.entries[2 * slot]) * 64 + threadIdx.x;
+        if (k >= P) continue;
+        const int64_t i = order ? (int64_t)order[k] : k;
+        write_query(m, out, i, v3(pts[3 * i], pts[3 * i + 1], pts[3 * i + 2]), ho.best[(int64_t)slot * 64 + threadIdx.x],
+                    ho.hits[(int64_t)slot * 64 + threadIdx.x]);
+    }
+}
+
+__global__ __launch_bounds__(64) void chamfer_finish_kernel(MeshArgs m, const int* __restrict__ order, const float* __restrict__ W,
+                                                            const float* __restrict__ pts, int64_t N, float scale, HandOver ho,
+                                                            double* __restrict__ out_sum) {
+    const int listed = min(*ho.count, ho.cap);
+    for (int slot = blockIdx.x; slot < listed; slot += gridDim.x) {
+        const int64_t k = (int64_t)ho.entries[2 * slot] * 64 + threadIdx.x;
+        const int b = ho.entries[2 * slot + 1];
+        const V3 p = chamfer_point(W + 16 * (int64_t)b, pts, point_index(order, k, N));
+        chamfer_accumulate(m, p, k < N, ho.best[(int64_t)slot * 64 + threadIdx.x], scale, out_sum + b);
+    }
 }
 
 // Z-order key of each point inside the box [lo, hi] (device [2][3]).  Sorting queries by it makes the 64 points of a
@@ -967,6 +1097,9 @@ extern "C" int pvamd_mesh_prepare(const float* tri, const int32_t* face_id, int3
     return (int)hipGetLastError();
 }
 
+// grid.x of the launches that walk the list of handed-over groups
+static unsigned list_blocks(int cap) { return (unsigned)(cap < 512 ? (cap < 1 ? 1 : cap) : 512); }
+
 extern "C" int pvamd_mesh_query(const pvamd_mesh_t* mesh, const float* points, const int32_t* order, int64_t P,
                                 uint64_t jitter_seed, int64_t index_base, float* out_closest, float* out_dist, float* out_grad,
                                 int32_t* out_face, float* out_normal, void* scratch, void* stream) {
@@ -984,36 +1117,48 @@ extern "C" int pvamd_mesh_query(const pvamd_mesh_t* mesh, const float* points, c
     const QueryOut out{out_closest, out_dist, out_grad, out_face, out_normal};
     const int ntiles = (mesh->F + kTile - 1) / kTile;
     const int slices = pick_slices(groups, ntiles);
+    const int cap = (int)(groups < kHandOverCap ? groups : kHandOverCap);  // what PVAMD_MESH_SCRATCH_BYTES(P) holds
+    const HandOver ho = hand_over(scratch, cap);
     // few point groups, many tiles: spread each group's tiles over `parts` blocks of four waves, one per 64-record pass
-    // (see mesh_query_rest_kernel)
+    // (see mesh_parts_kernel)
     int parts = (int)((int64_t)kFillWaves / (groups * (kTile / 64)));
     if (parts > ntiles) parts = ntiles;
     {   // cap, but never below what fills the chip twice over (1000 points: 0.061 ms with 62 parts, 0.080 with 32)
         const int64_t fill = 16384 / (groups * (kTile / 64));
-        const int cap = fill > kMaxParts ? (int)fill : kMaxParts;
-        if (parts > cap) parts = cap;
+        const int most = fill > kMaxParts ? (int)fill : kMaxParts;
+        if (parts > most) parts = most;
     }
-    if (scratch && parts >= kMinParts) {
-        hipLaunchKernelGGL(mesh_scratch_fill_kernel, dim3((unsigned)groups), dim3(64), 0, s, scratch);
-        hipLaunchKernelGGL(mesh_query_rest_kernel, dim3((unsigned)groups, (unsigned)parts), dim3(kTile), 0, s, m, order, points, P, jitter_seed, index_base, scratch);
-        hipLaunchKernelGGL(mesh_query_finish_kernel, dim3((unsigned)groups), dim3(64), 0, s, m, order, points, P, scratch, out);
+    if (ho.cap > 0 && groups <= ho.cap && parts >= kMinParts) {
+        hipLaunchKernelGGL(hand_over_all_kernel, dim3((unsigned)groups), dim3(64), 0, s, ho, (int)groups);
+        hipLaunchKernelGGL(mesh_parts_all_kernel, dim3((unsigned)groups, (unsigned)parts), dim3(kTile), 0, s, m, order, points, P,
+                           jitter_seed, index_base, ho);
+        hipLaunchKernelGGL(mesh_query_finish_kernel, dim3((unsigned)groups), dim3(64), 0, s, m, order, points, P, ho, (int)groups, out);
         return (int)hipGetLastError();
     }
+    const bool heavy = ho.cap > 0 && ntiles >= kHeavyMinTiles;
+    const HandOver none = hand_over(nullptr, 0);
+    if (heavy) hipLaunchKernelGGL(hand_over_none_kernel, dim3(1), dim3(1), 0, s, ho);
     switch (slices) {
-        case 8: hipLaunchKernelGGL((mesh_query_kernel<8>), dim3((unsigned)groups), dim3(512), 0, s, m, order, points, P, jitter_seed, index_base, out); break;
-        case 4: hipLaunchKernelGGL((mesh_query_kernel<4>), dim3((unsigned)groups), dim3(256), 0, s, m, order, points, P, jitter_seed, index_base, out); break;
-        case 2: hipLaunchKernelGGL((mesh_query_kernel<2>), dim3((unsigned)groups), dim3(128), 0, s, m, order, points, P, jitter_seed, index_base, out); break;
-        default: hipLaunchKernelGGL((mesh_query_kernel<1>), dim3((unsigned)groups), dim3(64), 0, s, m, order, points, P, jitter_seed, index_base, out); break;
+        case 8: hipLaunchKernelGGL((mesh_query_kernel<8>), dim3((unsigned)groups), dim3(512), 0, s, m, order, points, P, jitter_seed, index_base, out, heavy ? ho : none); break;
+        case 4: hipLaunchKernelGGL((mesh_query_kernel<4>), dim3((unsigned)groups), dim3(256), 0, s, m, order, points, P, jitter_seed, index_base, out, heavy ? ho : none); break;
+        case 2: hipLaunchKernelGGL((mesh_query_kernel<2>), dim3((unsigned)groups), dim3(128), 0, s, m, order, points, P, jitter_seed, index_base, out, heavy ? ho : none); break;
+        default: hipLaunchKernelGGL((mesh_query_kernel<1>), dim3((unsigned)groups), dim3(64), 0, s, m, order, points, P, jitter_seed, index_base, out, heavy ? ho : none); break;
+    }
+    if (heavy) {
+        hipLaunchKernelGGL((mesh_parts_kernel<true>), dim3(list_blocks(ho.cap), kHeavyParts), dim3(kTile), 0, s, m, order,
+                           (const float*)nullptr, points, P, jitter_seed, index_base, ho);
+        hipLaunchKernelGGL(mesh_query_finish_kernel, dim3(list_blocks(ho.cap)), dim3(64), 0, s, m, order, points, P, ho, -1, out);
     }
     return (int)hipGetLastError();
 }
 
 extern "C" int pvamd_chamfer_mesh(const pvamd_mesh_t* mesh, const float* W, int32_t B, const float* points,
-                                  const int32_t* order, int64_t N, float scale, double* out_sum, void* stream) {
+                                  const int32_t* order, int64_t N, float scale, double* out_sum, void* scratch, void* stream) {
     if (B < 0 || N < 0) return PVAMD_E_SHAPE;
     if (B == 0) return 0;
     if (!mesh || !out_sum) return PVAMD_E_NULL;
     if (mesh->F < 0) return PVAMD_E_SHAPE;
+    if (scratch && !aligned_to(scratch, 8)) return PVAMD_E_ALIGN;
     hipStream_t s = (hipStream_t)stream;
     hipLaunchKernelGGL(zero_f64_kernel, dim3((B + 255) / 256), dim3(256), 0, s, out_sum, B);
     if (N == 0 || mesh->F == 0) return (int)hipGetLastError();
@@ -1022,17 +1167,26 @@ extern "C" int pvamd_chamfer_mesh(const pvamd_mesh_t* mesh, const float* W, int3
     const MeshArgs m = mesh_args(*mesh);
     const int64_t groups = (N + 63) / 64;
     if (groups > 0x7fffffff) return PVAMD_E_SHAPE;
-    const int slices = pick_slices(groups * (int64_t)B, (mesh->F + kTile - 1) / kTile);
+    const int ntiles = (mesh->F + kTile - 1) / kTile;
+    const int slices = pick_slices(groups * (int64_t)B, ntiles);
+    const int cap = (int)(groups < kHandOverCap ? groups : kHandOverCap);
+    const HandOver ho = hand_over(ntiles >= kHeavyMinTiles ? scratch : nullptr, cap);
+    if (ho.cap > 0) hipLaunchKernelGGL(hand_over_none_kernel, dim3(1), dim3(1), 0, s, ho);
     // y-dimension of a HIP grid is limited to 65535: walk B in slabs
     for (int32_t b0 = 0; b0 < B; b0 += 65535) {
         const int32_t nb = (B - b0) < 65535 ? (B - b0) : 65535;
         const dim3 grid((unsigned)groups, nb);
         switch (slices) {
-            case 8: hipLaunchKernelGGL((chamfer_mesh_kernel<8>), grid, dim3(512), 0, s, m, order, W + 16 * (int64_t)b0, points, N, scale, out_sum + b0); break;
-            case 4: hipLaunchKernelGGL((chamfer_mesh_kernel<4>), grid, dim3(256), 0, s, m, order, W + 16 * (int64_t)b0, points, N, scale, out_sum + b0); break;
-            case 2: hipLaunchKernelGGL((chamfer_mesh_kernel<2>), grid, dim3(128), 0, s, m, order, W + 16 * (int64_t)b0, points, N, scale, out_sum + b0); break;
-            default: hipLaunchKernelGGL((chamfer_mesh_kernel<1>), grid, dim3(64), 0, s, m, order, W + 16 * (int64_t)b0, points, N, scale, out_sum + b0); break;
+            case 8: hipLaunchKernelGGL((chamfer_mesh_kernel<8>), grid, dim3(512), 0, s, m, order, W, b0, points, N, scale, out_sum, ho); break;
+            case 4: hipLaunchKernelGGL((chamfer_mesh_kernel<4>), grid, dim3(256), 0, s, m, order, W, b0, points, N, scale, out_sum, ho); break;
+            case 2: hipLaunchKernelGGL((chamfer_mesh_kernel<2>), grid, dim3(128), 0, s, m, order, W, b0, points, N, scale, out_sum, ho); break;
+            default: hipLaunchKernelGGL((chamfer_mesh_kernel<1>), grid, dim3(64), 0, s, m, order, W, b0, points, N, scale, out_sum, ho); break;
         }
+    }
+    if (ho.cap > 0) {
+        hipLaunchKernelGGL((mesh_parts_kernel<false>), dim3(list_blocks(ho.cap), kHeavyParts), dim3(kTile), 0, s, m, order, W, points,
+                           N, (uint64_t)0, (int64_t)0, ho);
+        hipLaunchKernelGGL(chamfer_finish_kernel, dim3(list_blocks(ho.cap)), dim3(64), 0, s, m, order, W, points, N, scale, ho, out_sum);
     }
     return (int)hipGetLastError();
 }

@@ -206,8 +206,9 @@ class ObjectFactory(abc.ABC):
         with _lib.on_device(dev):
             order = _lib.morton_order(flat)
             scratch = None
-            if 0 < P <= _lib.MESH_SCRATCH_MAX_POINTS and getattr(self, "tile_split", True):
-                # small query: let the kernel spread each group's tiles over several workgroups
+            if P > 0 and getattr(self, "tile_split", True):
+                # lets the kernel spread a point group's tiles over several workgroups (every group of a small query, the
+                # heavy groups of a large one)
                 scratch = torch.empty((_lib.mesh_scratch_bytes(P) // 8,), dtype=torch.int64, device=dev)
             _lib.check(lib.pvamd_mesh_query(ctypes.byref(desc), _lib.ptr(flat), _lib.ptr(order), P,
                                             ctypes.c_uint64(self.jitter_seed),

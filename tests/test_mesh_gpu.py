@@ -180,6 +180,47 @@ def test_eight_wave_configuration_on_a_mesh_of_many_tiles():
     assert np.array_equal(res.gradient[:n].cpu().numpy(), og)
 
 
+def test_heavy_point_groups_are_handed_over_with_the_same_bits():
+    """A sphere mesh of more than 128 tiles and points around its centre -- about equidistant to the whole surface: such
+    point groups are handed over to a second launch that spreads their tiles over many workgroups (scratch given), or walk
+    the mesh on their own 8 waves (scratch withheld).  Same bits either way, and the oracle's on a slice that contains
+    centre points.  The chamfer entry point reports how many groups it handed over."""
+    import ctypes
+    from pytorch_volumetric_amd import _lib
+    obj = pv.MeshObjectFactory(mesh=mesh_io.uv_sphere_mesh(0.1, 150, 120))
+    assert obj.num_faces > 128 * 256
+    g = torch.Generator().manual_seed(3)
+    centre = (torch.rand(4096, 3, generator=g) - 0.5) * 0.02
+    pts = torch.cat((centre[:700], H.uniform_points((1 << 17) - 4096, [-0.15] * 3, [0.15] * 3, seed=9), centre[700:])).float()
+    obj.jitter_seed = 11
+    outs = []
+    for split in (True, False):
+        obj.tile_split = split
+        r = obj.object_frame_closest_point(pts.cuda(), compute_normal=True)
+        outs.append((r.closest.clone(), r.distance.clone(), r.gradient.clone(), obj._last_face_ids.clone()))
+    for a_, b_ in zip(*outs):
+        assert torch.equal(a_, b_)
+    n = 1500
+    oc, od, og, of, on = oracle.mesh_query(H.oracle_mesh_from_factory(obj), pts[:n].numpy(), seed=11)
+    assert np.array_equal(outs[0][3][:n].cpu().numpy(), of) and np.array_equal(outs[0][0][:n].cpu().numpy(), oc)
+    assert np.array_equal(outs[0][1][:n].cpu().numpy(), od) and np.array_equal(outs[0][2][:n].cpu().numpy(), og)
+    # chamfer: with / without the scratch, and the number of groups listed
+    lib = _lib.load()
+    desc = obj._mesh_desc()
+    dev_pts = pts.cuda().contiguous()
+    W = torch.eye(4).unsqueeze(0).repeat(2, 1, 1).cuda().contiguous()
+    W[1, :3, 3] = torch.tensor([0.01, 0.0, -0.02])
+    order = _lib.morton_order(dev_pts)
+    sums = torch.empty((2, 2), dtype=torch.float64, device="cuda")
+    scratch = torch.zeros((_lib.mesh_scratch_bytes(pts.shape[0]) // 8,), dtype=torch.int64, device="cuda")
+    for k, sc in enumerate((None, scratch)):
+        _lib.check(lib.pvamd_chamfer_mesh(ctypes.byref(desc), _lib.ptr(W), 2, _lib.ptr(dev_pts), _lib.ptr(order), pts.shape[0],
+                                          1000.0, _lib.ptr(sums[k]), _lib.ptr(sc), _lib.stream_ptr()), "pvamd_chamfer_mesh")
+    listed = int(scratch.view(torch.int32)[0].item())
+    assert 0 < listed < 2 * (pts.shape[0] // 64), listed
+    assert torch.allclose(sums[0], sums[1], rtol=1e-12, atol=0)
+
+
 def test_culling_is_exact_for_far_and_degenerate_queries():
     """Points far from the mesh (every tile 'far'), on vertices / edges (distance 0, ties), and NaN."""
     obj = factory("box_template.obj")

@@ -14,9 +14,10 @@ W = torch.eye(4).unsqueeze(0).cuda()
 lib = _lib.load()
 desc = mesh._mesh_desc()
 sums = torch.empty((1,), dtype=torch.float64, device="cuda")
+scratch = torch.empty((_lib.mesh_scratch_bytes(N) // 8,), dtype=torch.int64, device="cuda")  # None: nothing is handed over
 def run(order):
     _lib.check(lib.pvamd_chamfer_mesh(ctypes.byref(desc), _lib.ptr(W), 1, _lib.ptr(pts), _lib.ptr(order), N, 1000.0,
-                                      _lib.ptr(sums), _lib.stream_ptr()), "chamfer")
+                                      _lib.ptr(sums), _lib.ptr(scratch), _lib.stream_ptr()), "chamfer")
 order = _lib.morton_order(pts)
 t0, _ = gpu_time(lambda: run(order), reps=5); ref = sums.item()
 # group-level reorder: groups of 64 consecutive points in Morton order, sorted by their mean distance to the centre
