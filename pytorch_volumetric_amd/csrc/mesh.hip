@@ -670,7 +670,10 @@ static __host__ __device__ inline HandOver hand_over(void* scratch, int cap) {
 // (389 tiles, 32,768 groups), groups listed / ms: 96 tiles 1739 / 5.54, 192: 394 / 5.41, 256: 201 / 5.20, 300: 103 / 5.17
 // (16 -> 32 parts: -0.2 ms; 64: -0.05 more); nothing handed over: 5.9
 constexpr int kHeavyEighths = PVAMD_MESH_HEAVY_EIGHTHS;
-constexpr int kHeavyMinTiles = 128;
+#ifndef PVAMD_MESH_HEAVY_MIN_TILES
+#define PVAMD_MESH_HEAVY_MIN_TILES 128
+#endif
+constexpr int kHeavyMinTiles = PVAMD_MESH_HEAVY_MIN_TILES;
 constexpr int kHeavyParts = PVAMD_MESH_HEAVY_PARTS;
 constexpr int kHandOverCap = PVAMD_MESH_SCRATCH_GROUPS;
 
