@@ -612,13 +612,15 @@ PVAMD_DEV void scan_finish(const MeshArgs& m, GroupShared<WITH_RAY>& g, WaveLoca
 // False when no lane has a finite point (uniform over the block: every wave holds the same points).
 template <bool WITH_RAY>
 PVAMD_DEV bool scan_begin(const MeshArgs& m, GroupShared<WITH_RAY>& g, Wave<WITH_RAY>& wv, int wave, uint64_t seed,
-                          int64_t jitter_index, const unsigned long long* start) {
+                          int64_t jitter_index, const unsigned long long* start, const float* __restrict__ drawn = nullptr) {
     const int lane = threadIdx.x & 63;
     if (wave == 0) {
         g.best[lane] = start ? *start : kBestInit;
         if (WITH_RAY) {
             g.hits[lane] = 0;
-            const V3 dir = jitter_dir(m.ray_dir, seed, jitter_index);
+            // the jitter is ~1200 instructions of hashing on the block's critical path: a listed group finds it drawn already
+            const V3 dir = drawn ? v3(drawn[3 * lane], drawn[3 * lane + 1], drawn[3 * lane + 2])
+                                 : jitter_dir(m.ray_dir, seed, jitter_index);
             const float inv_len = 1.f / sqrt_rn(dot(dir, dir));
             g.dir[3 * lane] = dir.x; g.dir[3 * lane + 1] = dir.y; g.dir[3 * lane + 2] = dir.z;
             g.dn[3 * lane] = dir.x * inv_len; g.dn[3 * lane + 1] = dir.y * inv_len; g.dn[3 * lane + 2] = dir.z * inv_len;
@@ -641,12 +643,14 @@ PVAMD_DEV bool scan_begin(const MeshArgs& m, GroupShared<WITH_RAY>& g, Wave<WITH
 // second launch spreads the tiles of every listed group over kHeavyParts blocks of four waves (one per 64-record pass),
 // folding into the group's scratch slots with global atomicMin / atomicAdd, and a third writes the listed groups'
 // outputs.  The few-points path (below) is the same three launches with EVERY group listed up front.
-// scratch: int count | int entries[cap][2] (point group, transform) | u64 best[cap][64] | int hits[cap][64]
+// scratch: int count | int entries[cap][2] (point group, transform) | u64 best[cap][64] | int hits[cap][64] |
+//          float dir[cap][64][3] (the jittered ray of each point, drawn once)
 struct HandOver {
     int* count;
     int* entries;
     unsigned long long* best;
     int* hits;
+    float* dir;
     int cap;  // 0: nothing is handed over
 };
 constexpr int kHandOverHeader = 64;  // bytes
@@ -657,6 +661,7 @@ static __host__ __device__ inline HandOver hand_over(void* scratch, int cap) {
     h.entries = reinterpret_cast<int*>(base + kHandOverHeader);
     h.best = reinterpret_cast<unsigned long long*>(base + kHandOverHeader + (size_t)cap * 8);
     h.hits = reinterpret_cast<int*>(base + kHandOverHeader + (size_t)cap * 8 + (size_t)cap * 64 * 8);
+    h.dir = reinterpret_cast<float*>(base + kHandOverHeader + (size_t)cap * 8 + (size_t)cap * 64 * 12);
     h.cap = scratch ? cap : 0;
     return h;
 }
@@ -725,7 +730,10 @@ PVAMD_DEV bool scan_mesh(const MeshArgs& m, MeshShared<SLICES, WITH_RAY>& sh, Wa
                         ho.entries[2 * slot + 1] = transform;
                     }
                     ho.best[(int64_t)slot * 64 + lane] = sh.g.best[lane];  // a bound to start from; the hits are counted afresh
-                    if (WITH_RAY) ho.hits[(int64_t)slot * 64 + lane] = 0;
+                    if (WITH_RAY) {
+                        ho.hits[(int64_t)slot * 64 + lane] = 0;
+                        for (int d = 0; d < 3; ++d) ho.dir[((int64_t)slot * 64 + lane) * 3 + d] = sh.g.dir[3 * lane + d];
+                    }
                 }
                 if (lane == 0) sh.g.handed = slot >= 0 ? 1 : 0;
             }
@@ -858,10 +866,14 @@ __global__ __launch_bounds__(64 * SLICES) void chamfer_mesh_kernel(MeshArgs m, c
 //   finish  (one wave per listed group)  outputs from the slots
 // (A `first` launch that visited the nearest tile and handed its bound on cost what it saved in the few-points path: C1
 // 0.159 vs 0.158 ms, 1000 points 0.089 vs 0.063 ms without it.)
-__global__ __launch_bounds__(64) void hand_over_all_kernel(HandOver ho, int groups) {
+__global__ __launch_bounds__(64) void hand_over_all_kernel(MeshArgs m, const int* __restrict__ order, int64_t P, uint64_t seed,
+                                                           int64_t index_base, HandOver ho, int groups) {
     const int g = blockIdx.x;
     ho.best[(int64_t)g * 64 + threadIdx.x] = kBestInit;
     ho.hits[(int64_t)g * 64 + threadIdx.x] = 0;
+    const V3 dir = jitter_dir(m.ray_dir, seed, index_base + point_index(order, (int64_t)g * 64 + threadIdx.x, P));
+    float* o = ho.dir + ((int64_t)g * 64 + threadIdx.x) * 3;
+    o[0] = dir.x; o[1] = dir.y; o[2] = dir.z;
     if (threadIdx.x == 0) {
         ho.entries[2 * g] = g;
         ho.entries[2 * g + 1] = 0;
@@ -884,7 +896,7 @@ PVAMD_DEV void parts_of_group(const MeshArgs& m, MeshShared<kTile / 64, WITH_RAY
     Wave<WITH_RAY> wv;
     wv.s.p = M ? chamfer_point(M, pts, i) : v3(pts[3 * i], pts[3 * i + 1], pts[3 * i + 2]);
     const unsigned long long start = ho.best[(int64_t)slot * 64 + lane];
-    if (scan_begin(m, sh.g, wv, wave, seed, index_base + i, &start)) {
+    if (scan_begin(m, sh.g, wv, wave, seed, index_base + i, &start, WITH_RAY ? ho.dir + (int64_t)slot * 192 : nullptr)) {
         scan_seed(m, wv, 0, 1);  // the bound from the tile spheres (the slot's own bound is pulled in scan_tiles)
         scan_tiles<WITH_RAY>(m, sh.g, sh.w[wave], wv, -1, (int)blockIdx.y, (int)gridDim.y, wave, wave + 1);
         scan_finish(m, sh.g, sh.w[wave], wv);
@@ -1132,7 +1144,8 @@ extern "C" int pvamd_mesh_query(const pvamd_mesh_t* mesh, const float* points, c
         if (parts > most) parts = most;
     }
     if (ho.cap > 0 && groups <= ho.cap && parts >= kMinParts) {
-        hipLaunchKernelGGL(hand_over_all_kernel, dim3((unsigned)groups), dim3(64), 0, s, ho, (int)groups);
+        hipLaunchKernelGGL(hand_over_all_kernel, dim3((unsigned)groups), dim3(64), 0, s, m, order, P, jitter_seed, index_base, ho,
+                           (int)groups);
         hipLaunchKernelGGL(mesh_parts_all_kernel, dim3((unsigned)groups, (unsigned)parts), dim3(kTile), 0, s, m, order, points, P,
                            jitter_seed, index_base, ho);
         hipLaunchKernelGGL(mesh_query_finish_kernel, dim3((unsigned)groups), dim3(64), 0, s, m, order, points, P, ho, (int)groups, out);
