@@ -244,15 +244,19 @@ extern "C" int pvamd_debug_stats(unsigned long long* out, int reset) {
 // SLICES waves that all hold the same 64 points.  Wave w walks the tiles ti % SLICES == w on its own -- no barrier between
 // the one that publishes the rays and the one before the results are read; the waves only meet in the per-point result
 // slots (LDS atomics), from which each keeps pulling the others' finds, and every wave-uniform quantity sits in SGPRs.  (A
-// point group near the medial axis needs most of the mesh; spreading its tiles over the waves bounds that tail.)
+// point group near the medial axis needs most of the mesh; spreading its tiles over the waves bounds that tail, and the
+// worst of them are handed over to a launch of their own: "point groups that are handed over" below.)
 //   bound   the wave keeps a sphere (c, rho) around its live points and Q = max reach + rho.  Whatever a lane still
 //           needs lies within Q of c: |p - ctr| >= |c - ctr| - rho, and the distance to a rectangle is 1-Lipschitz in p.
 //           The same holds for the rays: all lanes shoot within `chord` of one direction, so a sphere missed by the
 //           axis ray through c by more than r + rho + 2 chord (|w| + rho) is missed by every lane's ray.
 //   tiles   lanes = TILES (64 tile spheres per pass): one evaluation of the sphere test at (c, Q) answers "does any
 //           lane need this tile" for 64 tiles at once; the nearest tile is visited first, which brings every reach
-//           down to about the true distance, then the flagged tiles in index order, re-flagged after every visit.
-//   records lanes = RECORDS (64 per pass, 4 passes per tile, skipped per pass through the 16 group spheres): sphere
+//           down to about the true distance, then the flagged tiles of each pass nearest-first, re-flagged after every
+//           visit and confirmed by one per-point look at the tile's sphere before the visit is paid for.
+//   groups  lanes = the tile's 16 GROUP spheres at (c, Q); the few that pass are tested per point (sphere of group b
+//           broadcast from lane b) -- what keeps the record passes to the groups some lane really needs.
+//   records lanes = RECORDS (64 per pass, 4 passes per tile, skipped per pass through the group mask): sphere
 //           test + rectangle test at (c, Q) + ray test about the axis, on coalesced 16-byte loads of the tile's planes.
 //           Only the survivors (typically a few per cent) are looked at per point: their filter data goes through a
 //           wave-private LDS slice and is read back wave-uniformly (LDS broadcast), one survivor at a time, for the
