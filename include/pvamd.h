@@ -215,8 +215,9 @@ int pvamd_composed_query_bucketed(const pvamd_grid_t* grids, int32_t S, const fl
                                   const float* sorted_points, const int32_t* inv, int64_t P, int64_t Pp,
                                   float* scratch, float* out_val, float* out_grad, int32_t flags, void* stream);
 
-/* The two halves of the above, for callers that move the packed records themselves (a query sharded over GPUs gathers
- * ONE buffer of records instead of val and grad, then unpacks straight into the final layout):
+/* The two halves of the above, for callers that move the packed records themselves: RobotSDF.__call__
+ * (model_to_sdf.py:117-125 -> sdf.py:392-433) sharded over GPUs runs on each rank's slice of the points, gathers ONE
+ * buffer of records instead of val and grad, then unpacks straight into the reference's (A, P) / (A, P, 3) layout:
  * pvamd_composed_query_packed: out_rec[a][k] = (val, gx, gy, gz) of configuration a at points[k].  points: device [Pp][3],
  *   Pp a multiple of 256, 16-byte aligned.  out_rec: device, A * Pp * 16 bytes, 16-byte aligned.  A <= 65535.
  * pvamd_unpack_records: out_val[a][j] / out_grad[a][j] = rec[a * stride + index[j]] for j < P (index[j] may point
