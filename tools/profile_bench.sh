@@ -2,10 +2,10 @@
 # The driver-shaped bench line + the rocprofv3 kernel trace of the SAME command + PMC traffic passes -> gpurun_out/$1/
 export TMPDIR=/tmp
 O=gpurun_out/$1; mkdir -p $O
-python bench.py --gpus 1 --steps 20 --warmup 5 > $O/bench_k20.json 2> $O/bench_k20.err
+[ -z "$ONLY_KT" ] && python bench.py --gpus 1 --steps 20 --warmup 5 > $O/bench_k20.json 2> $O/bench_k20.err
 rocprofv3 --kernel-trace --stats -d $O/kt -o bench --output-format csv -- python bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline > $O/kt.log 2>&1
-rocprofv3 --pmc FETCH_SIZE -d $O/fetch -o bench --output-format csv -- python bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline --no-large --no-legs > $O/fetch.log 2>&1
-rocprofv3 --pmc WRITE_SIZE -d $O/write -o bench --output-format csv -- python bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline --no-large --no-legs > $O/write.log 2>&1
+[ -z "$ONLY_KT" ] && rocprofv3 --pmc FETCH_SIZE -d $O/fetch -o bench --output-format csv -- python bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline --no-large --no-legs > $O/fetch.log 2>&1
+[ -z "$ONLY_KT" ] && rocprofv3 --pmc WRITE_SIZE -d $O/write -o bench --output-format csv -- python bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline --no-large --no-legs > $O/write.log 2>&1
 python - <<PY > $O/kernel_stats.md
 # per (kernel, launch geometry): the same template instantiation serves the 1M-point steps and the 8M / 64M-point legs
 import csv, glob, collections
@@ -14,7 +14,11 @@ for f in glob.glob("$O/kt/**/*kernel_trace.csv", recursive=True):
     for r in csv.DictReader(open(f)):
         grid = r.get("Grid_Size_X") or r.get("Grid_Size") or "?"
         wg = r.get("Workgroup_Size_X") or r.get("Workgroup_Size") or "?"
-        rows[(r["Kernel_Name"][:96], grid, wg)].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
+        d = (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3
+        name = r["Kernel_Name"][:96]
+        if "cached_query_wave<true, false, false, true>" in name:  # same capped grid for every size: split by duration
+            name += " [1,048,576-point launches]" if d < 20 else " [8M-point launches of the mid_batch leg]"
+        rows[(name, grid, wg)].append(d)
 total = sum(sum(v) for v in rows.values())
 print("| kernel | grid (threads) x workgroup | calls | total us | avg us | min us | max us | % |")
 print("|---|---|---|---|---|---|---|---|")
@@ -22,7 +26,7 @@ for (name, grid, wg), v in sorted(rows.items(), key=lambda kv: -sum(kv[1]))[:32]
     print("| \`%s\` | %s x %s | %d | %.1f | %.2f | %.2f | %.2f | %.2f |" % (name, grid, wg, len(v), sum(v), sum(v) / len(v), min(v), max(v), 100 * sum(v) / total))
 PY
 F=$(find $O/fetch -name "*counter_collection.csv" | head -1); W=$(find $O/write -name "*counter_collection.csv" | head -1)
-python tools/pmc_summary.py $F $W cached_query_wave 1048576 > $O/traffic.json
+[ -z "$ONLY_KT" ] && python tools/pmc_summary.py $F $W cached_query_wave 1048576 > $O/traffic.json
 find $O -name "*.csv" -size +1M -delete
 tail -c 2500 $O/bench_k20.json | head -c 100 > /dev/null
 head -12 $O/kernel_stats.md; cat $O/traffic.json
