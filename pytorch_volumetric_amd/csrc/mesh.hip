@@ -670,14 +670,15 @@ static __host__ __device__ inline HandOver hand_over(void* scratch, int cap) {
     return h;
 }
 #ifndef PVAMD_MESH_HEAVY_EIGHTHS
-#define PVAMD_MESH_HEAVY_EIGHTHS 5
+#define PVAMD_MESH_HEAVY_EIGHTHS 3
 #endif
 #ifndef PVAMD_MESH_HEAVY_PARTS
 #define PVAMD_MESH_HEAVY_PARTS 32
 #endif
 // heavy = still flags this many eighths of the tiles (of at least kHeavyMinTiles) once its reaches are about final.  C5
-// (389 tiles, 32,768 groups), groups listed / ms: 96 tiles 1739 / 5.54, 192: 394 / 5.41, 256: 201 / 5.20, 300: 103 / 5.17
-// (16 -> 32 parts: -0.2 ms; 64: -0.05 more); nothing handed over: 5.9
+// (389 tiles, 32,768 groups), groups listed / ms with 4 waves per group in the main launch: 2/8 1671 / 3.91, 3/8 703 / 3.71,
+// 4/8 384 / 3.80, 5/8 238 / 3.99 (64 instead of 32 parts: +0.04); with 8 waves per group 5.2-5.5 whatever the threshold;
+// nothing handed over: 5.9 (8 waves)
 constexpr int kHeavyEighths = PVAMD_MESH_HEAVY_EIGHTHS;
 #ifndef PVAMD_MESH_HEAVY_MIN_TILES
 #define PVAMD_MESH_HEAVY_MIN_TILES 128
@@ -1061,13 +1062,14 @@ constexpr int kMinParts = PVAMD_MESH_MIN_PARTS;     // below this the single lau
 //                            with 4, 2.4 with 1, 3.1 with 8);
 //   fewer groups          -> 4, 8, so that the 1024 SIMDs still fill (100k points on the drill: 0.40 ms with 8, 0.47 with
 //                            4, 0.79 with 2);
-//   many tiles            -> 8: the work per group is heavy-tailed (a point near the medial axis is equidistant to much of
-//                            the surface and needs most tiles), and on a mesh of hundreds of tiles the slowest groups
-//                            set the kernel time (C5, 389 tiles: 5.9 ms with 8, 7.7 with 4).
-static int pick_slices(int64_t groups, int mesh_tiles) {
+//   many tiles            -> the work per group is heavy-tailed (a point near the medial axis is equidistant to much of
+//                            the surface and needs most tiles) and the slowest groups set the kernel time: 8 when nothing
+//                            can be handed over (C5, 389 tiles: 5.9 ms with 8, 7.5 with 4, 11 with 2), 4 when the heavy
+//                            groups go to a launch of their own (5.2 ms with 8, 4.0 with 4, 4.7 with 2).
+static int pick_slices(int64_t groups, int mesh_tiles, bool hand_over) {
     int s = 2;
     while (s < 8 && (int64_t)s * groups < 16384) s <<= 1;
-    if (mesh_tiles > 128) s = 8;
+    if (mesh_tiles > 128) s = hand_over ? 4 : 8;
     if (s > PVAMD_MESH_MAX_SLICES) s = PVAMD_MESH_MAX_SLICES;
     while (s > 1 && s > mesh_tiles) s >>= 1;
     return s;
@@ -1135,9 +1137,10 @@ extern "C" int pvamd_mesh_query(const pvamd_mesh_t* mesh, const float* points, c
     hipStream_t s = (hipStream_t)stream;
     const QueryOut out{out_closest, out_dist, out_grad, out_face, out_normal};
     const int ntiles = (mesh->F + kTile - 1) / kTile;
-    const int slices = pick_slices(groups, ntiles);
+    
     const int cap = (int)(groups < kHandOverCap ? groups : kHandOverCap);  // what PVAMD_MESH_SCRATCH_BYTES(P) holds
     const HandOver ho = hand_over(scratch, cap);
+    const int slices = pick_slices(groups, ntiles, ho.cap > 0 && ntiles >= kHeavyMinTiles);
     // few point groups, many tiles: spread each group's tiles over `parts` blocks of four waves, one per 64-record pass
     // (see mesh_parts_kernel)
     int parts = (int)((int64_t)kFillWaves / (groups * (kTile / 64)));
@@ -1188,9 +1191,9 @@ extern "C" int pvamd_chamfer_mesh(const pvamd_mesh_t* mesh, const float* W, int3
     const int64_t groups = (N + 63) / 64;
     if (groups > 0x7fffffff) return PVAMD_E_SHAPE;
     const int ntiles = (mesh->F + kTile - 1) / kTile;
-    const int slices = pick_slices(groups * (int64_t)B, ntiles);
     const int cap = (int)(groups < kHandOverCap ? groups : kHandOverCap);
     const HandOver ho = hand_over(ntiles >= kHeavyMinTiles ? scratch : nullptr, cap);
+    const int slices = pick_slices(groups * (int64_t)B, ntiles, ho.cap > 0);
     if (ho.cap > 0) hipLaunchKernelGGL(hand_over_none_kernel, dim3(1), dim3(1), 0, s, ho);
     // y-dimension of a HIP grid is limited to 65535: walk B in slabs
     for (int32_t b0 = 0; b0 < B; b0 += 65535) {
