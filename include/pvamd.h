@@ -273,7 +273,7 @@ int pvamd_morton_order(const float* points, int64_t P, int32_t* order_out, int32
  * points, and the heavy groups of a large one (points about equidistant to much of a mesh of >= 128 tiles) -- in three
  * launches that meet in scratch; results are the same bits either way.  Contents on return are unspecified.      */
 #define PVAMD_MESH_SCRATCH_GROUPS 2048  /* point groups (of 64) a scratch buffer has slots for, at most */
-#define PVAMD_MESH_SCRATCH_BYTES(P) (64 + ((((P) + 63) / 64) < PVAMD_MESH_SCRATCH_GROUPS ? (((P) + 63) / 64) : PVAMD_MESH_SCRATCH_GROUPS) * (int64_t)(64 * 24 + 8))
+#define PVAMD_MESH_SCRATCH_BYTES(P) (64 + ((((P) + 63) / 64) < PVAMD_MESH_SCRATCH_GROUPS ? (((P) + 63) / 64) : PVAMD_MESH_SCRATCH_GROUPS) * (int64_t)(64 * 28 + 8))
 int pvamd_mesh_query(const pvamd_mesh_t* mesh, const float* points, const int32_t* order, int64_t P,
                      uint64_t jitter_seed, int64_t index_base, float* out_closest, float* out_dist, float* out_grad, int32_t* out_face,
                      float* out_normal, void* scratch, void* stream);

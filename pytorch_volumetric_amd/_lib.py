@@ -35,7 +35,7 @@ MESH_SCRATCH_GROUPS = 2048
 
 def mesh_scratch_bytes(P):
     """PVAMD_MESH_SCRATCH_BYTES(P)"""
-    return 64 + min((P + 63) // 64, MESH_SCRATCH_GROUPS) * (64 * 24 + 8)
+    return 64 + min((P + 63) // 64, MESH_SCRATCH_GROUPS) * (64 * 28 + 8)
 
 
 _c_float_p = ctypes.POINTER(ctypes.c_float)

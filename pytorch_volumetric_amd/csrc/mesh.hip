@@ -648,13 +648,15 @@ PVAMD_DEV bool scan_begin(const MeshArgs& m, GroupShared<WITH_RAY>& g, Wave<WITH
 // folding into the group's scratch slots with global atomicMin / atomicAdd, and a third writes the listed groups'
 // outputs.  The few-points path (below) is the same three launches with EVERY group listed up front.
 // scratch: int count | int entries[cap][2] (point group, transform) | u64 best[cap][64] | int hits[cap][64] |
-//          float dir[cap][64][3] (the jittered ray of each point, drawn once)
+//          float dir[cap][64][3] (the jittered ray of each point, drawn once) | float reach[cap][64] (an upper bound
+//          of each point's distance to the mesh to start from, +inf when none was worked out)
 struct HandOver {
     int* count;
     int* entries;
     unsigned long long* best;
     int* hits;
     float* dir;
+    float* reach;
     int cap;  // 0: nothing is handed over
 };
 constexpr int kHandOverHeader = 64;  // bytes
@@ -666,6 +668,7 @@ static __host__ __device__ inline HandOver hand_over(void* scratch, int cap) {
     h.best = reinterpret_cast<unsigned long long*>(base + kHandOverHeader + (size_t)cap * 8);
     h.hits = reinterpret_cast<int*>(base + kHandOverHeader + (size_t)cap * 8 + (size_t)cap * 64 * 8);
     h.dir = reinterpret_cast<float*>(base + kHandOverHeader + (size_t)cap * 8 + (size_t)cap * 64 * 12);
+    h.reach = reinterpret_cast<float*>(base + kHandOverHeader + (size_t)cap * 8 + (size_t)cap * 64 * 24);
     h.cap = scratch ? cap : 0;
     return h;
 }
@@ -735,6 +738,7 @@ PVAMD_DEV bool scan_mesh(const MeshArgs& m, MeshShared<SLICES, WITH_RAY>& sh, Wa
                         ho.entries[2 * slot + 1] = transform;
                     }
                     ho.best[(int64_t)slot * 64 + lane] = sh.g.best[lane];  // a bound to start from; the hits are counted afresh
+                    ho.reach[(int64_t)slot * 64 + lane] = INFINITY;
                     if (WITH_RAY) {
                         ho.hits[(int64_t)slot * 64 + lane] = 0;
                         for (int d = 0; d < 3; ++d) ho.dir[((int64_t)slot * 64 + lane) * 3 + d] = sh.g.dir[3 * lane + d];
@@ -871,14 +875,46 @@ __global__ __launch_bounds__(64 * SLICES) void chamfer_mesh_kernel(MeshArgs m, c
 //   finish  (one wave per listed group)  outputs from the slots
 // (A `first` launch that visited the nearest tile and handed its bound on cost what it saved in the few-points path: C1
 // 0.159 vs 0.158 ms, 1000 points 0.089 vs 0.063 ms without it.)
-__global__ __launch_bounds__(64) void hand_over_all_kernel(MeshArgs m, const int* __restrict__ order, int64_t P, uint64_t seed,
-                                                           int64_t index_base, HandOver ho, int groups) {
+__global__ __launch_bounds__(64) void hand_over_all_kernel(MeshArgs m, const int* __restrict__ order, const float* __restrict__ pts,
+                                                           int64_t P, uint64_t seed, int64_t index_base, HandOver ho, int groups) {
     const int g = blockIdx.x;
     ho.best[(int64_t)g * 64 + threadIdx.x] = kBestInit;
     ho.hits[(int64_t)g * 64 + threadIdx.x] = 0;
-    const V3 dir = jitter_dir(m.ray_dir, seed, index_base + point_index(order, (int64_t)g * 64 + threadIdx.x, P));
+    const int64_t i = point_index(order, (int64_t)g * 64 + threadIdx.x, P);
+    const V3 dir = jitter_dir(m.ray_dir, seed, index_base + i);
     float* o = ho.dir + ((int64_t)g * 64 + threadIdx.x) * 3;
     o[0] = dir.x; o[1] = dir.y; o[2] = dir.z;
+    // An upper bound of the point's distance to the mesh, by a greedy descent tile -> group -> record along the smallest
+    // |p - ctr| + r (every sphere contains whole triangles).  The blocks of the parts launch cannot hand each other their
+    // finds, so each would otherwise start from the tile-sphere bound (a tile radius too wide) and queue 3x the pairs.
+    float bound = INFINITY;
+    if (m.F > 0) {
+        const V3 p = v3(pts[3 * i], pts[3 * i + 1], pts[3 * i + 2]);
+        const int ntiles = (m.F + kTile - 1) / kTile;
+        const f32x4* spheres = reinterpret_cast<const f32x4*>(m.tiles);
+        auto reach_of = [&](f32x4 sp) {
+            const V3 w = v3(sp.x - p.x, sp.y - p.y, sp.z - p.z);
+            return fast_sqrt(dot(w, w)) * 1.00001f + (sp.w + 1.1e-19f);  // slack: 1 ulp + the flushed denormals
+        };
+        int ti = 0;
+        for (int t = 0; t < ntiles; ++t) {  // wave-uniform t: scalar loads
+            const float b = reach_of(spheres[t]);
+            if (b < bound) { bound = b; ti = t; }
+        }
+        int gi = 0;
+        const int ngroups = (min(kTile, m.F - ti * kTile) + kGroup - 1) / kGroup;
+        for (int k = 0; k < kGroupsPerTile; ++k) {
+            if (k >= ngroups) break;
+            const float b = reach_of(spheres[ntiles + ti * kGroupsPerTile + k]);
+            if (b < bound) { bound = b; gi = k; }
+        }
+        const int j0 = ti * kTile + gi * kGroup;
+        for (int k = 0; k < kGroup; ++k) {
+            if (j0 + k >= m.F) break;
+            bound = fminf(bound, reach_of(record_plane(m.rec, j0 + k, kPlaneSphere)));
+        }
+    }
+    ho.reach[(int64_t)g * 64 + threadIdx.x] = bound * 1.00001f;  // a NaN / inf point: never a finite bound
     if (threadIdx.x == 0) {
         ho.entries[2 * g] = g;
         ho.entries[2 * g + 1] = 0;
@@ -902,7 +938,10 @@ PVAMD_DEV void parts_of_group(const MeshArgs& m, MeshShared<kTile / 64, WITH_RAY
     wv.s.p = M ? chamfer_point(M, pts, i) : v3(pts[3 * i], pts[3 * i + 1], pts[3 * i + 2]);
     const unsigned long long start = ho.best[(int64_t)slot * 64 + lane];
     if (scan_begin(m, sh.g, wv, wave, seed, index_base + i, &start, WITH_RAY ? ho.dir + (int64_t)slot * 192 : nullptr)) {
-        scan_seed(m, wv, 0, 1);  // the bound from the tile spheres (the slot's own bound is pulled in scan_tiles)
+        scan_seed(m, wv, 0, 1);  // the bound from the tile spheres (the slot's own finds are pulled in scan_tiles) ...
+        const float known = ho.reach[(int64_t)slot * 64 + lane];  // ... and the one worked out when the group was listed
+        if (known < wv.s.reach) set_reach(wv.s, known);
+        refresh_bound(wv);
         scan_tiles<WITH_RAY>(m, sh.g, sh.w[wave], wv, -1, (int)blockIdx.y, (int)gridDim.y, wave, wave + 1);
         scan_finish(m, sh.g, sh.w[wave], wv);
     }
@@ -1151,8 +1190,8 @@ extern "C" int pvamd_mesh_query(const pvamd_mesh_t* mesh, const float* points, c
         if (parts > most) parts = most;
     }
     if (ho.cap > 0 && groups <= ho.cap && parts >= kMinParts) {
-        hipLaunchKernelGGL(hand_over_all_kernel, dim3((unsigned)groups), dim3(64), 0, s, m, order, P, jitter_seed, index_base, ho,
-                           (int)groups);
+        hipLaunchKernelGGL(hand_over_all_kernel, dim3((unsigned)groups), dim3(64), 0, s, m, order, points, P, jitter_seed, index_base,
+                           ho, (int)groups);
         hipLaunchKernelGGL(mesh_parts_all_kernel, dim3((unsigned)groups, (unsigned)parts), dim3(kTile), 0, s, m, order, points, P,
                            jitter_seed, index_base, ho);
         hipLaunchKernelGGL(mesh_query_finish_kernel, dim3((unsigned)groups), dim3(64), 0, s, m, order, points, P, ho, (int)groups, out);
