@@ -875,15 +875,26 @@ __global__ __launch_bounds__(64 * SLICES) void chamfer_mesh_kernel(MeshArgs m, c
 //   finish  (one wave per listed group)  outputs from the slots
 // (A `first` launch that visited the nearest tile and handed its bound on cost what it saved in the few-points path: C1
 // 0.159 vs 0.158 ms, 1000 points 0.089 vs 0.063 ms without it.)
-__global__ __launch_bounds__(64) void hand_over_all_kernel(MeshArgs m, const int* __restrict__ order, const float* __restrict__ pts,
-                                                           int64_t P, uint64_t seed, int64_t index_base, HandOver ho, int groups) {
-    const int g = blockIdx.x;
-    ho.best[(int64_t)g * 64 + threadIdx.x] = kBestInit;
-    ho.hits[(int64_t)g * 64 + threadIdx.x] = 0;
-    const int64_t i = point_index(order, (int64_t)g * 64 + threadIdx.x, P);
-    const V3 dir = jitter_dir(m.ray_dir, seed, index_base + i);
-    float* o = ho.dir + ((int64_t)g * 64 + threadIdx.x) * 3;
-    o[0] = dir.x; o[1] = dir.y; o[2] = dir.z;
+// block = one point group, two waves: wave 0 draws the rays and clears the slots, wave 1 works out the bound (two
+// independent serial chains: 5 + 8 us one after the other, 8 side by side)
+__global__ __launch_bounds__(128) void hand_over_all_kernel(MeshArgs m, const int* __restrict__ order, const float* __restrict__ pts,
+                                                            int64_t P, uint64_t seed, int64_t index_base, HandOver ho, int groups) {
+    const int g = blockIdx.x, lane = threadIdx.x & 63;
+    const int64_t slot = (int64_t)g * 64 + lane;
+    const int64_t i = point_index(order, slot, P);
+    if (threadIdx.x < 64) {
+        ho.best[slot] = kBestInit;
+        ho.hits[slot] = 0;
+        const V3 dir = jitter_dir(m.ray_dir, seed, index_base + i);
+        float* o = ho.dir + slot * 3;
+        o[0] = dir.x; o[1] = dir.y; o[2] = dir.z;
+        if (lane == 0) {
+            ho.entries[2 * g] = g;
+            ho.entries[2 * g + 1] = 0;
+            if (g == 0) *ho.count = groups;
+        }
+        return;
+    }
     // An upper bound of the point's distance to the mesh, by a greedy descent tile -> group -> record along the smallest
     // |p - ctr| + r (every sphere contains whole triangles).  The blocks of the parts launch cannot hand each other their
     // finds, so each would otherwise start from the tile-sphere bound (a tile radius too wide) and queue 3x the pairs.
@@ -914,12 +925,7 @@ __global__ __launch_bounds__(64) void hand_over_all_kernel(MeshArgs m, const int
             bound = fminf(bound, reach_of(record_plane(m.rec, j0 + k, kPlaneSphere)));
         }
     }
-    ho.reach[(int64_t)g * 64 + threadIdx.x] = bound * 1.00001f;  // a NaN / inf point: never a finite bound
-    if (threadIdx.x == 0) {
-        ho.entries[2 * g] = g;
-        ho.entries[2 * g + 1] = 0;
-        if (g == 0) *ho.count = groups;
-    }
+    ho.reach[slot] = bound * 1.00001f;  // a NaN / inf point: never a finite bound
 }
 __global__ void hand_over_none_kernel(HandOver ho) { *ho.count = 0; }
 
@@ -1190,7 +1196,7 @@ extern "C" int pvamd_mesh_query(const pvamd_mesh_t* mesh, const float* points, c
         if (parts > most) parts = most;
     }
     if (ho.cap > 0 && groups <= ho.cap && parts >= kMinParts) {
-        hipLaunchKernelGGL(hand_over_all_kernel, dim3((unsigned)groups), dim3(64), 0, s, m, order, points, P, jitter_seed, index_base,
+        hipLaunchKernelGGL(hand_over_all_kernel, dim3((unsigned)groups), dim3(128), 0, s, m, order, points, P, jitter_seed, index_base,
                            ho, (int)groups);
         hipLaunchKernelGGL(mesh_parts_all_kernel, dim3((unsigned)groups, (unsigned)parts), dim3(kTile), 0, s, m, order, points, P,
                            jitter_seed, index_base, ho);
