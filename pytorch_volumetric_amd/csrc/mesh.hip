@@ -564,6 +564,34 @@ PVAMD_DEV int scan_seed(const MeshArgs& m, Wave<WITH_RAY>& wv, int part, int npa
     return at ? __builtin_amdgcn_readlane(nearest, __builtin_ctzll(at)) : -1;
 }
 
+// Before the first visit: tighten every lane's reach by a greedy descent through tile `ti` -- the group, then the record,
+// with the smallest |p - ctr| + r (each sphere contains whole triangles, so each is an upper bound of the lane's distance
+// to the mesh).  The first visit then queues pairs against a bound a few millimetres wide instead of a tile radius.
+template <bool WITH_RAY>
+PVAMD_DEV void greedy_reach(const MeshArgs& m, Wave<WITH_RAY>& wv, int ti) {
+    const int ntiles = (m.F + kTile - 1) / kTile;
+    const f32x4* spheres = reinterpret_cast<const f32x4*>(m.tiles);
+    const V3 p = wv.s.p;
+    auto reach_of = [&](f32x4 sp) {
+        const V3 w = v3(sp.x - p.x, sp.y - p.y, sp.z - p.z);
+        return fast_sqrt(dot(w, w)) * 1.00001f + (sp.w + 1.1e-19f);
+    };
+    float bound = INFINITY;
+    int gi = 0;
+    const int ngroups = (min(kTile, m.F - ti * kTile) + kGroup - 1) / kGroup;
+    for (int k = 0; k < ngroups; ++k) {  // wave-uniform: scalar loads
+        const float b = reach_of(spheres[ntiles + ti * kGroupsPerTile + k]);
+        if (b < bound) { bound = b; gi = k; }
+    }
+    const int j0 = ti * kTile + gi * kGroup;  // per lane
+    for (int k = 0; k < kGroup; ++k) {
+        if (j0 + k < m.F) bound = fminf(bound, reach_of(record_plane(m.rec, j0 + k, kPlaneSphere)));
+    }
+    bound *= 1.00001f;
+    if (bound < wv.s.reach) set_reach(wv.s, bound);  // a NaN point: never
+    refresh_bound(wv);
+}
+
 // the tiles ti with ti % nparts == part, `skip` excepted (it was visited before), flagged 64 at a time
 template <bool WITH_RAY>
 PVAMD_DEV void scan_tiles(const MeshArgs& m, GroupShared<WITH_RAY>& g, WaveLocal<WITH_RAY>& wl, Wave<WITH_RAY>& wv, int skip,
@@ -719,6 +747,9 @@ PVAMD_DEV bool scan_mesh(const MeshArgs& m, MeshShared<SLICES, WITH_RAY>& sh, Wa
     if (scan_begin(m, sh.g, wv, wave, seed, jitter_index, nullptr) && m.F > 0) {
         const int first = scan_seed(m, wv, wave, SLICES);
         if (first >= 0) {
+#ifndef PVAMD_MESH_NO_GREEDY
+            greedy_reach(m, wv, first);
+#endif
             visit_tile<WITH_RAY>(m, sh.g, sh.w[wave], wv, first);
             drain_closest(m, sh.g, sh.w[wave], wv, true);  // publish what the nearest tile gave before looking further
         }
