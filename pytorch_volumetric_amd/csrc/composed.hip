@@ -149,6 +149,10 @@ PVAMD_DEV void rotate_back(const float* __restrict__ M, const Best& b, float& ox
 // AND its lower bound exceeds the upper bound some other out-of-range leaf guarantees for every point (strictly, with
 // margin -- first-minimum ties cannot be affected).
 constexpr int kMaxCullLeaves = 64;
+#ifndef PVAMD_COMPOSED_MASK_SPAN
+#define PVAMD_COMPOSED_MASK_SPAN 0.5f
+#endif
+constexpr float kMaskSpan = PVAMD_COMPOSED_MASK_SPAN;
 
 PVAMD_DEV void build_cull_spheres(const pvamd_grid_t* __restrict__ grids, int S, const float* __restrict__ tf, int A,
                                   int a, float (*cull)[8]) {
@@ -246,6 +250,93 @@ constexpr int kTilePoints = 256;
 #define PVAMD_COMPOSED_MINWAVES 8
 #endif
 
+// The leaf loop of one tile: PPP points per lane at a time, results into the wave's LDS slice (or packed, to memory).
+// MASKED = false: the tile was not worth a leaf mask (every leaf is visited; no bit tests, no refinement).
+template <int PPP, int MODE, bool PACKED, bool MASKED>
+PVAMD_DEV void tile_passes(const pvamd_grid_t* __restrict__ grids, int S, const float* __restrict__ tf, int A, int a,
+                           int64_t tile, int64_t P, float* __restrict__ val, int* __restrict__ leaf, float* spf, int lane,
+                           uint64_t todo, float lower) {
+    float* svf = spf + 768;
+    const int first_leaf = todo ? __builtin_ctzll(todo) : 0;
+    // A tile compact enough for the static test to drop a leaf is worth re-testing as the minimum tightens: after
+    // every visited leaf the wave's largest running minimum is an upper bound of every point's final value, and the
+    // leaves whose lower bound exceeds it are dropped (strictly greater, so ties cannot be affected).  Scattered
+    // tiles (nothing dropped statically) skip the ~10 instructions per visited leaf.
+    const bool refine = MASKED && S <= 64 && todo != (S >= 64 ? ~0ull : ((1ull << S) - 1ull));
+    // PPP points per lane go through the leaf loop together (fewer live registers -> more waves per SIMD; the
+    // leaf constants are scalar loads, so re-walking the leaves per pass costs SALU/SMEM, not VALU)
+#pragma unroll
+    for (int h = 0; h < 4; h += PPP) {
+        float px[PPP], py[PPP], pz[PPP];
+        Best best[PPP];
+#pragma unroll
+        for (int k = 0; k < PPP; ++k) {
+            const int p = lane + 64 * (h + k);
+            px[k] = spf[3 * p];
+            py[k] = spf[3 * p + 1];
+            pz[k] = spf[3 * p + 2];
+            best[k] = best_init(first_leaf);
+        }
+        bool unsure[PPP];
+#pragma unroll
+        for (int k = 0; k < PPP; ++k) unsure[k] = false;
+        uint64_t rem = todo;
+        for (int s = 0; s < S; ++s) {
+            if (MASKED && s < 64 && !((rem >> s) & 1ull)) continue;  // wave-uniform
+            const float* M = tf + 16 * ((int64_t)s * A + a);  // wave-uniform: scalar loads
+            const pvamd_grid_t& g = grids[s];
+            // all PPP candidates first, their comparisons after: the gathers of the PPP points are in flight together
+            float v[PPP], ga[PPP], gb[PPP], gc[PPP];
+            bool valid[PPP];
+#pragma unroll
+            for (int k = 0; k < PPP; ++k)
+                leaf_candidate<MODE>(g, M, px[k], py[k], pz[k], v[k], ga[k], gb[k], gc[k], valid[k], unsure[k]);
+#pragma unroll
+            for (int k = 0; k < PPP; ++k) keep_first_minimum(best[k], s, v[k], ga[k], gb[k], gc[k], valid[k]);
+            if (refine) {
+                float m = best[0].v;
+#pragma unroll
+                for (int k = 1; k < PPP; ++k) m = __builtin_fmaxf(m, best[k].v);
+                const float ub = wave_max(m);  // NaN minima are ignored: nothing replaces them anyway
+                rem &= ~__builtin_amdgcn_ballot_w64(lower > ub + 1e-6f * fabsf(ub));
+            }
+        }
+        if constexpr (MODE == kEstimate) {
+            // the few points whose index estimate could not be trusted for some leaf: all over again, exactly
+#pragma unroll
+            for (int k = 0; k < PPP; ++k) {
+                if (__builtin_expect(wave_any(unsure[k]), 0)) {
+                    Best redo = best_init(first_leaf);
+                    bool dummy = false;
+                    walk_leaves<kExact>(grids, S, tf, A, a, todo, px[k], py[k], pz[k], redo, dummy);
+                    if (unsure[k]) best[k] = redo;
+                }
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < PPP; ++k) {
+            const int p = lane + 64 * (h + k);
+            const int s_win = best[k].tag & (kUnnormalised - 1);
+            // per-lane winner: these matrix reads are vector loads, but the S*A stack is tiny and cache-resident
+            const float* M = tf + 16 * ((int64_t)s_win * A + a);
+            float gx, gy, gz;
+            rotate_back(M, best[k], gx, gy, gz);
+            if constexpr (PACKED) {
+                // one (val, gx, gy, gz) record per point, in processing order: lanes hold consecutive points, so the
+                // wave's store is a contiguous 1 KB as it is; plain stores -- the un-permute pass reads them back
+                // from L2 / Infinity Cache right away
+                reinterpret_cast<f32x4*>(val)[(int64_t)a * P + tile * kTilePoints + p] = f32x4{best[k].v, gx, gy, gz};
+            } else {
+                svf[p] = best[k].v;  // a lane overwrites only the LDS slots of the points it owns
+                spf[3 * p] = gx;
+                spf[3 * p + 1] = gy;
+                spf[3 * p + 2] = gz;
+            }
+            if (leaf) leaf[(int64_t)a * P + tile * kTilePoints + p] = s_win;
+        }
+    }
+}
+
 template <int PPP, int MODE, bool PACKED>
 __global__ __launch_bounds__(kWavesPerBlock * 64, MODE == kEstimate ? PVAMD_COMPOSED_MINWAVES : 1) void composed_query_wave(const pvamd_grid_t* __restrict__ grids, int S,
                                                                            const float* __restrict__ tf, int A,
@@ -259,13 +350,26 @@ __global__ __launch_bounds__(kWavesPerBlock * 64, MODE == kEstimate ? PVAMD_COMP
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     float* spf = lds[wave];
     f32x4_alias* sp = reinterpret_cast<f32x4_alias*>(spf);
-    float* svf = spf + 768;
     // blockIdx.x = configuration (fastest), blockIdx.y = tile block: the A configurations of one group of tiles run
     // back to back, so the leaf-grid region that tile touches (it moves little between configurations) and the tile's
     // points stay in L2 -- what matters once the grids are far larger than L2 (README-size link grids)
     const int a = a0 + blockIdx.x;
     build_cull_spheres(grids, S, tf, A, a, cull);
     __syncthreads();
+    // The mask drops leaves only for tiles that are small against the scene, and costs ~150 instructions a tile (6 % of
+    // C4 on random points, where it drops nothing: 0.834 -> 0.792 ms without it).  `scene` = radius about leaf 0's centre
+    // that holds every leaf's range; a tile whose first and last point are further apart than kMaskSpan of it is not
+    // worth a mask (always safe: no mask = every leaf).
+    float scene = __builtin_inff();
+    if (S <= kMaxCullLeaves) {
+        float reach = -__builtin_inff();
+        if (lane < S) {
+            const float dx = cull[lane][0] - cull[0][0], dy = cull[lane][1] - cull[0][1], dz = cull[lane][2] - cull[0][2];
+            reach = fast_sqrt(dx * dx + dy * dy + dz * dz) + cull[lane][3];
+        }
+        scene = wave_max(reach);
+    }
+    const float span2 = (kMaskSpan * scene) * (kMaskSpan * scene);
     const int64_t wstride = (int64_t)gridDim.y * kWavesPerBlock;
     for (int64_t tile = (int64_t)blockIdx.y * kWavesPerBlock + wave; tile < ntiles; tile += wstride) {
         const f32x4* src = pts4 + tile * 192;  // re-read for every configuration: L2-resident
@@ -277,87 +381,26 @@ __global__ __launch_bounds__(kWavesPerBlock * 64, MODE == kEstimate ? PVAMD_COMP
 #ifdef PVAMD_NO_TILE_MASK
         lower = -__builtin_inff();
         const uint64_t todo = S >= 64 ? ~0ull : ((1ull << S) - 1ull);
+        const bool masked = false;
 #else
-        const uint64_t todo = tile_leaf_mask(cull, S, lane, spf, lower);
-#endif
-        const int first_leaf = todo ? __builtin_ctzll(todo) : 0;
-        // A tile compact enough for the static test to drop a leaf is worth re-testing as the minimum tightens: after
-        // every visited leaf the wave's largest running minimum is an upper bound of every point's final value, and the
-        // leaves whose lower bound exceeds it are dropped (strictly greater, so ties cannot be affected).  Scattered
-        // tiles (nothing dropped statically) skip the ~10 instructions per visited leaf.
-        const bool refine = S <= 64 && todo != (S >= 64 ? ~0ull : ((1ull << S) - 1ull));
-        // PPP points per lane go through the leaf loop together (fewer live registers -> more waves per SIMD; the
-        // leaf constants are scalar loads, so re-walking the leaves per pass costs SALU/SMEM, not VALU)
-#pragma unroll
-        for (int h = 0; h < 4; h += PPP) {
-            float px[PPP], py[PPP], pz[PPP];
-            Best best[PPP];
-#pragma unroll
-            for (int k = 0; k < PPP; ++k) {
-                const int p = lane + 64 * (h + k);
-                px[k] = spf[3 * p];
-                py[k] = spf[3 * p + 1];
-                pz[k] = spf[3 * p + 2];
-                best[k] = best_init(first_leaf);
-            }
-            bool unsure[PPP];
-#pragma unroll
-            for (int k = 0; k < PPP; ++k) unsure[k] = false;
-            uint64_t rem = todo;
-            for (int s = 0; s < S; ++s) {
-                if (s < 64 && !((rem >> s) & 1ull)) continue;  // wave-uniform
-                const float* M = tf + 16 * ((int64_t)s * A + a);  // wave-uniform: scalar loads
-                const pvamd_grid_t& g = grids[s];
-                // all PPP candidates first, their comparisons after: the gathers of the PPP points are in flight together
-                float v[PPP], ga[PPP], gb[PPP], gc[PPP];
-                bool valid[PPP];
-#pragma unroll
-                for (int k = 0; k < PPP; ++k)
-                    leaf_candidate<MODE>(g, M, px[k], py[k], pz[k], v[k], ga[k], gb[k], gc[k], valid[k], unsure[k]);
-#pragma unroll
-                for (int k = 0; k < PPP; ++k) keep_first_minimum(best[k], s, v[k], ga[k], gb[k], gc[k], valid[k]);
-                if (refine) {
-                    float m = best[0].v;
-#pragma unroll
-                    for (int k = 1; k < PPP; ++k) m = __builtin_fmaxf(m, best[k].v);
-                    const float ub = wave_max(m);  // NaN minima are ignored: nothing replaces them anyway
-                    rem &= ~__builtin_amdgcn_ballot_w64(lower > ub + 1e-6f * fabsf(ub));
-                }
-            }
-            if constexpr (MODE == kEstimate) {
-                // the few points whose index estimate could not be trusted for some leaf: all over again, exactly
-#pragma unroll
-                for (int k = 0; k < PPP; ++k) {
-                    if (__builtin_expect(wave_any(unsure[k]), 0)) {
-                        Best redo = best_init(first_leaf);
-                        bool dummy = false;
-                        walk_leaves<kExact>(grids, S, tf, A, a, todo, px[k], py[k], pz[k], redo, dummy);
-                        if (unsure[k]) best[k] = redo;
-                    }
-                }
-            }
-#pragma unroll
-            for (int k = 0; k < PPP; ++k) {
-                const int p = lane + 64 * (h + k);
-                const int s_win = best[k].tag & (kUnnormalised - 1);
-                // per-lane winner: these matrix reads are vector loads, but the S*A stack is tiny and cache-resident
-                const float* M = tf + 16 * ((int64_t)s_win * A + a);
-                float gx, gy, gz;
-                rotate_back(M, best[k], gx, gy, gz);
-                if constexpr (PACKED) {
-                    // one (val, gx, gy, gz) record per point, in processing order: lanes hold consecutive points, so the
-                    // wave's store is a contiguous 1 KB as it is; plain stores -- the un-permute pass reads them back
-                    // from L2 / Infinity Cache right away
-                    reinterpret_cast<f32x4*>(val)[(int64_t)a * P + tile * kTilePoints + p] = f32x4{best[k].v, gx, gy, gz};
-                } else {
-                    svf[p] = best[k].v;  // a lane overwrites only the LDS slots of the points it owns
-                    spf[3 * p] = gx;
-                    spf[3 * p + 1] = gy;
-                    spf[3 * p + 2] = gz;
-                }
-                if (leaf) leaf[(int64_t)a * P + tile * kTilePoints + p] = s_win;
+        uint64_t todo;
+        bool masked;
+        {
+            const float ex = spf[765] - spf[0], ey = spf[766] - spf[1], ez = spf[767] - spf[2];  // last - first point: LDS broadcasts
+            masked = ex * ex + ey * ey + ez * ez <= span2;  // false for a NaN, too
+            if (masked) {
+                todo = tile_leaf_mask(cull, S, lane, spf, lower);
+            } else {
+                lower = -__builtin_inff();
+                todo = S >= 64 ? ~0ull : ((1ull << S) - 1ull);
             }
         }
+#endif
+        // two copies of the leaf loop only where instructions are what binds (kEstimate: grids that live in L2); the
+        // gather-bound kInlineExact build loses more to the larger body than the simpler loop gives (README-size robot,
+        // sorted points: 1.00 -> 1.10 ms with both copies)
+        if (MODE != kEstimate || masked) tile_passes<PPP, MODE, PACKED, true>(grids, S, tf, A, a, tile, P, val, leaf, spf, lane, todo, lower);
+        else tile_passes<PPP, MODE, PACKED, false>(grids, S, tf, A, a, tile, P, val, leaf, spf, lane, todo, lower);
         PVAMD_WAVE_SYNC();
         if constexpr (PACKED) continue;
         const int64_t o = (int64_t)a * P + tile * kTilePoints;  // multiple of 4: rows start 16-byte aligned
