@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define PVAMD_ABI_VERSION 6
+#define PVAMD_ABI_VERSION 7
 
 #define PVAMD_E_NULL      (-1)  /* a required pointer is NULL            */
 #define PVAMD_E_SHAPE     (-2)  /* a size/shape argument is out of range */
@@ -47,7 +47,25 @@ extern "C" {
  * Index arithmetic is carried out in the dtype the reference's torch promotion would use:
  * index_f64 = 1 when the value range reached the view as float64 (numpy ranges, the README flow),
  * 0 when it reached it as float32 (python-float ranges).  Both triples are always filled in.
+ *
+ * `rule`: the choices of the view that NO reference test pins (multidim_indexing is an un-vendored, un-pinned
+ * dependency; call sites sdf.py:521,537-540).  0 = what this library restates by default: the index is
+ * round-half-to-even((p - min) / res), a point is valid when min <= p <= max (tested on the VALUE).  The bits
+ * select the alternatives, so that matching the real package is a flag, not a kernel change:
+ *   PVAMD_RULE_VALID_ON_INDEX   valid when 0 <= index < shape on the ROUNDED index (NaN / infinite quotients: invalid),
+ *                               i.e. the range grows by half a voxel on every side
+ *   PVAMD_RULE_ROUND_HALF_AWAY  index = round((p - min) / res), halves away from zero (C roundf / round)
+ *   PVAMD_RULE_ROUND_FLOOR_HALF index = floor((p - min) / res + 0.5), the sum rounded in the index dtype
+ *   PVAMD_RULE_RES_F64          (host side; nothing in the kernels reads it) a float32 range's resolution was evaluated
+ *                               in float64 and then rounded to float32, instead of in float32 throughout
+ * The query kernels' fast paths are rule-independent: their range test compares with vlo / vhi and their index
+ * estimate falls back to the exact statement near every half-integer -- pvamd_grid_finalize() derives vlo / vhi for the
+ * rule, and the exact statements (grid_lookup.h voxel_index_1d) follow it.
  */
+#define PVAMD_RULE_VALID_ON_INDEX   1
+#define PVAMD_RULE_ROUND_HALF_AWAY  2
+#define PVAMD_RULE_ROUND_FLOOR_HALF 4
+#define PVAMD_RULE_RES_F64          8
 typedef struct pvamd_grid {
     const float* vox;        /* device, [nx*ny*nz][4]                                              */
     double       dmin[3];    /* range minimum per dim (float64 view)                               */
@@ -63,10 +81,12 @@ typedef struct pvamd_grid {
     int32_t      oob_mode;   /* PVAMD_OOB_*                                                        */
     int32_t      finalized;  /* set by pvamd_grid_finalize(); kernels refuse descriptors without it */
     /* ---- derived by pvamd_grid_finalize() from the fields above; callers do not fill these ---- */
-    float        vlo[3];     /* smallest float32 p with min <= p in the index dtype (exact range test in fp32)  */
-    float        vhi[3];     /* largest  float32 p with p <= max                                             */
+    float        vlo[3];     /* smallest float32 p that is valid under `rule` (exact range test in fp32)       */
+    float        vhi[3];     /* largest  float32 p that is valid                                             */
     float        inv32[3];   /* float32(1/res): the multiply-first index estimate, checked against a rounding */
     float        err32[3];   /* bound and redone with the exact IEEE division when it is within it            */
+    /* ---- filled by the caller (before pvamd_grid_finalize) ---- */
+    int32_t      rule;       /* PVAMD_RULE_* bits; 0 = the default restatement (occupies former padding)      */
     /* ---- float64 query points (the *_f64 entry points) ---- */
     double       dbb_min[3]; /* surface bounding box in float64: sdf.py:556-557 casts self.bb to the query dtype   */
     double       dbb_max[3];
@@ -182,10 +202,12 @@ int pvamd_voxel_scatter_u8(const pvamd_grid_t* grid, uint8_t* storage, const flo
  * flags are rare and the grids are L2-resident, i.e. the kernel is instruction-bound); with the hint the exact statements
  * sit inline (cheapest for large, gather-bound grids, whose larger coordinate / resolution ratios also flag more visits).
  * The transforms must be RIGID (orthonormal 3x3, last row 0 0 0 1): the gradient is rotated back with R^T and the
- * leaf-culling bounds rely on distances being preserved.                                                  */
+ * leaf-culling bounds rely on distances being preserved.
+ * Any P >= 0 and any A >= 1 (batches above 65535 configurations go out in slabs); points / out_val / out_grad need only
+ * their natural 4-byte alignment -- rows of an odd P (the reference README's M = 15,251) take the same kernel.      */
 #define PVAMD_COMPOSED_INLINE_EXACT 1
 #define PVAMD_COMPOSED_FORCE_PER_LANE 2   /* testing / tuning: take the one-point-per-lane kernel whatever the size */
-#define PVAMD_COMPOSED_FORCE_WAVE_TILE 4  /* testing / tuning: take the wave-tile kernel for every whole 256-point tile  */
+#define PVAMD_COMPOSED_FORCE_WAVE_TILE 4  /* testing / tuning: take the wave-tile kernel whatever the size                 */
 int pvamd_composed_query(const pvamd_grid_t* grids, int32_t S, const float* tf, int32_t A,
                          const float* points, int64_t P,
                          float* out_val, float* out_grad, int32_t* out_leaf, int32_t flags, void* stream);

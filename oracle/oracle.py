@@ -21,7 +21,7 @@ class OracleGrid(ctypes.Structure):
         ("fmin", ctypes.c_float * 3), ("fmax", ctypes.c_float * 3), ("fres", ctypes.c_float * 3),
         ("bb_min", ctypes.c_float * 3), ("bb_max", ctypes.c_float * 3),
         ("shape", ctypes.c_int32 * 3), ("index_f64", ctypes.c_int32), ("oob_mode", ctypes.c_int32),
-        ("reserved", ctypes.c_int32),
+        ("rule", ctypes.c_int32),
         ("dbb_min", ctypes.c_double * 3), ("dbb_max", ctypes.c_double * 3),
     ]
 
@@ -70,7 +70,7 @@ class Grid:
     range_min / range_max: length-3 sequences; their numpy dtype (float32 / float64) selects the index dtype the way
     torch promotion does in the reference."""
 
-    def __init__(self, val, grad, range_min, range_max, bb, oob_mode=1, index_f64=None):
+    def __init__(self, val, grad, range_min, range_max, bb, oob_mode=1, index_f64=None, rule=0):
         self.val = _f32(val)
         self.shape = tuple(self.val.shape)
         self.grad = _f32(grad).reshape(-1, 3)
@@ -87,7 +87,10 @@ class Grid:
             fmin, fmax, fres = dmin.astype(np.float32), dmax.astype(np.float32), dres.astype(np.float32)
         else:
             fmin, fmax = rmin.astype(np.float32), rmax.astype(np.float32)
-            fres = ((fmax - fmin) / cells.astype(np.float32)).astype(np.float32)
+            if rule & 8:  # the resolution of a float32 range evaluated in float64, then rounded
+                fres = ((fmax.astype(np.float64) - fmin.astype(np.float64)) / cells).astype(np.float32)
+            else:
+                fres = ((fmax - fmin) / cells.astype(np.float32)).astype(np.float32)
             dmin, dmax, dres = fmin.astype(np.float64), fmax.astype(np.float64), fres.astype(np.float64)
         bb64 = np.asarray(bb, dtype=np.float64).reshape(3, 2)  # float64 queries see the un-rounded box (sdf.py:556-557)
         bb = bb64.astype(np.float32)
@@ -99,6 +102,8 @@ class Grid:
             g.shape[d] = self.shape[d]
         g.index_f64 = int(self.index_f64)
         g.oob_mode = int(oob_mode)
+        g.rule = int(rule)
+        self.rule = int(rule)
         self.c = g
 
 

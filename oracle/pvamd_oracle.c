@@ -46,7 +46,9 @@ typedef struct oracle_grid {
     int32_t shape[3];
     int32_t index_f64;
     int32_t oob_mode; /* 0 LOOKUP_GT_SDF (zeros + mask), 1 BOUNDING_BOX */
-    int32_t reserved;
+    int32_t rule;     /* which of the UNPINNED choices of the third-party view to restate (include/pvamd.h PVAMD_RULE_*):
+                         0 = round half to even + validity on the value; 1 validity on the rounded index; 2 round half away
+                         from zero; 4 floor(q + 0.5); 8 (host side only) resolution of a float32 range evaluated in float64 */
     double dbb_min[3], dbb_max[3]; /* the bounding box as float64: what sdf.py:556-557 casts self.bb to for float64 queries */
 } oracle_grid_t;
 
@@ -66,14 +68,38 @@ void oracle_set_num_threads(int n) {
 #endif
 }
 
+/* The quotient -> index step.  Which rounding multidim_indexing applies is not pinned by anything in the reference
+ * (sdf.py:537 only calls ensure_index_key); rule 0 restates torch.round (half to even), the bits the alternatives. */
+static double round_rule_d(int rule, double q) {
+    if (rule & 2) return round(q);        /* halves away from zero */
+    if (rule & 4) return floor(q + 0.5);  /* the sum rounds in float64 */
+    return rint(q);
+}
+static float round_rule_f(int rule, float q) {
+    if (rule & 2) return roundf(q);
+    if (rule & 4) return floorf(q + 0.5f); /* the sum rounds in float32 (-ffp-contract=off) */
+    return rintf(q);
+}
+/* float -> int64 as the GPU converts (saturating, NaN -> 0), so that keys of invalid points compare equal too */
+static int64_t to_key(double kq) {
+    if (!(kq == kq)) return 0;
+    if (kq >= 9223372036854775807.0) return INT64_MAX;
+    if (kq <= -9223372036854775808.0) return INT64_MIN;
+    return (int64_t)kq;
+}
+
 /* sdf.py:537 ensure_index_key + sdf.py:540 get_valid_values, one dimension */
 static int index_1d(const oracle_grid_t* g, int d, float p, int64_t* k) {
     if (g->index_f64) {
         const double pd = (double)p;
-        *k = (int64_t)rint((pd - g->dmin[d]) / g->dres[d]);
+        const double kq = round_rule_d(g->rule, (pd - g->dmin[d]) / g->dres[d]);
+        *k = to_key(kq);
+        if (g->rule & 1) return (kq >= 0.0) && (kq <= (double)(g->shape[d] - 1)); /* validity on the rounded index */
         return (g->dmin[d] <= pd) && (pd <= g->dmax[d]);
     }
-    *k = (int64_t)rintf((p - g->fmin[d]) / g->fres[d]);
+    const float kq = round_rule_f(g->rule, (p - g->fmin[d]) / g->fres[d]);
+    *k = to_key((double)kq);
+    if (g->rule & 1) return (kq >= 0.f) && (kq <= (float)(g->shape[d] - 1));
     return (g->fmin[d] <= p) && (p <= g->fmax[d]);
 }
 
@@ -150,7 +176,9 @@ void oracle_cached_query(const oracle_grid_t* g, const float* pts, int64_t P, fl
  * (points - min) / resolution (sdf.py:537 via the view) is float64 whatever dtype the range had, the range test
  * (sdf.py:540) compares in float64, and the BOUNDING_BOX branch runs on self.bb.to(float64) (sdf.py:556-557). */
 static int index_1d_f64(const oracle_grid_t* g, int d, double p, int64_t* k) {
-    *k = (int64_t)rint((p - g->dmin[d]) / g->dres[d]); /* dmin / dres = the view's tensors promoted to float64 */
+    const double kq = round_rule_d(g->rule, (p - g->dmin[d]) / g->dres[d]); /* dmin / dres = the view's tensors promoted to float64 */
+    *k = to_key(kq);
+    if (g->rule & 1) return (kq >= 0.0) && (kq <= (double)(g->shape[d] - 1));
     return (g->dmin[d] <= p) && (p <= g->dmax[d]);
 }
 

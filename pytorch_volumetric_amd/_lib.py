@@ -11,10 +11,14 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("PVAMD_LIB") or os.path.join(_HERE, "csrc", "libpvamd.so")  # PVAMD_LIB: A/B builds (tools/)
 
-ABI_VERSION = 6
+ABI_VERSION = 7
 OOB_LOOKUP_GT_SDF = 0
 OOB_BOUNDING_BOX = 1
 COMPOSED_INLINE_EXACT = 1
+RULE_VALID_ON_INDEX = 1
+RULE_ROUND_HALF_AWAY = 2
+RULE_ROUND_FLOOR_HALF = 4
+RULE_RES_F64 = 8
 TRI_REC = 24
 TRI_TILE = 256
 TRI_GROUP = 16
@@ -61,6 +65,7 @@ class GridDesc(ctypes.Structure):
         ("vhi", ctypes.c_float * 3),
         ("inv32", ctypes.c_float * 3),
         ("err32", ctypes.c_float * 3),
+        ("rule", ctypes.c_int32),
         ("dbb_min", ctypes.c_double * 3),
         ("dbb_max", ctypes.c_double * 3),
     ]
@@ -240,6 +245,20 @@ class on_device:
         if self.prev >= 0:
             torch.cuda.set_device(self.prev)
         return False
+
+
+# Bumped whenever an attribute that the cached call plans of CachedSDF / ComposedSDF depend on is assigned
+# (CachedSDF.__setattr__): a plan remembers the epoch it was built in and is rebuilt when it has moved on.
+EPOCH = [0]
+current_device_index = torch._C._cuda_getDevice
+current_raw_stream = torch._C._cuda_getCurrentRawStream
+
+
+def same_gpu(out_device, dev):
+    """Whether results wanted on `out_device` (a str / torch.device as the reference's `device=` arguments take them)
+    can stay where the kernel wrote them, on `dev`."""
+    d = torch.device(out_device)
+    return d.type == "cuda" and (d.index is None or d.index == dev.index)
 
 
 def ptr(t):

@@ -9,32 +9,53 @@ namespace pvamd {
 
 // ---- wave-tile path: one wave = 256 consecutive points per pass ----
 // Every global instruction moves a contiguous 1 KB (64 lanes x 16 B): 3 loads bring the tile's 768 floats of xyz into
-// a wave-private LDS slice, each lane then owns points lane, lane+64, lane+128, lane+192 of the tile (stride-3 dword
-// LDS reads: conflict-free), the 4 results go back through the same slice and leave as 1 + 3 contiguous 1 KB stores.
+// a wave-private LDS slice; the results go back through the same slice and leave as 1 + 3 contiguous 1 KB stores.
 // No block barrier: a wave's LDS traffic is ordered.  Measured against the previous "4 points per thread, 48-byte
 // strided float4" form: 0.63 ms -> 0.38 ms for 64M points (tools/kbench.hip, profiles/r01_kbench.txt).
-constexpr int kWavesPerBlock = 4;
+// Which points a lane owns (PVAMD_CQ_OWN4):
+//   0  lane, lane+64, lane+128, lane+192: stride-3 dword LDS reads (conflict-free), 16 dword LDS writes for the results
+//   1  4*lane .. 4*lane+3: the lane's 12 input floats are three ds_read_b128 at a 48-byte lane stride (conflict-free per
+//      16 lanes), its four values are ONE 16-byte global store (no LDS), its 12 gradient floats three ds_write_b128:
+//      12 LDS instructions per tile instead of 35
+// Any point count and any 4-byte aligned buffers: the 16-byte accesses take dword addresses (common.h f32x4_u), the last
+// tile may hold fewer than 256 points (its loads are clamped to the array, its stores are per-dword and guarded).
+#ifndef PVAMD_CQ_WAVES
+#define PVAMD_CQ_WAVES 4
+#endif
+#ifndef PVAMD_CQ_OWN4
+#define PVAMD_CQ_OWN4 1
+#endif
+constexpr int kWavesPerBlock = PVAMD_CQ_WAVES;
 constexpr int kTilePoints = 256;
+constexpr bool kOwn4 = PVAMD_CQ_OWN4 != 0;
+#ifndef PVAMD_CQ_MIN_POINTS
+#define PVAMD_CQ_MIN_POINTS 16384
+#endif
+constexpr int64_t kWaveTileMinPoints = PVAMD_CQ_MIN_POINTS;
 
 // LD_NT / ST_NT: non-temporal loads / stores.  Measured (tools/kbench.hip): batches whose points are cache-resident
 // (<= a few M points, e.g. produced by the previous kernel or re-used) prefer plain loads + nt stores (6.6 -> 6.3 us per
 // 1M points); batches far beyond the 256 MB Infinity Cache prefer nt loads + plain stores (0.370 -> 0.358 ms per 64M).
+#ifndef PVAMD_CQ_MINWAVES
+#define PVAMD_CQ_MINWAVES 1
+#endif
 template <bool F64, bool WRITE_OOB, bool LD_NT, bool ST_NT>
-__global__ __launch_bounds__(kWavesPerBlock * 64) void cached_query_wave(const pvamd_grid_t g,
-                                                                         const f32x4* __restrict__ pts4,
-                                                                         int64_t ntiles, f32x4* __restrict__ val4,
-                                                                         f32x4* __restrict__ grad4,
+__global__ __launch_bounds__(kWavesPerBlock * 64, PVAMD_CQ_MINWAVES) void cached_query_wave(const pvamd_grid_t g,
+                                                                         const float* __restrict__ pts, int64_t P,
+                                                                         float* __restrict__ val,
+                                                                         float* __restrict__ grad,
                                                                          uint8_t* __restrict__ oob) {
     __shared__ __attribute__((aligned(16))) float lds[kWavesPerBlock][1024];  // per wave: 768 floats xyz/grad + 256 floats val = 4 KB
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     float* spf = lds[wave];
     f32x4_alias* sp = reinterpret_cast<f32x4_alias*>(spf);
     float* svf = spf + 768;
+    const int64_t ntiles = (P + kTilePoints - 1) / kTilePoints;
     const int64_t wstride = (int64_t)gridDim.x * kWavesPerBlock;
     int64_t tile = (int64_t)blockIdx.x * kWavesPerBlock + wave;
     f32x4 a, b, c;
-    auto load3 = [&](int64_t t) {
-        const f32x4* src = pts4 + t * 192;
+    auto load3 = [&](int64_t t) {  // a whole tile: three contiguous KB
+        const f32x4_u* src = reinterpret_cast<const f32x4_u*>(pts + t * 768);
         if (LD_NT) {
             a = __builtin_nontemporal_load(src + lane);
             b = __builtin_nontemporal_load(src + lane + 64);
@@ -45,54 +66,113 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void cached_query_wave(const p
             c = src[lane + 128];
         }
     };
-    if (tile < ntiles) load3(tile);
+    auto whole = [&](int64_t t) { return P - t * kTilePoints >= kTilePoints; };
+    if (tile < ntiles && whole(tile)) load3(tile);
     for (; tile < ntiles; tile += wstride) {
-        sp[lane] = a;
-        sp[lane + 64] = b;
-        sp[lane + 128] = c;
+        if (__builtin_expect(whole(tile), 1)) {
+            sp[lane] = a;
+            sp[lane + 64] = b;
+            sp[lane + 128] = c;
+        } else {  // the last, partial tile (rare; kept small): straight into LDS, slots past the end repeat the last float
+            const int last = 3 * (int)(P - tile * kTilePoints) - 1;
+#pragma unroll 1
+            for (int i = lane; i < 768; i += 64) spf[i] = pts[tile * 768 + (i < last ? i : last)];
+        }
         // software prefetch: the next tile's HBM loads are in flight while this tile is looked up (the wave fences
         // below stop the compiler from doing this itself); 0.47 -> 0.42 ms per 64M points (profiles/r01_kbench.txt)
         const int64_t next = tile + wstride;
-        if (next < ntiles) load3(next);
+        if (next < ntiles && whole(next)) load3(next);
         PVAMD_WAVE_SYNC();
+        const int64_t left = P - tile * kTilePoints;
+        const int nvalid = left < kTilePoints ? (int)left : kTilePoints;
         float px[4], py[4], pz[4];
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const int p = lane + 64 * k;
-            px[k] = spf[3 * p];
-            py[k] = spf[3 * p + 1];
-            pz[k] = spf[3 * p + 2];
-        }
-        PVAMD_WAVE_SYNC();
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const int p = lane + 64 * k;
-            bool valid;
-            const float4 r = cached_lookup<F64>(g, px[k], py[k], pz[k], valid);
-            svf[p] = r.x;
-            spf[3 * p] = r.y;
-            spf[3 * p + 1] = r.z;
-            spf[3 * p + 2] = r.w;
-            if constexpr (WRITE_OOB) oob[tile * kTilePoints + p] = valid ? 0 : 1;
-        }
-        PVAMD_WAVE_SYNC();
-        f32x4* dst = grad4 + tile * 192;
-        if (ST_NT) {
-            __builtin_nontemporal_store(sp[192 + lane], val4 + tile * 64 + lane);
-            __builtin_nontemporal_store(sp[lane], dst + lane);
-            __builtin_nontemporal_store(sp[lane + 64], dst + lane + 64);
-            __builtin_nontemporal_store(sp[lane + 128], dst + lane + 128);
+        if constexpr (kOwn4) {
+            const f32x4 q0 = sp[3 * lane], q1 = sp[3 * lane + 1], q2 = sp[3 * lane + 2];
+            px[0] = q0.x; py[0] = q0.y; pz[0] = q0.z;
+            px[1] = q0.w; py[1] = q1.x; pz[1] = q1.y;
+            px[2] = q1.z; py[2] = q1.w; pz[2] = q2.x;
+            px[3] = q2.y; py[3] = q2.z; pz[3] = q2.w;
         } else {
-            val4[tile * 64 + lane] = sp[192 + lane];
-            dst[lane] = sp[lane];
-            dst[lane + 64] = sp[lane + 64];
-            dst[lane + 128] = sp[lane + 128];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int p = lane + 64 * k;
+                px[k] = spf[3 * p];
+                py[k] = spf[3 * p + 1];
+                pz[k] = spf[3 * p + 2];
+            }
+        }
+        PVAMD_WAVE_SYNC();
+        const int64_t o = tile * kTilePoints;
+        const bool full = nvalid == kTilePoints;
+        f32x4 v4;
+        if constexpr (kOwn4) {
+            float4 r[4];
+            bool valid[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) r[k] = cached_lookup<F64>(g, px[k], py[k], pz[k], valid[k]);
+            sp[3 * lane] = f32x4{r[0].y, r[0].z, r[0].w, r[1].y};
+            sp[3 * lane + 1] = f32x4{r[1].z, r[1].w, r[2].y, r[2].z};
+            sp[3 * lane + 2] = f32x4{r[2].w, r[3].y, r[3].z, r[3].w};
+            v4 = f32x4{r[0].x, r[1].x, r[2].x, r[3].x};
+            if constexpr (WRITE_OOB) {
+                if (__builtin_expect(full, 1)) {
+                    const uint32_t m = (valid[0] ? 0u : 1u) | (valid[1] ? 0u : 1u << 8) | (valid[2] ? 0u : 1u << 16) | (valid[3] ? 0u : 1u << 24);
+                    __builtin_memcpy(oob + o + 4 * lane, &m, 4);  // the 4 consecutive flags of this lane
+                } else {
+#pragma unroll 1
+                    for (int k = 0; k < 4; ++k)
+                        if (4 * lane + k < nvalid) oob[o + 4 * lane + k] = valid[k] ? 0 : 1;
+                }
+            }
+            if (__builtin_expect(!full, 0)) {
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+                    if (4 * lane + k < nvalid) val[o + 4 * lane + k] = r[k].x;
+            }
+        } else {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int p = lane + 64 * k;
+                bool valid;
+                const float4 r = cached_lookup<F64>(g, px[k], py[k], pz[k], valid);
+                svf[p] = r.x;
+                spf[3 * p] = r.y;
+                spf[3 * p + 1] = r.z;
+                spf[3 * p + 2] = r.w;
+                if constexpr (WRITE_OOB) {
+                    if (p < nvalid) oob[o + p] = valid ? 0 : 1;
+                }
+            }
+        }
+        PVAMD_WAVE_SYNC();
+        if (__builtin_expect(full, 1)) {
+            f32x4_u* vdst = reinterpret_cast<f32x4_u*>(val + o);
+            f32x4_u* dst = reinterpret_cast<f32x4_u*>(grad + 3 * o);
+            if constexpr (!kOwn4) v4 = sp[192 + lane];
+            if (ST_NT) {
+                __builtin_nontemporal_store(v4, vdst + lane);
+                __builtin_nontemporal_store(sp[lane], dst + lane);
+                __builtin_nontemporal_store(sp[lane + 64], dst + lane + 64);
+                __builtin_nontemporal_store(sp[lane + 128], dst + lane + 128);
+            } else {
+                vdst[lane] = v4;
+                dst[lane] = sp[lane];
+                dst[lane + 64] = sp[lane + 64];
+                dst[lane + 128] = sp[lane + 128];
+            }
+        } else {
+            if constexpr (!kOwn4) {
+#pragma unroll 1
+                for (int i = lane; i < nvalid; i += 64) val[o + i] = svf[i];
+            }
+#pragma unroll 1
+            for (int i = lane; i < 3 * nvalid; i += 64) grad[3 * o + i] = spf[i];
         }
         PVAMD_WAVE_SYNC();
     }
 }
 
-// ---- scalar path: tail points and buffers that are not 16-byte aligned ----
+// ---- one point per lane: small batches (more waves than 256-point tiles would give) ----
 template <bool F64>
 __global__ __launch_bounds__(256) void cached_query_scalar(const pvamd_grid_t g, const float* __restrict__ pts,
                                                             int64_t first, int64_t P, float* __restrict__ val,
@@ -147,8 +227,10 @@ PVAMD_DEV bool voxel_key_f64(const pvamd_grid_t& g, const double p[3], long long
     bool valid = true;
 #pragma unroll
     for (int d = 0; d < 3; ++d) {
-        valid &= (g.dmin[d] <= p[d]) && (p[d] <= g.dmax[d]);
-        key[d] = (long long)__builtin_rint((p[d] - g.dmin[d]) / g.dres[d]);
+        const double kq = round_by_rule<double>(g.rule, (p[d] - g.dmin[d]) / g.dres[d]);
+        key[d] = (long long)kq;
+        if (__builtin_expect(g.rule & PVAMD_RULE_VALID_ON_INDEX, 0)) valid &= (kq >= 0.0) && (kq <= (double)(g.shape[d] - 1));
+        else valid &= (g.dmin[d] <= p[d]) && (p[d] <= g.dmax[d]);
     }
     return valid;
 }
@@ -256,25 +338,30 @@ extern "C" int pvamd_cached_query(const pvamd_grid_t* grid, const float* points,
     if (!aligned_to(points, 4) || !aligned_to(out_val, 4) || !aligned_to(out_grad, 4)) return PVAMD_E_ALIGN;
     hipStream_t s = (hipStream_t)stream;
     const bool f64 = grid->index_f64 != 0;
-    const bool vec_ok = aligned_to(points, 16) && aligned_to(out_val, 16) && aligned_to(out_grad, 16);
-    const int64_t ntiles = vec_ok ? P / kTilePoints : 0;
-    if (ntiles > 0) {
+    // One launch for any P.  >= 16,384 points (64 tiles = a workgroup per four CUs): the wave-tile kernel, which finishes a
+    // partial last tile itself; fewer: one point per lane (4x the waves, nothing to amortise).
+    if (P >= kWaveTileMinPoints) {
+        const int64_t ntiles = (P + kTilePoints - 1) / kTilePoints;
         const int64_t need = (ntiles + kWavesPerBlock - 1) / kWavesPerBlock;
 #ifndef PVAMD_CQ_BIG_ST_NT
 #define PVAMD_CQ_BIG_ST_NT false
 #endif
+#ifndef PVAMD_CQ_BIG_LD_NT
+#define PVAMD_CQ_BIG_LD_NT true
+#endif
 #ifndef PVAMD_CQ_BLOCKS
 #define PVAMD_CQ_BLOCKS 1024
 #endif
-        const dim3 grid_dim((unsigned)(need < PVAMD_CQ_BLOCKS ? need : PVAMD_CQ_BLOCKS)), block(kWavesPerBlock * 64);
-        const f32x4* p4 = reinterpret_cast<const f32x4*>(points);
-        f32x4* v4 = reinterpret_cast<f32x4*>(out_val);
-        f32x4* g4 = reinterpret_cast<f32x4*>(out_grad);
+#ifndef PVAMD_CQ_BIG_BLOCKS
+#define PVAMD_CQ_BIG_BLOCKS PVAMD_CQ_BLOCKS
+#endif
         const bool big = P > ((int64_t)8 << 20);  // > 8M points (96 MB of xyz): streaming regime
+        const int64_t cap = big ? PVAMD_CQ_BIG_BLOCKS : PVAMD_CQ_BLOCKS;  // 0: one tile per wave, no grid-stride loop
+        const dim3 grid_dim((unsigned)((cap > 0 && need > cap) ? cap : need)), block(kWavesPerBlock * 64);
 #define PVAMD_LAUNCH_CQ(F64_, OOB_)                                                                                      \
     do {                                                                                                                \
-        if (big) hipLaunchKernelGGL((cached_query_wave<F64_, OOB_, true, PVAMD_CQ_BIG_ST_NT>), grid_dim, block, 0, s, *grid, p4, ntiles, v4, g4, out_oob); \
-        else hipLaunchKernelGGL((cached_query_wave<F64_, OOB_, false, true>), grid_dim, block, 0, s, *grid, p4, ntiles, v4, g4, out_oob);    \
+        if (big) hipLaunchKernelGGL((cached_query_wave<F64_, OOB_, PVAMD_CQ_BIG_LD_NT, PVAMD_CQ_BIG_ST_NT>), grid_dim, block, 0, s, *grid, points, P, out_val, out_grad, out_oob); \
+        else hipLaunchKernelGGL((cached_query_wave<F64_, OOB_, false, true>), grid_dim, block, 0, s, *grid, points, P, out_val, out_grad, out_oob);    \
     } while (0)
         if (f64) {
             if (out_oob) PVAMD_LAUNCH_CQ(true, true);
@@ -284,12 +371,10 @@ extern "C" int pvamd_cached_query(const pvamd_grid_t* grid, const float* points,
             else PVAMD_LAUNCH_CQ(false, false);
         }
 #undef PVAMD_LAUNCH_CQ
-    }
-    const int64_t first = ntiles * kTilePoints;
-    if (first < P) {
-        const dim3 grid_dim(stream_grid(P - first, 256)), block(256);
-        if (f64) hipLaunchKernelGGL((cached_query_scalar<true>), grid_dim, block, 0, s, *grid, points, first, P, out_val, out_grad, out_oob);
-        else hipLaunchKernelGGL((cached_query_scalar<false>), grid_dim, block, 0, s, *grid, points, first, P, out_val, out_grad, out_oob);
+    } else {
+        const dim3 grid_dim(stream_grid(P, 256)), block(256);
+        if (f64) hipLaunchKernelGGL((cached_query_scalar<true>), grid_dim, block, 0, s, *grid, points, (int64_t)0, P, out_val, out_grad, out_oob);
+        else hipLaunchKernelGGL((cached_query_scalar<false>), grid_dim, block, 0, s, *grid, points, (int64_t)0, P, out_val, out_grad, out_oob);
     }
     return (int)hipGetLastError();
 }

@@ -11,6 +11,10 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 // same 16-byte vector, but allowed to alias plain float storage (LDS slices accessed both as floats and as float4s)
 typedef f32x4 __attribute__((may_alias)) f32x4_alias;
+// the same 16 bytes at an address that is only 4-byte aligned: gfx950 global_load/store_dwordx4 take any dword address
+// (amdhsa runs with unaligned access mode on), so an (A, P) output row that starts at a * P floats with P odd still
+// leaves as 16-byte stores -- the compiler emits the same instruction as for f32x4
+typedef float f32x4_u __attribute__((ext_vector_type(4), aligned(4)));
 
 // Wave-synchronous LDS exchange: lanes of ONE wave hand data to each other through LDS without a block barrier.  The
 // hardware executes a wave's DS instructions in order, but the compiler reasons per thread and will move a lane's

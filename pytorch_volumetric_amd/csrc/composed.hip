@@ -240,6 +240,17 @@ PVAMD_DEV uint64_t tile_leaf_mask(const float (*cull)[8], int S, int lane, const
 // through a wave-private LDS slice (same scheme as cached_query_wave, see cached.hip).
 constexpr int kWavesPerBlock = 4;
 constexpr int kTilePoints = 256;
+// configurations per launch (a grid dimension carries them); a build knob so that a test can cross the slab border with
+// a small batch
+#ifndef PVAMD_COMPOSED_SLAB
+#define PVAMD_COMPOSED_SLAB 65535
+#endif
+constexpr int kConfigSlab = PVAMD_COMPOSED_SLAB;
+// fewer (tile, configuration) pairs than this: the one-point-per-lane kernel (4x the parallelism)
+#ifndef PVAMD_COMPOSED_WAVE_MIN_TILES
+#define PVAMD_COMPOSED_WAVE_MIN_TILES 4096
+#endif
+constexpr int64_t kWaveTileMinTiles = PVAMD_COMPOSED_WAVE_MIN_TILES;
 #ifndef PVAMD_COMPOSED_PPP
 #define PVAMD_COMPOSED_PPP 2
 #endif
@@ -255,7 +266,7 @@ constexpr int kTilePoints = 256;
 template <int PPP, int MODE, bool PACKED, bool MASKED>
 PVAMD_DEV void tile_passes(const pvamd_grid_t* __restrict__ grids, int S, const float* __restrict__ tf, int A, int a,
                            int64_t tile, int64_t P, float* __restrict__ val, int* __restrict__ leaf, float* spf, int lane,
-                           uint64_t todo, float lower) {
+                           uint64_t todo, float lower, int nvalid) {
     float* svf = spf + 768;
     const int first_leaf = todo ? __builtin_ctzll(todo) : 0;
     // A tile compact enough for the static test to drop a leaf is worth re-testing as the minimum tightens: after
@@ -332,7 +343,7 @@ PVAMD_DEV void tile_passes(const pvamd_grid_t* __restrict__ grids, int S, const 
                 spf[3 * p + 1] = gy;
                 spf[3 * p + 2] = gz;
             }
-            if (leaf) leaf[(int64_t)a * P + tile * kTilePoints + p] = s_win;
+            if (leaf && p < nvalid) leaf[(int64_t)a * P + tile * kTilePoints + p] = s_win;
         }
     }
 }
@@ -340,7 +351,7 @@ PVAMD_DEV void tile_passes(const pvamd_grid_t* __restrict__ grids, int S, const 
 template <int PPP, int MODE, bool PACKED>
 __global__ __launch_bounds__(kWavesPerBlock * 64, MODE == kEstimate ? PVAMD_COMPOSED_MINWAVES : 1) void composed_query_wave(const pvamd_grid_t* __restrict__ grids, int S,
                                                                            const float* __restrict__ tf, int A,
-                                                                           const f32x4* __restrict__ pts4,
+                                                                           const float* __restrict__ pts,
                                                                            int64_t ntiles, int64_t P,
                                                                            float* __restrict__ val,
                                                                            float* __restrict__ grad,
@@ -372,10 +383,23 @@ __global__ __launch_bounds__(kWavesPerBlock * 64, MODE == kEstimate ? PVAMD_COMP
     const float span2 = (kMaskSpan * scene) * (kMaskSpan * scene);
     const int64_t wstride = (int64_t)gridDim.y * kWavesPerBlock;
     for (int64_t tile = (int64_t)blockIdx.y * kWavesPerBlock + wave; tile < ntiles; tile += wstride) {
-        const f32x4* src = pts4 + tile * 192;  // re-read for every configuration: L2-resident
-        sp[lane] = src[lane];
-        sp[lane + 64] = src[lane + 64];
-        sp[lane + 128] = src[lane + 128];
+        // P is any count: the last tile may hold fewer than 256 points (nvalid); its empty slots carry copies of the
+        // last point, so that the tile's bounds stay tight and no lane computes on garbage (no result is written for them)
+        const int64_t left = P - tile * kTilePoints;
+        const int nvalid = left < kTilePoints ? (int)left : kTilePoints;
+        if (__builtin_expect(nvalid == kTilePoints, 1)) {
+            // re-read for every configuration: L2-resident.  The array is only known to be 4-byte aligned.
+            const f32x4_u* src = reinterpret_cast<const f32x4_u*>(pts + tile * 768);
+            sp[lane] = src[lane];
+            sp[lane + 64] = src[lane + 64];
+            sp[lane + 128] = src[lane + 128];
+        } else {
+#pragma unroll
+            for (int k = 0; k < 12; ++k) {
+                const int i = lane + 64 * k, p = i / 3;
+                spf[i] = pts[tile * 768 + (p < nvalid ? i : i - 3 * (p - (nvalid - 1)))];
+            }
+        }
         PVAMD_WAVE_SYNC();
         float lower;
 #ifdef PVAMD_NO_TILE_MASK
@@ -399,16 +423,30 @@ __global__ __launch_bounds__(kWavesPerBlock * 64, MODE == kEstimate ? PVAMD_COMP
         // two copies of the leaf loop only where instructions are what binds (kEstimate: grids that live in L2); the
         // gather-bound kInlineExact build loses more to the larger body than the simpler loop gives (README-size robot,
         // sorted points: 1.00 -> 1.10 ms with both copies)
-        if (MODE != kEstimate || masked) tile_passes<PPP, MODE, PACKED, true>(grids, S, tf, A, a, tile, P, val, leaf, spf, lane, todo, lower);
-        else tile_passes<PPP, MODE, PACKED, false>(grids, S, tf, A, a, tile, P, val, leaf, spf, lane, todo, lower);
+        if (MODE != kEstimate || masked) tile_passes<PPP, MODE, PACKED, true>(grids, S, tf, A, a, tile, P, val, leaf, spf, lane, todo, lower, nvalid);
+        else tile_passes<PPP, MODE, PACKED, false>(grids, S, tf, A, a, tile, P, val, leaf, spf, lane, todo, lower, nvalid);
         PVAMD_WAVE_SYNC();
         if constexpr (PACKED) continue;
-        const int64_t o = (int64_t)a * P + tile * kTilePoints;  // multiple of 4: rows start 16-byte aligned
-        __builtin_nontemporal_store(sp[192 + lane], reinterpret_cast<f32x4*>(val + o) + lane);
-        f32x4* dst = reinterpret_cast<f32x4*>(grad + 3 * o);
-        __builtin_nontemporal_store(sp[lane], dst + lane);
-        __builtin_nontemporal_store(sp[lane + 64], dst + lane + 64);
-        __builtin_nontemporal_store(sp[lane + 128], dst + lane + 128);
+        // row a starts at a * P floats: 16-byte aligned only when P % 4 == 0 -- the stores take any dword address
+        const int64_t o = (int64_t)a * P + tile * kTilePoints;
+        if (__builtin_expect(nvalid == kTilePoints, 1)) {
+            __builtin_nontemporal_store(sp[192 + lane], reinterpret_cast<f32x4_u*>(val + o) + lane);
+            f32x4_u* dst = reinterpret_cast<f32x4_u*>(grad + 3 * o);
+            __builtin_nontemporal_store(sp[lane], dst + lane);
+            __builtin_nontemporal_store(sp[lane + 64], dst + lane + 64);
+            __builtin_nontemporal_store(sp[lane + 128], dst + lane + 128);
+        } else {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int i = lane + 64 * k;
+                if (i < nvalid) __builtin_nontemporal_store(spf[768 + i], val + o + i);
+            }
+#pragma unroll
+            for (int k = 0; k < 12; ++k) {
+                const int i = lane + 64 * k;
+                if (i < 3 * nvalid) __builtin_nontemporal_store(spf[i], grad + 3 * o + i);
+            }
+        }
         PVAMD_WAVE_SYNC();
     }
 }
@@ -417,14 +455,19 @@ __global__ __launch_bounds__(256) void composed_query_scalar(const pvamd_grid_t*
                                                               const float* __restrict__ tf, int A,
                                                               const float* __restrict__ pts, int64_t first,
                                                               int64_t P, float* __restrict__ val,
-                                                              float* __restrict__ grad, int* __restrict__ leaf, int a0) {
-    const int a = a0 + blockIdx.y;
-    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+                                                              float* __restrict__ grad, int* __restrict__ leaf, int a0,
+                                                              int config_fastest) {
+    // two block orders: points fastest (blockIdx.x = point block, blockIdx.y = configuration) or, like the wave-tile
+    // kernel, configuration fastest (blockIdx.x = configuration): the configurations of one block of points run back to
+    // back and share the grid lines those points touch
+    const int a = a0 + (config_fastest ? blockIdx.x : blockIdx.y);
+    const int64_t bx = config_fastest ? blockIdx.y : blockIdx.x, nbx = config_fastest ? gridDim.y : gridDim.x;
+    const int64_t stride = nbx * blockDim.x;
     const int64_t n = P - first;
     // whole waves iterate together (leaf_candidate votes across the wave): lanes past the end carry a NaN point
     const int64_t rounds = (n + stride - 1) / stride;
     for (int64_t r = 0; r < rounds; ++r) {
-        const int64_t i = first + r * stride + (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+        const int64_t i = first + r * stride + bx * blockDim.x + threadIdx.x;
         const bool live = i < P;
         const float nanv = __builtin_nanf("");
         const float px = live ? pts[3 * i] : nanv, py = live ? pts[3 * i + 1] : nanv, pz = live ? pts[3 * i + 2] : nanv;
@@ -534,7 +577,7 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void composed_unpermute_kernel
         const int64_t j0 = (tile0 + t) * kTilePoints;
         if (j0 >= P) break;
         const int64_t o = (int64_t)a * P + j0;
-        if ((j0 + kTilePoints <= P) && (P % 4 == 0)) {
+        if (j0 + kTilePoints <= P) {  // rows of an odd P start at any dword: 16-byte stores take that (common.h)
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
                 const int p = lane + 64 * k;
@@ -544,8 +587,8 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void composed_unpermute_kernel
                 spf[3 * p + 2] = r[t][k].w;
             }
             PVAMD_WAVE_SYNC();
-            __builtin_nontemporal_store(sp[192 + lane], reinterpret_cast<f32x4*>(val + o) + lane);
-            f32x4* dst = reinterpret_cast<f32x4*>(grad + 3 * o);
+            __builtin_nontemporal_store(sp[192 + lane], reinterpret_cast<f32x4_u*>(val + o) + lane);
+            f32x4_u* dst = reinterpret_cast<f32x4_u*>(grad + 3 * o);
             __builtin_nontemporal_store(sp[lane], dst + lane);
             __builtin_nontemporal_store(sp[lane + 64], dst + lane + 64);
             __builtin_nontemporal_store(sp[lane + 128], dst + lane + 128);
@@ -580,13 +623,12 @@ extern "C" int pvamd_composed_query_packed(const pvamd_grid_t* grids, int32_t S,
     const int64_t tile_blocks = (ntiles + kWavesPerBlock - 1) / kWavesPerBlock;
     constexpr int kSlab = 65535;  // gridDim.y of the query kernel = tile blocks
     if (tile_blocks > kSlab || A > kSlab) return PVAMD_E_SHAPE;  // > 67 M points per call: use the direct entry point
-    const f32x4* p4 = reinterpret_cast<const f32x4*>(points);
     if (flags & PVAMD_COMPOSED_INLINE_EXACT)
         hipLaunchKernelGGL((composed_query_wave<PVAMD_COMPOSED_PPP, kInlineExact, true>), dim3(A, (unsigned)tile_blocks),
-                           dim3(kWavesPerBlock * 64), 0, s, grids, S, tf, A, p4, ntiles, Pp, out_rec, nullptr, nullptr, 0);
+                           dim3(kWavesPerBlock * 64), 0, s, grids, S, tf, A, points, ntiles, Pp, out_rec, nullptr, nullptr, 0);
     else
         hipLaunchKernelGGL((composed_query_wave<PVAMD_COMPOSED_PPP, kEstimate, true>), dim3(A, (unsigned)tile_blocks),
-                           dim3(kWavesPerBlock * 64), 0, s, grids, S, tf, A, p4, ntiles, Pp, out_rec, nullptr, nullptr, 0);
+                           dim3(kWavesPerBlock * 64), 0, s, grids, S, tf, A, points, ntiles, Pp, out_rec, nullptr, nullptr, 0);
     return (int)hipGetLastError();
 }
 
@@ -594,7 +636,7 @@ extern "C" int pvamd_unpack_records(const float* rec, const int32_t* index, int6
                                     float* out_val, float* out_grad, void* stream) {
     if (A < 1 || P < 1 || stride < 1) return PVAMD_E_SHAPE;
     if (!rec || !index || !out_val || !out_grad) return PVAMD_E_NULL;
-    if (!aligned_to(rec, 16) || !aligned_to(index, 4) || !aligned_to(out_val, 16) || !aligned_to(out_grad, 16)) return PVAMD_E_ALIGN;
+    if (!aligned_to(rec, 16) || !aligned_to(index, 4) || !aligned_to(out_val, 4) || !aligned_to(out_grad, 4)) return PVAMD_E_ALIGN;
     const int64_t ntiles = (P + kTilePoints - 1) / kTilePoints;
     const int64_t tile_blocks = (ntiles + kWavesPerBlock - 1) / kWavesPerBlock;
     const int64_t groups = ((int64_t)A + 7) / 8;
@@ -626,9 +668,10 @@ extern "C" int pvamd_composed_query(const pvamd_grid_t* grids, int32_t S, const 
     if (S < 1 || A < 1 || P < 0 || S >= kUnnormalised) return PVAMD_E_SHAPE;
     if (P == 0) return 0;
     if (!grids || !tf || !out_val || !out_grad || !points) return PVAMD_E_NULL;
-    if (!aligned_to(grids, 8) || !aligned_to(tf, 4) || !aligned_to(points, 4)) return PVAMD_E_ALIGN;
+    if (!aligned_to(grids, 8) || !aligned_to(tf, 4) || !aligned_to(points, 4) || !aligned_to(out_val, 4) ||
+        !aligned_to(out_grad, 4))
+        return PVAMD_E_ALIGN;
     hipStream_t s = (hipStream_t)stream;
-    const bool vec_ok = (P % 4 == 0) && aligned_to(points, 16) && aligned_to(out_val, 16) && aligned_to(out_grad, 16);
     // The leaf descriptors live in device memory; whether any of them asks for float64 index arithmetic is not
     // known host-side, so the kernels are built for the general case and test the (wave-uniform) flag per leaf.
     // Two kernels.  The wave-tile kernel (256 points per wave through LDS, per-tile leaf mask, configuration-fastest block
@@ -637,35 +680,37 @@ extern "C" int pvamd_composed_query(const pvamd_grid_t* grids, int32_t S, const 
     // scalar_probe.py, ms, wave-tile | one-point-per-lane): C3 4M random 0.106 | 0.095, C3 Morton-sorted 0.064 | 0.074,
     // C4 200 x 262k random 0.85 | 0.97, sorted 0.60 | 0.82, README-size grids 4.9 | 6.4 and 1.0 | 2.6.  So: a single
     // configuration, or too few tiles to fill the chip (100k points x 8 leaves: 36 -> 17 us), takes the per-lane kernel.
+    // Either kernel takes ANY point count and any 4-byte aligned buffers (round 2 sent P % 4 != 0 -- the reference README's
+    // own M = 15,251 -- to the per-lane kernel: the wave-tile kernel's 16-byte stores wanted aligned (A, P) rows; they do
+    // not: common.h f32x4_u) and the wave-tile kernel finishes the partial last tile itself: one launch per slab.
     // (flags bits 1 and 2, for tools/scalar_probe.py and the tests: force the per-lane / the wave-tile kernel.)
-    const bool enough = vec_ok && ((A >= 2 && (P / kTilePoints) * (int64_t)A >= 4096 && !(flags & 2)) || (flags & 4));
-    const int64_t ntiles = enough ? P / kTilePoints : 0;
+    const int64_t ntiles = (P + kTilePoints - 1) / kTilePoints;
+    const bool wave_tiles = (A >= 2 && ntiles * (int64_t)A >= kWaveTileMinTiles && !(flags & 2)) || (flags & 4);
     // up to ~65536 blocks in total, split over the A configurations: about one 256-point tile per wave.  (Sweep on C4,
     // 200 x 262,144: 1024 blocks 1.40 ms, 4096 1.17, 8192 1.13, 32768 1.09, 65536 1.08 -- the hardware dispatcher
     // balances better than a grid-stride loop over unequal tiles.)
-    // gridDim.y carries the configuration: at most 65535 per launch, so larger batches go out in slabs (the kernels
-    // take the slab's first configuration and index transforms / outputs with the global one)
-    constexpr int kSlab = 65535;
-    for (int a0 = 0; a0 < A; a0 += kSlab) {
-        const int An = A - a0 < kSlab ? A - a0 : kSlab;
+    // The configuration is a grid dimension (blockIdx.x of the wave-tile kernel, blockIdx.y of the per-lane kernel): at
+    // most 65535 per launch, so larger batches go out in slabs (the kernels take the slab's first configuration and
+    // index transforms / outputs with the global one)
+    for (int a0 = 0; a0 < A; a0 += kConfigSlab) {
+        const int An = A - a0 < kConfigSlab ? A - a0 : kConfigSlab;
         int64_t cap = ((int64_t)65536 + An - 1) / An;
         if (cap > 65535) cap = 65535;  // gridDim.y
-        if (ntiles > 0) {
+        if (wave_tiles) {
             const int64_t need = (ntiles + kWavesPerBlock - 1) / kWavesPerBlock;
-            const unsigned gx = (unsigned)(need < cap ? need : (cap < 1 ? 1 : cap));
+            const unsigned gy = (unsigned)(need < cap ? need : (cap < 1 ? 1 : cap));
             if (flags & PVAMD_COMPOSED_INLINE_EXACT)
-                hipLaunchKernelGGL((composed_query_wave<PVAMD_COMPOSED_PPP, kInlineExact, false>), dim3(An, gx), dim3(kWavesPerBlock * 64), 0, s,
-                                   grids, S, tf, A, reinterpret_cast<const f32x4*>(points), ntiles, P, out_val, out_grad, out_leaf, a0);
+                hipLaunchKernelGGL((composed_query_wave<PVAMD_COMPOSED_PPP, kInlineExact, false>), dim3(An, gy), dim3(kWavesPerBlock * 64), 0, s,
+                                   grids, S, tf, A, points, ntiles, P, out_val, out_grad, out_leaf, a0);
             else
-                hipLaunchKernelGGL((composed_query_wave<PVAMD_COMPOSED_PPP, kEstimate, false>), dim3(An, gx), dim3(kWavesPerBlock * 64), 0, s,
-                                   grids, S, tf, A, reinterpret_cast<const f32x4*>(points), ntiles, P, out_val, out_grad, out_leaf, a0);
-        }
-        const int64_t first = ntiles * kTilePoints;
-        if (first < P) {
-            const int64_t need = (P - first + 255) / 256;
+                hipLaunchKernelGGL((composed_query_wave<PVAMD_COMPOSED_PPP, kEstimate, false>), dim3(An, gy), dim3(kWavesPerBlock * 64), 0, s,
+                                   grids, S, tf, A, points, ntiles, P, out_val, out_grad, out_leaf, a0);
+        } else {
+            const int64_t need = (P + 255) / 256;
             const unsigned gx = (unsigned)(need < cap ? need : (cap < 1 ? 1 : cap));
-            hipLaunchKernelGGL(composed_query_scalar, dim3(gx, An), dim3(256), 0, s, grids, S, tf, A, points, first,
-                               P, out_val, out_grad, out_leaf, a0);
+            const int cf = (flags & 8) ? 1 : 0;
+            hipLaunchKernelGGL(composed_query_scalar, cf ? dim3(An, gx) : dim3(gx, An), dim3(256), 0, s, grids, S, tf, A, points,
+                               (int64_t)0, P, out_val, out_grad, out_leaf, a0, cf);
         }
     }
     return (int)hipGetLastError();

@@ -16,17 +16,37 @@ namespace pvamd {
 // written with explicit fmaf / __f*_rn so that the CPU oracle can state the same sequence.
 #define PVAMD_DEV __device__ __forceinline__
 
+// The quotient -> index step under pvamd_grid_t::rule (include/pvamd.h): half-to-even by default; the alternatives sit
+// behind a wave-uniform branch on a kernarg / scalar-loaded field.
+template <typename T>
+PVAMD_DEV T round_by_rule(int rule, T q) {
+    if (__builtin_expect((rule & (PVAMD_RULE_ROUND_HALF_AWAY | PVAMD_RULE_ROUND_FLOOR_HALF)) == 0, 1)) {
+        if constexpr (sizeof(T) == 8) return __builtin_rint(q);
+        else return __builtin_rintf(q);
+    }
+    if (rule & PVAMD_RULE_ROUND_HALF_AWAY) {
+        if constexpr (sizeof(T) == 8) return __builtin_round(q);
+        else return __builtin_roundf(q);
+    }
+    if constexpr (sizeof(T) == 8) return __builtin_floor(q + 0.5);  // the sum rounds in the index dtype (-ffp-contract=off)
+    else return __builtin_floorf(add_rn(q, 0.5f));
+}
+
+// index (as the reference would hold it, int64) and validity of one coordinate.  kq = the rounded quotient as a float:
+// "valid on the index" tests it (0 <= kq <= shape - 1; a NaN / infinite quotient fails), "valid on the value" tests p.
 template <bool F64>
 PVAMD_DEV bool voxel_index_1d(const pvamd_grid_t& g, int d, float p, long long& k) {
     if constexpr (F64) {
         const double pd = (double)p;
-        const bool valid = (g.dmin[d] <= pd) && (pd <= g.dmax[d]);
-        k = (long long)__builtin_rint((pd - g.dmin[d]) / g.dres[d]);
-        return valid;
+        const double kq = round_by_rule<double>(g.rule, (pd - g.dmin[d]) / g.dres[d]);
+        k = (long long)kq;
+        if (__builtin_expect(g.rule & PVAMD_RULE_VALID_ON_INDEX, 0)) return (kq >= 0.0) && (kq <= (double)(g.shape[d] - 1));
+        return (g.dmin[d] <= pd) && (pd <= g.dmax[d]);
     } else {
-        const bool valid = (g.fmin[d] <= p) && (p <= g.fmax[d]);
-        k = (long long)__builtin_rintf(div_rn(sub_rn(p, g.fmin[d]), g.fres[d]));
-        return valid;
+        const float kq = round_by_rule<float>(g.rule, div_rn(sub_rn(p, g.fmin[d]), g.fres[d]));
+        k = (long long)kq;
+        if (__builtin_expect(g.rule & PVAMD_RULE_VALID_ON_INDEX, 0)) return (kq >= 0.f) && (kq <= (float)(g.shape[d] - 1));
+        return (g.fmin[d] <= p) && (p <= g.fmax[d]);
     }
 }
 
@@ -54,8 +74,9 @@ PVAMD_DEV bool voxel_flat(const pvamd_grid_t& g, float x, float y, float z, int&
 }
 
 // ---- fast path used by the query kernels (bit-identical to the exact statements above) ----
-// Range test in fp32: for a float32 p, "min <= p <= max" in the index dtype is equivalent to vlo <= p <= vhi with the
-// bounds rounded inward to float32 by pvamd_grid_finalize().
+// Range test in fp32: the set of valid float32 p is an interval per coordinate whatever the rule (the index statement is
+// monotone in p); pvamd_grid_finalize() finds its float32 end points vlo / vhi -- for the default rule "min <= p <= max"
+// in the index dtype with the bounds rounded inward to float32.
 PVAMD_DEV bool in_range(const pvamd_grid_t& g, float x, float y, float z) {
     return (g.vlo[0] <= x) & (x <= g.vhi[0]) & (g.vlo[1] <= y) & (y <= g.vhi[1]) & (g.vlo[2] <= z) & (z <= g.vhi[2]);
 }

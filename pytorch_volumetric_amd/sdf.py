@@ -443,8 +443,29 @@ class CachedSDF(ObjectFrameSDF):
             centre_val = val[..., 0] if self._dim == 2 else val
             assert torch.allclose(centre_val.reshape(-1).to(q.device, q.dtype)[ok], q[ok])  # voxel centres map to themselves
 
+    _PLAN_ATTRS = frozenset(("device", "out_of_bounds_strategy", "debug_check_sdf", "_packed", "bb"))
+
+    def __setattr__(self, name, value):
+        if name in CachedSDF._PLAN_ATTRS:
+            _lib.EPOCH[0] += 1  # call plans (this object's and those of compositions over it) are rebuilt on next use
+        object.__setattr__(self, name, value)
+
     def surface_bounding_box(self, **kwargs):
         return self.gt_sdf.surface_bounding_box(**kwargs)
+
+    def _fast_plan(self):
+        """What the fast path of __call__ needs, resolved once per configuration epoch: float32 points that already sit
+        contiguous on the grid's GPU, the fused BOUNDING_BOX strategy, results wanted on that same GPU -> one C-ABI call
+        between two allocations.  None when this object cannot take it."""
+        dev = self._packed.device
+        ok = self._dim == 3 and self.out_of_bounds_strategy == OutOfBoundsStrategy.BOUNDING_BOX and \
+            not self.debug_check_sdf and _lib.same_gpu(self.device, dev)
+        plan = None
+        if ok:
+            desc = self._grid_desc()
+            plan = (dev, dev.index, ctypes.byref(desc), _lib.load().pvamd_cached_query, desc)
+        object.__setattr__(self, "_plan", (_lib.EPOCH[0], plan))
+        return plan
 
     def _lift(self, points):
         """planar caches: (..., 2) query points -> (..., 3) with z = 0 (see __init__)"""
@@ -479,6 +500,21 @@ class CachedSDF(ObjectFrameSDF):
 
     def __call__(self, points_in_object_frame):
         """sdf.py:535-591"""
+        p = points_in_object_frame
+        # the common call of a planner's inner loop -- float32 points already contiguous on the grid's GPU -- skips every
+        # conversion below: two allocations in the final shapes and one C-ABI call (~9 us instead of ~18 us of host time per
+        # call; the kernel itself takes 6 us for a million points)
+        cached = self.__dict__.get("_plan")
+        plan = cached[1] if cached is not None and cached[0] == _lib.EPOCH[0] else self._fast_plan()
+        if plan is not None and type(p) is torch.Tensor and p.dtype is torch.float32 and p.device == plan[0] and \
+                p.is_contiguous() and p.dim() >= 1 and p.shape[-1] == 3 and _lib.current_device_index() == plan[1]:
+            val = torch.empty(p.shape[:-1], dtype=torch.float32, device=plan[0])
+            grad = torch.empty(p.shape, dtype=torch.float32, device=plan[0])
+            rc = plan[3](plan[2], p.data_ptr(), val.numel(), val.data_ptr(), grad.data_ptr(), None,
+                         _lib.current_raw_stream(plan[1]))
+            if rc != 0:
+                _lib.check(rc, "pvamd_cached_query")
+            return val, grad
         lib = _lib.load()
         # the launch happens on the GPU that holds the grid, whatever device is current in the calling code
         # float64 points are looked up in float64 (index arithmetic, range test and bounding-box branch all promote to
@@ -565,6 +601,7 @@ class ComposedSDF(ObjectFrameSDF):
         self._tf_dev = None
         self._grids_dev = None
         self._grids_key = None
+        self._plan = None
         self.set_transforms(obj_frame_to_each_frame)
 
     def ith_transform_slice(self, i):
@@ -683,9 +720,60 @@ class ComposedSDF(ObjectFrameSDF):
             self._tf_dev = tf.as_matrix(self.obj_frame_to_link_frame).to(device=dev, dtype=torch.float32).contiguous()
         return self._tf_dev
 
+    def _call_plan(self):
+        """What the fast path of __call__ needs about the LEAVES (not the transforms: a planner sets those before every
+        query), resolved once per (configuration epoch, leaf list): every leaf a BOUNDING_BOX CachedSDF on one GPU, the
+        descriptor array there, results wanted on that GPU.  None when the composition cannot take the fast path."""
+        sdfs = self.sdfs
+        key = (_lib.EPOCH[0], *map(id, sdfs))
+        cached = self._plan
+        if cached is not None and cached[0] == key:
+            return cached[1]
+        plan = None
+        if len(sdfs) > 0 and all(isinstance(s, CachedSDF) and s._dim == 3 and
+                                 s.out_of_bounds_strategy == OutOfBoundsStrategy.BOUNDING_BOX for s in sdfs):
+            devs = {s._packed.device for s in sdfs}
+            if len(devs) == 1:
+                dev = next(iter(devs))
+                with _lib.on_device(dev):
+                    grids = self._leaf_grids(dev)
+                if _lib.same_gpu(sdfs[0].device, dev):
+                    plan = (dev, dev.index, grids.data_ptr(), len(sdfs), _lib.load().pvamd_composed_query, grids)
+        self._plan = (key, plan)
+        return plan
+
     def __call__(self, points_in_object_frame):
         """sdf.py:392-433.  Returns (A..., B..., N) / (A..., B..., N, 3) with a transform batch, and -- like the
         reference -- FLAT (P,) / (P, 3) without one."""
+        p = points_in_object_frame
+        plan = self._call_plan()
+        # float32 points already contiguous on the leaves' GPU, fused leaves, rigid transforms, no sort wanted: two
+        # allocations in the final shapes around one C-ABI call (RobotSDF.__call__ in a planner's loop)
+        if plan is not None and type(p) is torch.Tensor and p.dtype is torch.float32 and p.device == plan[0] and \
+                p.is_contiguous() and p.dim() >= 1 and p.shape[-1] == 3 and self._rigid and \
+                self.obj_frame_to_link_frame is not None and _lib.current_device_index() == plan[1]:
+            P = p.numel() // 3
+            batch = self.tsf_batch
+            A = math.prod(batch) if batch is not None else 1
+            bp = self.bucket_points
+            flags = self._query_flags
+            sort = (flags & 1 and A >= 8 and P >= 32768 and A * P * 16 <= (8 << 30)) if bp == "auto" else (bool(bp) and P >= 256)
+            if P > 0 and not sort:
+                dev = plan[0]
+                tfd = self._tf_dev
+                if tfd is None or tfd.device != dev:
+                    tfd = self._tf_device(dev)
+                if batch is not None:
+                    val = torch.empty((*batch, *p.shape[:-1]), dtype=torch.float32, device=dev)
+                    grad = torch.empty((*batch, *p.shape), dtype=torch.float32, device=dev)
+                else:
+                    val = torch.empty((P,), dtype=torch.float32, device=dev)
+                    grad = torch.empty((P, 3), dtype=torch.float32, device=dev)
+                rc = plan[4](plan[2], plan[3], tfd.data_ptr(), A, p.data_ptr(), P, val.data_ptr(), grad.data_ptr(), None,
+                             flags, _lib.current_raw_stream(plan[1]))
+                if rc != 0:
+                    _lib.check(rc, "pvamd_composed_query")
+                return val, grad
         S = len(self.sdfs)
         A = math.prod(self.tsf_batch) if self.tsf_batch is not None else 1
         if not torch.is_tensor(points_in_object_frame):

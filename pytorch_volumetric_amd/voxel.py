@@ -33,6 +33,16 @@ def get_coordinates_and_points_in_grid(resolution, range_per_dim, dtype=torch.fl
     return coords, pts
 
 
+# Which of the UNPINNED choices of multidim_indexing's value-range view the kernels restate (include/pvamd.h
+# PVAMD_RULE_*, _lib.RULE_*): 0 = index by round-half-to-even, a point is valid when min <= p <= max.  Nothing in the
+# reference pins these (the package is an un-vendored dependency, call sites sdf.py:521,537-540); should the real
+# package turn out to test validity on the rounded index, round halves away from zero / as floor(q + 0.5), or evaluate
+# a float32 range's resolution in float64, set this (before building caches) instead of touching a kernel:
+#   import pytorch_volumetric_amd as pv; pv.voxel.INDEX_RULE = pv.RULE_VALID_ON_INDEX | pv.RULE_ROUND_HALF_AWAY
+# tools/rule_exposure.py measures how many results each alternative changes (profiles/r03_rule_exposure.txt).
+INDEX_RULE = 0
+
+
 class RangeView:
     """The numbers a value-range view of a dense grid needs: min, max, resolution per dim, in the dtype torch would
     give them.
@@ -45,7 +55,8 @@ class RangeView:
     can do the index arithmetic in the same dtype (pvamd_grid_t.index_f64).
     """
 
-    def __init__(self, range_per_dim, shape):
+    def __init__(self, range_per_dim, shape, rule=None):
+        self.rule = INDEX_RULE if rule is None else int(rule)
         lows = [b[0] for b in range_per_dim]
         highs = [b[1] for b in range_per_dim]
         vmin = torch.tensor(lows)
@@ -59,6 +70,8 @@ class RangeView:
         cells = torch.tensor(self.shape) - 1
         self.min, self.max = vmin, vmax
         self.resolution = (vmax - vmin) / cells
+        if (self.rule & _lib.RULE_RES_F64) and not self.index_f64:
+            self.resolution = ((vmax.double() - vmin.double()) / cells).float()
         # both triples are always available to the kernels
         self.dmin, self.dmax = vmin.double(), vmax.double()
         self.dres = self.resolution.double() if not self.index_f64 else self.resolution
@@ -71,6 +84,7 @@ class RangeView:
             desc.fmin[d], desc.fmax[d], desc.fres[d] = self.fmin[d].item(), self.fmax[d].item(), self.fres[d].item()
             desc.shape[d] = self.shape[d]
         desc.index_f64 = 1 if self.index_f64 else 0
+        desc.rule = self.rule
 
 
 def bounds_contain_another_bounds(outer_bounds, inner_bounds):

@@ -32,6 +32,8 @@ class ValueRangeView:
         self.invalid_value = invalid_value
         self._ranges = [(b[0], b[1]) for b in value_ranges]
         self._desc = None
+        from pytorch_volumetric_amd import voxel
+        self._rule = voxel.INDEX_RULE  # the view's unpinned choices (voxel.INDEX_RULE), as of construction
 
     # ---- HIP path: 3-D float32 / bool storage on the GPU, float32 points ----
     def _device_path(self, pts):
@@ -42,7 +44,7 @@ class ValueRangeView:
     def _grid_desc(self):
         if self._desc is None:
             desc = _lib.GridDesc()
-            RangeView(self._ranges, self.shape).fill(desc)  # same dtype inference as the torch tensors above
+            RangeView(self._ranges, self.shape, rule=self._rule).fill(desc)  # same dtype inference as the torch tensors above
             desc.oob_mode = _lib.OOB_BOUNDING_BOX
             _lib.check(_lib.load().pvamd_grid_finalize(ctypes.byref(desc)), "pvamd_grid_finalize")
             self._desc = desc
@@ -86,8 +88,16 @@ class ValueRangeView:
                           int(bool(scalar)) if as_bytes else float(scalar), P, _lib.ptr(owner), _lib.stream_ptr()),
                        "pvamd_voxel_scatter")
 
+    def _rounded(self, key):
+        q = (key - self._min) / self._resolution
+        if self._rule & _lib.RULE_ROUND_HALF_AWAY:
+            return torch.sign(q) * torch.floor(torch.abs(q) + 0.5)
+        if self._rule & _lib.RULE_ROUND_FLOOR_HALF:
+            return torch.floor(q + 0.5)
+        return torch.round(q)
+
     def ensure_index_key(self, key):
-        return torch.round((key - self._min) / self._resolution).to(torch.long)
+        return self._rounded(key).to(torch.long)
 
     def ensure_value_key(self, index):
         return index.to(self._resolution.dtype) * self._resolution + self._min
@@ -99,6 +109,9 @@ class ValueRangeView:
         return flat
 
     def get_valid_values(self, key):
+        if self._rule & _lib.RULE_VALID_ON_INDEX:
+            k = self._rounded(key)
+            return ((k >= 0) & (k <= self._extent - 1)).all(dim=-1)
         return ((key >= self._min) & (key <= self._max)).all(dim=-1)
 
     def _flat(self, pts):

@@ -69,7 +69,7 @@ def oracle_grid_from_cached(cached, oob_mode=None):
     bb = cached.bb.cpu().numpy()
     if oob_mode is None:
         oob_mode = 1 if cached.out_of_bounds_strategy.value == 1 else 0
-    return oracle.Grid(val, grad, rmin, rmax, bb, oob_mode=oob_mode, index_f64=view.index_f64)
+    return oracle.Grid(val, grad, rmin, rmax, bb, oob_mode=oob_mode, index_f64=view.index_f64, rule=view.rule)
 
 
 def oracle_mesh_from_factory(obj):

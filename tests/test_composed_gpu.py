@@ -267,3 +267,74 @@ def test_non_rigid_transforms_take_the_general_path_and_stay_consistent():
     assert torch.allclose(grad[ok].nan_to_num(0.0), g_expect[ok].nan_to_num(0.0), atol=1e-4) and ok.float().mean() > 0.95
     rigid = pv.ComposedSDF([leaf, leaf], H.random_rigid(2, seed=4, trans=0.1))
     assert rigid._rigid is True and rigid._fusable()
+
+
+def _force_flags(comp, flags):
+    comp._leaf_grids(torch.device("cuda", torch.cuda.current_device()))
+    comp._query_flags = flags
+
+
+@pytest.mark.parametrize("A,P,flags", [(200, 15_251, 0), (20, 15_251, 4), (20, 15_251, 0), (24, 20_481, 4 | 1), (5, 255, 4),
+                                       (5, 257, 4), (3, 3, 4), (7, 513, 4), (2, 1, 4)])
+def test_any_point_count_goes_through_the_wave_tile_kernel_bitwise(A, P, flags):
+    """The reference README's own query has M = 15,251 points (README.md:177-200): (A, P) rows that start at any dword,
+    and a last tile of 147 points.  The wave-tile kernel takes them itself (16-byte stores at 4-byte aligned addresses,
+    partial last tile in the kernel); round 2 sent every P % 4 != 0 to the one-point-per-lane kernel.  flags 4 forces the
+    wave-tile kernel for the small cases; (200, 15251) and (20, 15251) take whatever the entry point picks."""
+    S = 8
+    leaves = [make_leaf(f64=(s % 2 == 0)) for s in range(S)]
+    tfm = H.random_rigid(S * A, seed=A + P, trans=0.3)
+    comp = pv.ComposedSDF(leaves, None)
+    comp.set_transforms(pv.Transform3d(matrix=tfm), batch_dim=(A,))
+    if flags:
+        _force_flags(comp, flags)
+    pts = scene_points(P, seed=P, extent=0.6)
+    val, grad = comp(pts.cuda())
+    assert val.shape == (A, P) and grad.shape == (A, P, 3)
+    oval, ograd, _ = oracle.composed_query([H.oracle_grid_from_cached(l) for l in leaves], tfm.numpy(), A, pts.numpy())
+    assert np.array_equal(val.cpu().numpy(), oval, equal_nan=True)
+    assert np.array_equal(grad.cpu().numpy(), ograd, equal_nan=True)
+
+
+@pytest.mark.parametrize("flags", [4, 2])
+def test_buffers_at_any_dword_address(flags):
+    """points / out_val / out_grad that are only 4-byte aligned (views into larger buffers), odd P, both kernels; the
+    floats around the outputs must stay untouched."""
+    S, A, P = 4, 6, 1000 + 3
+    leaves = [make_leaf() for _ in range(S)]
+    tfm = H.random_rigid(S * A, seed=3, trans=0.2)
+    comp = pv.ComposedSDF(leaves, None)
+    comp.set_transforms(pv.Transform3d(matrix=tfm), batch_dim=(A,))
+    _force_flags(comp, flags)
+    pts = scene_points(P, seed=1, extent=0.4)
+    pbuf = torch.zeros(3 * P + 8, device="cuda")
+    pbuf[1:1 + 3 * P] = pts.reshape(-1).cuda()
+    pview = pbuf[1:1 + 3 * P].view(P, 3)
+    vbuf = torch.full((A * P + 8,), -7.0, device="cuda")
+    gbuf = torch.full((3 * A * P + 8,), -7.0, device="cuda")
+    vview, gview = vbuf[3:3 + A * P].view(A, P), gbuf[1:1 + 3 * A * P].view(A, P, 3)
+    assert pview.data_ptr() % 16 == 4 and vview.data_ptr() % 16 == 12 and gview.data_ptr() % 16 == 4
+    comp.query_into(pview, vview, gview)
+    oval, ograd, _ = oracle.composed_query([H.oracle_grid_from_cached(l) for l in leaves], tfm.numpy(), A, pts.numpy())
+    assert np.array_equal(vview.cpu().numpy(), oval, equal_nan=True)
+    assert np.array_equal(gview.cpu().numpy(), ograd, equal_nan=True)
+    assert (vbuf[:3] == -7).all() and (vbuf[3 + A * P:] == -7).all() and (gbuf[:1] == -7).all() and (gbuf[1 + 3 * A * P:] == -7).all()
+
+
+@pytest.mark.parametrize("flags", [0, 2])
+def test_seventy_thousand_configurations_go_out_in_slabs(flags):
+    """pvamd_composed_query carries the configuration in a grid dimension (<= 65535): A = 70,000 x P = 8 crosses the slab
+    border in both kernels (the wave-tile kernel with a last -- and only -- tile of 8 points); the reference takes any
+    batch (sdf.py:370-383)."""
+    S, A, P = 2, 70_000, 8
+    leaves = [make_leaf(res=0.02) for _ in range(S)]
+    tfm = H.random_rigid(S * A, seed=6, trans=0.3)
+    comp = pv.ComposedSDF(leaves, None)
+    comp.set_transforms(pv.Transform3d(matrix=tfm), batch_dim=(A,))
+    if flags:
+        _force_flags(comp, flags)
+    pts = scene_points(P, seed=2, extent=0.4)
+    val, grad = comp(pts.cuda())
+    oval, ograd, _ = oracle.composed_query([H.oracle_grid_from_cached(l) for l in leaves], tfm.numpy(), A, pts.numpy())
+    assert np.array_equal(val.cpu().numpy(), oval, equal_nan=True)
+    assert np.array_equal(grad.cpu().numpy(), ograd, equal_nan=True)
