@@ -248,7 +248,8 @@ void oracle_cached_outside_f64(const oracle_grid_t* g, const double* pts, int64_
         for (int d = 0; d < 3; ++d) valid &= index_1d_f64(g, d, pts[3 * i + d], &k[d]);
         if (valid) {
             const int64_t flat = (k[0] * g->shape[1] + k[1]) * g->shape[2] + k[2];
-            out[i] = (uint8_t)((double)g->val[flat] > level);
+            /* sdf.py:601 raw_data[flat] > surface_level: a float32 tensor against a python scalar compares in float32 */
+            out[i] = (uint8_t)(g->val[flat] > (float)level);
         } else {
             out[i] = 1;
         }

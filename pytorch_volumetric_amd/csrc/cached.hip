@@ -17,10 +17,10 @@ namespace pvamd {
 //   1  4*lane .. 4*lane+3: the lane's 12 input floats are three ds_read_b128 at a 48-byte lane stride (conflict-free per
 //      16 lanes), its four values are ONE 16-byte global store (no LDS), its 12 gradient floats three ds_write_b128:
 //      12 LDS instructions per tile instead of 35
-// Any point count and any 4-byte aligned buffers: the 16-byte accesses take dword addresses (common.h f32x4_u), the last
-// tile may hold fewer than 256 points (its loads are clamped to the array, its stores are per-dword and guarded).
+// Any point count >= 256 and any 4-byte aligned buffers: the 16-byte accesses take dword addresses (common.h f32x4_u); a
+// ragged end is covered by moving the last tile back so that it ends at the last point.
 #ifndef PVAMD_CQ_WAVES
-#define PVAMD_CQ_WAVES 4
+#define PVAMD_CQ_WAVES 8
 #endif
 #ifndef PVAMD_CQ_OWN4
 #define PVAMD_CQ_OWN4 1
@@ -53,9 +53,12 @@ __global__ __launch_bounds__(kWavesPerBlock * 64, PVAMD_CQ_MINWAVES) void cached
     const int64_t ntiles = (P + kTilePoints - 1) / kTilePoints;
     const int64_t wstride = (int64_t)gridDim.x * kWavesPerBlock;
     int64_t tile = (int64_t)blockIdx.x * kWavesPerBlock + wave;
+    // any P >= 256: the LAST tile is moved back to end at the last point (it overlaps its neighbour; the overlap is
+    // computed and written twice with the same bits), so every tile is whole and there is no partial-tile path
+    auto first_point = [&](int64_t t) { return t * kTilePoints <= P - kTilePoints ? t * kTilePoints : P - kTilePoints; };
     f32x4 a, b, c;
-    auto load3 = [&](int64_t t) {  // a whole tile: three contiguous KB
-        const f32x4_u* src = reinterpret_cast<const f32x4_u*>(pts + t * 768);
+    auto load3 = [&](int64_t t) {  // three contiguous KB
+        const f32x4_u* src = reinterpret_cast<const f32x4_u*>(pts + 3 * first_point(t));
         if (LD_NT) {
             a = __builtin_nontemporal_load(src + lane);
             b = __builtin_nontemporal_load(src + lane + 64);
@@ -66,25 +69,16 @@ __global__ __launch_bounds__(kWavesPerBlock * 64, PVAMD_CQ_MINWAVES) void cached
             c = src[lane + 128];
         }
     };
-    auto whole = [&](int64_t t) { return P - t * kTilePoints >= kTilePoints; };
-    if (tile < ntiles && whole(tile)) load3(tile);
+    if (tile < ntiles) load3(tile);
     for (; tile < ntiles; tile += wstride) {
-        if (__builtin_expect(whole(tile), 1)) {
-            sp[lane] = a;
-            sp[lane + 64] = b;
-            sp[lane + 128] = c;
-        } else {  // the last, partial tile (rare; kept small): straight into LDS, slots past the end repeat the last float
-            const int last = 3 * (int)(P - tile * kTilePoints) - 1;
-#pragma unroll 1
-            for (int i = lane; i < 768; i += 64) spf[i] = pts[tile * 768 + (i < last ? i : last)];
-        }
+        sp[lane] = a;
+        sp[lane + 64] = b;
+        sp[lane + 128] = c;
         // software prefetch: the next tile's HBM loads are in flight while this tile is looked up (the wave fences
         // below stop the compiler from doing this itself); 0.47 -> 0.42 ms per 64M points (profiles/r01_kbench.txt)
         const int64_t next = tile + wstride;
-        if (next < ntiles && whole(next)) load3(next);
+        if (next < ntiles) load3(next);
         PVAMD_WAVE_SYNC();
-        const int64_t left = P - tile * kTilePoints;
-        const int nvalid = left < kTilePoints ? (int)left : kTilePoints;
         float px[4], py[4], pz[4];
         if constexpr (kOwn4) {
             const f32x4 q0 = sp[3 * lane], q1 = sp[3 * lane + 1], q2 = sp[3 * lane + 2];
@@ -102,8 +96,7 @@ __global__ __launch_bounds__(kWavesPerBlock * 64, PVAMD_CQ_MINWAVES) void cached
             }
         }
         PVAMD_WAVE_SYNC();
-        const int64_t o = tile * kTilePoints;
-        const bool full = nvalid == kTilePoints;
+        const int64_t o = first_point(tile);
         f32x4 v4;
         if constexpr (kOwn4) {
             float4 r[4];
@@ -115,19 +108,8 @@ __global__ __launch_bounds__(kWavesPerBlock * 64, PVAMD_CQ_MINWAVES) void cached
             sp[3 * lane + 2] = f32x4{r[2].w, r[3].y, r[3].z, r[3].w};
             v4 = f32x4{r[0].x, r[1].x, r[2].x, r[3].x};
             if constexpr (WRITE_OOB) {
-                if (__builtin_expect(full, 1)) {
-                    const uint32_t m = (valid[0] ? 0u : 1u) | (valid[1] ? 0u : 1u << 8) | (valid[2] ? 0u : 1u << 16) | (valid[3] ? 0u : 1u << 24);
-                    __builtin_memcpy(oob + o + 4 * lane, &m, 4);  // the 4 consecutive flags of this lane
-                } else {
-#pragma unroll 1
-                    for (int k = 0; k < 4; ++k)
-                        if (4 * lane + k < nvalid) oob[o + 4 * lane + k] = valid[k] ? 0 : 1;
-                }
-            }
-            if (__builtin_expect(!full, 0)) {
-#pragma unroll
-                for (int k = 0; k < 4; ++k)
-                    if (4 * lane + k < nvalid) val[o + 4 * lane + k] = r[k].x;
+                const uint32_t m = (valid[0] ? 0u : 1u) | (valid[1] ? 0u : 1u << 8) | (valid[2] ? 0u : 1u << 16) | (valid[3] ? 0u : 1u << 24);
+                __builtin_memcpy(oob + o + 4 * lane, &m, 4);  // the 4 consecutive flags of this lane
             }
         } else {
 #pragma unroll
@@ -139,34 +121,23 @@ __global__ __launch_bounds__(kWavesPerBlock * 64, PVAMD_CQ_MINWAVES) void cached
                 spf[3 * p] = r.y;
                 spf[3 * p + 1] = r.z;
                 spf[3 * p + 2] = r.w;
-                if constexpr (WRITE_OOB) {
-                    if (p < nvalid) oob[o + p] = valid ? 0 : 1;
-                }
+                if constexpr (WRITE_OOB) oob[o + p] = valid ? 0 : 1;
             }
         }
         PVAMD_WAVE_SYNC();
-        if (__builtin_expect(full, 1)) {
-            f32x4_u* vdst = reinterpret_cast<f32x4_u*>(val + o);
-            f32x4_u* dst = reinterpret_cast<f32x4_u*>(grad + 3 * o);
-            if constexpr (!kOwn4) v4 = sp[192 + lane];
-            if (ST_NT) {
-                __builtin_nontemporal_store(v4, vdst + lane);
-                __builtin_nontemporal_store(sp[lane], dst + lane);
-                __builtin_nontemporal_store(sp[lane + 64], dst + lane + 64);
-                __builtin_nontemporal_store(sp[lane + 128], dst + lane + 128);
-            } else {
-                vdst[lane] = v4;
-                dst[lane] = sp[lane];
-                dst[lane + 64] = sp[lane + 64];
-                dst[lane + 128] = sp[lane + 128];
-            }
+        f32x4_u* vdst = reinterpret_cast<f32x4_u*>(val + o);
+        f32x4_u* dst = reinterpret_cast<f32x4_u*>(grad + 3 * o);
+        if constexpr (!kOwn4) v4 = sp[192 + lane];
+        if (ST_NT) {
+            __builtin_nontemporal_store(v4, vdst + lane);
+            __builtin_nontemporal_store(sp[lane], dst + lane);
+            __builtin_nontemporal_store(sp[lane + 64], dst + lane + 64);
+            __builtin_nontemporal_store(sp[lane + 128], dst + lane + 128);
         } else {
-            if constexpr (!kOwn4) {
-#pragma unroll 1
-                for (int i = lane; i < nvalid; i += 64) val[o + i] = svf[i];
-            }
-#pragma unroll 1
-            for (int i = lane; i < 3 * nvalid; i += 64) grad[3 * o + i] = spf[i];
+            vdst[lane] = v4;
+            dst[lane] = sp[lane];
+            dst[lane + 64] = sp[lane + 64];
+            dst[lane + 128] = sp[lane + 128];
         }
         PVAMD_WAVE_SYNC();
     }
@@ -284,7 +255,9 @@ __global__ __launch_bounds__(256) void cached_outside_f64_kernel(const pvamd_gri
         const double p[3] = {pts[3 * i], pts[3 * i + 1], pts[3 * i + 2]};
         long long key[3];
         const bool valid = voxel_key_f64(g, p, key);
-        out[i] = valid ? (uint8_t)((double)g.vox[4 * (int64_t)clamped_flat(g, key)] > level) : (uint8_t)1;
+        // sdf.py:601: the float32 cache against a python scalar -- the scalar does not promote the tensor, so the comparison
+        // is a float32 one whatever the dtype of the query points
+        out[i] = valid ? (uint8_t)(g.vox[4 * (int64_t)clamped_flat(g, key)] > (float)level) : (uint8_t)1;
     }
 }
 
@@ -343,8 +316,12 @@ extern "C" int pvamd_cached_query(const pvamd_grid_t* grid, const float* points,
     if (P >= kWaveTileMinPoints) {
         const int64_t ntiles = (P + kTilePoints - 1) / kTilePoints;
         const int64_t need = (ntiles + kWavesPerBlock - 1) / kWavesPerBlock;
+// The streaming regime (> 8M points, far beyond the 256 MB Infinity Cache), round 3 (tools/cq_sweep.py over build
+// variants, profiles/r03_cq_variants.txt; 64M points, 52 % out of range): one tile per wave instead of a capped grid with a
+// grid-stride loop 431 -> 413 us, 8 waves per workgroup 369-374, non-temporal stores as well 361 us (5.2 TB/s); 16 waves
+// 363; plain loads 382.  What bounds it is in profiles/r03_cq64_counters.md: the L1 (TCP) -> L2 request path, not HBM.
 #ifndef PVAMD_CQ_BIG_ST_NT
-#define PVAMD_CQ_BIG_ST_NT false
+#define PVAMD_CQ_BIG_ST_NT true
 #endif
 #ifndef PVAMD_CQ_BIG_LD_NT
 #define PVAMD_CQ_BIG_LD_NT true
@@ -353,7 +330,7 @@ extern "C" int pvamd_cached_query(const pvamd_grid_t* grid, const float* points,
 #define PVAMD_CQ_BLOCKS 1024
 #endif
 #ifndef PVAMD_CQ_BIG_BLOCKS
-#define PVAMD_CQ_BIG_BLOCKS PVAMD_CQ_BLOCKS
+#define PVAMD_CQ_BIG_BLOCKS 0
 #endif
         const bool big = P > ((int64_t)8 << 20);  // > 8M points (96 MB of xyz): streaming regime
         const int64_t cap = big ? PVAMD_CQ_BIG_BLOCKS : PVAMD_CQ_BLOCKS;  // 0: one tile per wave, no grid-stride loop

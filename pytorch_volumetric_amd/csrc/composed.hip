@@ -246,9 +246,12 @@ constexpr int kTilePoints = 256;
 #define PVAMD_COMPOSED_SLAB 65535
 #endif
 constexpr int kConfigSlab = PVAMD_COMPOSED_SLAB;
-// fewer (tile, configuration) pairs than this: the one-point-per-lane kernel (4x the parallelism)
+// fewer (tile, configuration) pairs than this: the one-point-per-lane kernel.  A tile is one wave's work and the chip
+// holds 6,144-8,192 waves: below ~4 rounds of them the last, partly filled round costs more than the tile machinery saves
+// (README case, 200 x 15,251 points = 12,000 tiles: per-lane 0.076 / 0.061 ms on 21 MB / 100 KB link grids against 0.104 /
+// 0.088 ms; C4's 204,800 tiles: wave-tile 0.89 against 0.95 ms; tools/readme_case.py, profiles/r03_readme_case.txt)
 #ifndef PVAMD_COMPOSED_WAVE_MIN_TILES
-#define PVAMD_COMPOSED_WAVE_MIN_TILES 4096
+#define PVAMD_COMPOSED_WAVE_MIN_TILES 32768
 #endif
 constexpr int64_t kWaveTileMinTiles = PVAMD_COMPOSED_WAVE_MIN_TILES;
 #ifndef PVAMD_COMPOSED_PPP
@@ -260,13 +263,18 @@ constexpr int64_t kWaveTileMinTiles = PVAMD_COMPOSED_WAVE_MIN_TILES;
 #ifndef PVAMD_COMPOSED_MINWAVES
 #define PVAMD_COMPOSED_MINWAVES 8
 #endif
+// the inline-exact build: 6 = what the allocator chose on its own (78-80 VGPRs) until the switchable index rules added
+// statements to the exact path (89); held there
+#ifndef PVAMD_COMPOSED_MINWAVES_INLINE
+#define PVAMD_COMPOSED_MINWAVES_INLINE 6
+#endif
 
 // The leaf loop of one tile: PPP points per lane at a time, results into the wave's LDS slice (or packed, to memory).
 // MASKED = false: the tile was not worth a leaf mask (every leaf is visited; no bit tests, no refinement).
 template <int PPP, int MODE, bool PACKED, bool MASKED>
 PVAMD_DEV void tile_passes(const pvamd_grid_t* __restrict__ grids, int S, const float* __restrict__ tf, int A, int a,
-                           int64_t tile, int64_t P, float* __restrict__ val, int* __restrict__ leaf, float* spf, int lane,
-                           uint64_t todo, float lower, int nvalid) {
+                           int64_t first, int64_t P, float* __restrict__ val, int* __restrict__ leaf, float* spf, int lane,
+                           uint64_t todo, float lower) {
     float* svf = spf + 768;
     const int first_leaf = todo ? __builtin_ctzll(todo) : 0;
     // A tile compact enough for the static test to drop a leaf is worth re-testing as the minimum tightens: after
@@ -336,20 +344,20 @@ PVAMD_DEV void tile_passes(const pvamd_grid_t* __restrict__ grids, int S, const 
                 // one (val, gx, gy, gz) record per point, in processing order: lanes hold consecutive points, so the
                 // wave's store is a contiguous 1 KB as it is; plain stores -- the un-permute pass reads them back
                 // from L2 / Infinity Cache right away
-                reinterpret_cast<f32x4*>(val)[(int64_t)a * P + tile * kTilePoints + p] = f32x4{best[k].v, gx, gy, gz};
+                reinterpret_cast<f32x4*>(val)[(int64_t)a * P + first + p] = f32x4{best[k].v, gx, gy, gz};
             } else {
                 svf[p] = best[k].v;  // a lane overwrites only the LDS slots of the points it owns
                 spf[3 * p] = gx;
                 spf[3 * p + 1] = gy;
                 spf[3 * p + 2] = gz;
             }
-            if (leaf && p < nvalid) leaf[(int64_t)a * P + tile * kTilePoints + p] = s_win;
+            if (leaf) leaf[(int64_t)a * P + first + p] = s_win;
         }
     }
 }
 
 template <int PPP, int MODE, bool PACKED>
-__global__ __launch_bounds__(kWavesPerBlock * 64, MODE == kEstimate ? PVAMD_COMPOSED_MINWAVES : 1) void composed_query_wave(const pvamd_grid_t* __restrict__ grids, int S,
+__global__ __launch_bounds__(kWavesPerBlock * 64, MODE == kEstimate ? PVAMD_COMPOSED_MINWAVES : PVAMD_COMPOSED_MINWAVES_INLINE) void composed_query_wave(const pvamd_grid_t* __restrict__ grids, int S,
                                                                            const float* __restrict__ tf, int A,
                                                                            const float* __restrict__ pts,
                                                                            int64_t ntiles, int64_t P,
@@ -383,23 +391,14 @@ __global__ __launch_bounds__(kWavesPerBlock * 64, MODE == kEstimate ? PVAMD_COMP
     const float span2 = (kMaskSpan * scene) * (kMaskSpan * scene);
     const int64_t wstride = (int64_t)gridDim.y * kWavesPerBlock;
     for (int64_t tile = (int64_t)blockIdx.y * kWavesPerBlock + wave; tile < ntiles; tile += wstride) {
-        // P is any count: the last tile may hold fewer than 256 points (nvalid); its empty slots carry copies of the
-        // last point, so that the tile's bounds stay tight and no lane computes on garbage (no result is written for them)
-        const int64_t left = P - tile * kTilePoints;
-        const int nvalid = left < kTilePoints ? (int)left : kTilePoints;
-        if (__builtin_expect(nvalid == kTilePoints, 1)) {
-            // re-read for every configuration: L2-resident.  The array is only known to be 4-byte aligned.
-            const f32x4_u* src = reinterpret_cast<const f32x4_u*>(pts + tile * 768);
-            sp[lane] = src[lane];
-            sp[lane + 64] = src[lane + 64];
-            sp[lane + 128] = src[lane + 128];
-        } else {
-#pragma unroll
-            for (int k = 0; k < 12; ++k) {
-                const int i = lane + 64 * k, p = i / 3;
-                spf[i] = pts[tile * 768 + (p < nvalid ? i : i - 3 * (p - (nvalid - 1)))];
-            }
-        }
+        // P is any count >= 256: the LAST tile is moved back to end at the last point, overlapping its neighbour, so that
+        // every tile is whole (the overlap is computed twice and written twice with the same bits -- cheaper than a
+        // partial-tile path, whose registers every tile would pay for).  The array is only known to be 4-byte aligned.
+        const int64_t first = tile * kTilePoints <= P - kTilePoints ? tile * kTilePoints : P - kTilePoints;
+        const f32x4_u* src = reinterpret_cast<const f32x4_u*>(pts + 3 * first);  // re-read for every configuration: L2-resident
+        sp[lane] = src[lane];
+        sp[lane + 64] = src[lane + 64];
+        sp[lane + 128] = src[lane + 128];
         PVAMD_WAVE_SYNC();
         float lower;
 #ifdef PVAMD_NO_TILE_MASK
@@ -423,30 +422,17 @@ __global__ __launch_bounds__(kWavesPerBlock * 64, MODE == kEstimate ? PVAMD_COMP
         // two copies of the leaf loop only where instructions are what binds (kEstimate: grids that live in L2); the
         // gather-bound kInlineExact build loses more to the larger body than the simpler loop gives (README-size robot,
         // sorted points: 1.00 -> 1.10 ms with both copies)
-        if (MODE != kEstimate || masked) tile_passes<PPP, MODE, PACKED, true>(grids, S, tf, A, a, tile, P, val, leaf, spf, lane, todo, lower, nvalid);
-        else tile_passes<PPP, MODE, PACKED, false>(grids, S, tf, A, a, tile, P, val, leaf, spf, lane, todo, lower, nvalid);
+        if (MODE != kEstimate || masked) tile_passes<PPP, MODE, PACKED, true>(grids, S, tf, A, a, first, P, val, leaf, spf, lane, todo, lower);
+        else tile_passes<PPP, MODE, PACKED, false>(grids, S, tf, A, a, first, P, val, leaf, spf, lane, todo, lower);
         PVAMD_WAVE_SYNC();
         if constexpr (PACKED) continue;
         // row a starts at a * P floats: 16-byte aligned only when P % 4 == 0 -- the stores take any dword address
-        const int64_t o = (int64_t)a * P + tile * kTilePoints;
-        if (__builtin_expect(nvalid == kTilePoints, 1)) {
-            __builtin_nontemporal_store(sp[192 + lane], reinterpret_cast<f32x4_u*>(val + o) + lane);
-            f32x4_u* dst = reinterpret_cast<f32x4_u*>(grad + 3 * o);
-            __builtin_nontemporal_store(sp[lane], dst + lane);
-            __builtin_nontemporal_store(sp[lane + 64], dst + lane + 64);
-            __builtin_nontemporal_store(sp[lane + 128], dst + lane + 128);
-        } else {
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const int i = lane + 64 * k;
-                if (i < nvalid) __builtin_nontemporal_store(spf[768 + i], val + o + i);
-            }
-#pragma unroll
-            for (int k = 0; k < 12; ++k) {
-                const int i = lane + 64 * k;
-                if (i < 3 * nvalid) __builtin_nontemporal_store(spf[i], grad + 3 * o + i);
-            }
-        }
+        const int64_t o = (int64_t)a * P + first;
+        __builtin_nontemporal_store(sp[192 + lane], reinterpret_cast<f32x4_u*>(val + o) + lane);
+        f32x4_u* dst = reinterpret_cast<f32x4_u*>(grad + 3 * o);
+        __builtin_nontemporal_store(sp[lane], dst + lane);
+        __builtin_nontemporal_store(sp[lane + 64], dst + lane + 64);
+        __builtin_nontemporal_store(sp[lane + 128], dst + lane + 128);
         PVAMD_WAVE_SYNC();
     }
 }
@@ -682,10 +668,11 @@ extern "C" int pvamd_composed_query(const pvamd_grid_t* grids, int32_t S, const 
     // configuration, or too few tiles to fill the chip (100k points x 8 leaves: 36 -> 17 us), takes the per-lane kernel.
     // Either kernel takes ANY point count and any 4-byte aligned buffers (round 2 sent P % 4 != 0 -- the reference README's
     // own M = 15,251 -- to the per-lane kernel: the wave-tile kernel's 16-byte stores wanted aligned (A, P) rows; they do
-    // not: common.h f32x4_u) and the wave-tile kernel finishes the partial last tile itself: one launch per slab.
+    // not: common.h f32x4_u) and the wave-tile kernel covers a ragged end with a last tile moved back to end at point P - 1:
+    // one launch per slab (fewer than 256 points always take the per-lane kernel).
     // (flags bits 1 and 2, for tools/scalar_probe.py and the tests: force the per-lane / the wave-tile kernel.)
     const int64_t ntiles = (P + kTilePoints - 1) / kTilePoints;
-    const bool wave_tiles = (A >= 2 && ntiles * (int64_t)A >= kWaveTileMinTiles && !(flags & 2)) || (flags & 4);
+    const bool wave_tiles = P >= kTilePoints && ((A >= 2 && ntiles * (int64_t)A >= kWaveTileMinTiles && !(flags & 2)) || (flags & 4));
     // up to ~65536 blocks in total, split over the A configurations: about one 256-point tile per wave.  (Sweep on C4,
     // 200 x 262,144: 1024 blocks 1.40 ms, 4096 1.17, 8192 1.13, 32768 1.09, 65536 1.08 -- the hardware dispatcher
     // balances better than a grid-stride loop over unequal tiles.)
@@ -708,7 +695,9 @@ extern "C" int pvamd_composed_query(const pvamd_grid_t* grids, int32_t S, const 
         } else {
             const int64_t need = (P + 255) / 256;
             const unsigned gx = (unsigned)(need < cap ? need : (cap < 1 ? 1 : cap));
-            const int cf = (flags & 8) ? 1 : 0;
+            // configuration fastest unless flag 8 asks for the other order (tuning): with it the A = 200 README case runs
+            // 0.076 instead of 0.079 ms on the slice and 0.265 instead of 0.323 ms on random points (21 MB link grids)
+            const int cf = (flags & 8) ? 0 : 1;
             hipLaunchKernelGGL(composed_query_scalar, cf ? dim3(An, gx) : dim3(gx, An), dim3(256), 0, s, grids, S, tf, A, points,
                                (int64_t)0, P, out_val, out_grad, out_leaf, a0, cf);
         }

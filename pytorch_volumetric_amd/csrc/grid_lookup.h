@@ -16,37 +16,48 @@ namespace pvamd {
 // written with explicit fmaf / __f*_rn so that the CPU oracle can state the same sequence.
 #define PVAMD_DEV __device__ __forceinline__
 
-// The quotient -> index step under pvamd_grid_t::rule (include/pvamd.h): half-to-even by default; the alternatives sit
-// behind a wave-uniform branch on a kernarg / scalar-loaded field.
+// The quotient -> index step and the validity test under a NON-default pvamd_grid_t::rule (include/pvamd.h).  Out of line
+// on purpose: these statements only run for descriptors that ask for them, and inlined into the query kernels they cost
+// every launch registers (composed_query_wave: 42 -> 242 spilled VGPRs with them inline).
 template <typename T>
 PVAMD_DEV T round_by_rule(int rule, T q) {
-    if (__builtin_expect((rule & (PVAMD_RULE_ROUND_HALF_AWAY | PVAMD_RULE_ROUND_FLOOR_HALF)) == 0, 1)) {
-        if constexpr (sizeof(T) == 8) return __builtin_rint(q);
-        else return __builtin_rintf(q);
-    }
     if (rule & PVAMD_RULE_ROUND_HALF_AWAY) {
         if constexpr (sizeof(T) == 8) return __builtin_round(q);
         else return __builtin_roundf(q);
     }
-    if constexpr (sizeof(T) == 8) return __builtin_floor(q + 0.5);  // the sum rounds in the index dtype (-ffp-contract=off)
-    else return __builtin_floorf(add_rn(q, 0.5f));
+    if (rule & PVAMD_RULE_ROUND_FLOOR_HALF) {
+        if constexpr (sizeof(T) == 8) return __builtin_floor(q + 0.5);  // the sum rounds in the index dtype (-ffp-contract=off)
+        else return __builtin_floorf(add_rn(q, 0.5f));
+    }
+    if constexpr (sizeof(T) == 8) return __builtin_rint(q);
+    else return __builtin_rintf(q);
 }
 
-// index (as the reference would hold it, int64) and validity of one coordinate.  kq = the rounded quotient as a float:
-// "valid on the index" tests it (0 <= kq <= shape - 1; a NaN / infinite quotient fails), "valid on the value" tests p.
+// kq = the rounded quotient as a float: "valid on the index" tests it (0 <= kq <= shape - 1; a NaN / infinite quotient
+// fails), "valid on the value" tests p.
+PVAMD_DEV bool voxel_index_1d_ruled(const pvamd_grid_t& g, int d, float p, bool f64, long long& k) {
+    double kq;
+    if (f64) kq = round_by_rule<double>(g.rule, ((double)p - g.dmin[d]) / g.dres[d]);
+    else kq = (double)round_by_rule<float>(g.rule, div_rn(sub_rn(p, g.fmin[d]), g.fres[d]));
+    k = (long long)kq;
+    if (g.rule & PVAMD_RULE_VALID_ON_INDEX) return (kq >= 0.0) && (kq <= (double)(g.shape[d] - 1));
+    return f64 ? (g.dmin[d] <= (double)p) && ((double)p <= g.dmax[d]) : (g.fmin[d] <= p) && (p <= g.fmax[d]);
+}
+
+// index (as the reference would hold it, int64) and validity of one coordinate: the default statements inline, any other
+// rule behind one wave-uniform branch
 template <bool F64>
 PVAMD_DEV bool voxel_index_1d(const pvamd_grid_t& g, int d, float p, long long& k) {
+    if (__builtin_expect(g.rule != 0, 0)) return voxel_index_1d_ruled(g, d, p, F64, k);
     if constexpr (F64) {
         const double pd = (double)p;
-        const double kq = round_by_rule<double>(g.rule, (pd - g.dmin[d]) / g.dres[d]);
-        k = (long long)kq;
-        if (__builtin_expect(g.rule & PVAMD_RULE_VALID_ON_INDEX, 0)) return (kq >= 0.0) && (kq <= (double)(g.shape[d] - 1));
-        return (g.dmin[d] <= pd) && (pd <= g.dmax[d]);
+        const bool valid = (g.dmin[d] <= pd) && (pd <= g.dmax[d]);
+        k = (long long)__builtin_rint((pd - g.dmin[d]) / g.dres[d]);
+        return valid;
     } else {
-        const float kq = round_by_rule<float>(g.rule, div_rn(sub_rn(p, g.fmin[d]), g.fres[d]));
-        k = (long long)kq;
-        if (__builtin_expect(g.rule & PVAMD_RULE_VALID_ON_INDEX, 0)) return (kq >= 0.f) && (kq <= (float)(g.shape[d] - 1));
-        return (g.fmin[d] <= p) && (p <= g.fmax[d]);
+        const bool valid = (g.fmin[d] <= p) && (p <= g.fmax[d]);
+        k = (long long)__builtin_rintf(div_rn(sub_rn(p, g.fmin[d]), g.fres[d]));
+        return valid;
     }
 }
 

@@ -24,15 +24,40 @@ def shard_range(num_points, world_size, rank):
     return start, stop, chunk
 
 
+_INTO_TENSOR = {}
+
+
+def _gather_into(out, local, group):
+    """All-gather `local` into `out` (W, *local.shape).  Backends with all_gather_into_tensor (nccl = RCCL) get the one
+    flat collective; the others (gloo, the CPU tests) the list form.  Which one is decided ONCE per backend, from the
+    backend's name and -- for a backend this module has not seen -- a first attempt; a failure of the collective itself
+    is never answered with a second collective."""
+    backend = dist.get_backend(group)
+    into = _INTO_TENSOR.get(backend)
+    if into is None and backend == "gloo":
+        into = _INTO_TENSOR[backend] = False
+    if into is None:  # probe: NotImplementedError / "not supported" RuntimeError are raised before anything is sent
+        try:
+            dist.all_gather_into_tensor(out, local, group=group)
+            _INTO_TENSOR[backend] = True
+            return
+        except NotImplementedError:
+            into = _INTO_TENSOR[backend] = False
+        except RuntimeError as e:
+            if "support" not in str(e).lower() and "implement" not in str(e).lower():
+                raise
+            into = _INTO_TENSOR[backend] = False
+    if into:
+        dist.all_gather_into_tensor(out, local, group=group)
+    else:
+        dist.all_gather([out[r] for r in range(out.shape[0])], local, group=group)
+
+
 def _all_gather_cat(local, point_dim, group):
     """Gather equal-shaped `local` tensors from all ranks and concatenate them along `point_dim`."""
     world = dist.get_world_size(group)
     out = torch.empty((world,) + tuple(local.shape), dtype=local.dtype, device=local.device)
-    try:
-        dist.all_gather_into_tensor(out, local.contiguous(), group=group)  # one collective, no list of buffers
-    except (RuntimeError, NotImplementedError):
-        parts = [out[r] for r in range(world)]
-        dist.all_gather(parts, local.contiguous(), group=group)
+    _gather_into(out, local.contiguous(), group)
     # (W, ..., chunk, ...) -> (..., W*chunk, ...): the strided copy that restores the global point order
     point_dim = point_dim % local.dim()
     out = out.movedim(0, point_dim)  # (..., W, chunk, ...)
@@ -62,6 +87,7 @@ class ShardedSDF:
         world = dist.get_world_size(self.group)
         rank = dist.get_rank(self.group)
         lead = tuple(points_in_object_frame.shape[:-1])
+        self._query_dtype = points_in_object_frame.dtype if points_in_object_frame.dtype.is_floating_point else torch.float32
         flat = points_in_object_frame.reshape(-1, 3)
         P = flat.shape[0]
         start, stop, chunk = shard_range(P, world, rank)
@@ -107,10 +133,7 @@ class ShardedSDF:
             mine = torch.cat((mine, flat[:1].to(dev).expand(Pp - mine.shape[0], 3)), dim=0)
         rec = inner.query_packed(mine.contiguous())
         gathered = torch.empty((world, A, Pp, 4), dtype=torch.float32, device=dev)
-        try:
-            dist.all_gather_into_tensor(gathered, rec, group=self.group)
-        except (RuntimeError, NotImplementedError):
-            dist.all_gather([gathered[r] for r in range(world)], rec, group=self.group)
+        _gather_into(gathered, rec, self.group)
         key = (P, chunk, A, Pp, str(dev))
         if getattr(self, "_index_key", None) != key:  # caller point j sits in rank j // chunk's slab, at j % chunk
             j = torch.arange(P, device=dev, dtype=torch.int64)
@@ -121,6 +144,12 @@ class ShardedSDF:
         with _lib.on_device(dev):
             _lib.check(_lib.load().pvamd_unpack_records(_lib.ptr(gathered), _lib.ptr(self._index), P, Pp, A, _lib.ptr(val),
                                                         _lib.ptr(grad), _lib.stream_ptr()), "pvamd_unpack_records")
+        # the same device / dtype convention as ComposedSDF.__call__ (whatever path ran): results on the leaves' own
+        # device (sdf.py:546), in the dtype of the query points
+        out_device, out_dtype = inner.sdfs[0].device, self._query_dtype
+        if self.compute_device is not None:
+            out_device = self.compute_device
+        val, grad = val.to(device=out_device, dtype=out_dtype), grad.to(device=out_device, dtype=out_dtype)
         if inner.tsf_batch is None:
             return val.reshape(-1), grad.reshape(-1, 3)
         return val.reshape(*inner.tsf_batch, *lead), grad.reshape(*inner.tsf_batch, *lead, 3)

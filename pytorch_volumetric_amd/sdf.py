@@ -401,7 +401,7 @@ class CachedSDF(ObjectFrameSDF):
             pts = torch.cartesian_prod(*[c.to(dev_q) for c in coords])
             sdf_val, sdf_grad = gt_sdf(pts)  # with a MeshSDF this is the mesh kernel over every voxel centre
             val = sdf_val.reshape([len(coord) for coord in coords])
-            grad = sdf_grad.reshape(-1, 3)
+            grad = sdf_grad.reshape(-1, len(coords))  # (N, d): what the reference stores and pickles (sdf.py:505, squeeze(0))
             if cache_path is not None:
                 data[self.name] = val.cpu(), grad.cpu()
                 torch.save(data, cache_path)
@@ -872,23 +872,25 @@ class ComposedSDF(ObjectFrameSDF):
         dev = flat.device
         P = flat.shape[0]
         m = self._tf_device(dev).reshape(S, A, 4, 4)
-        if A > 65535:
-            raise ValueError("the per-leaf path takes at most 65535 configurations per call")
         best_v = torch.empty((A, P), dtype=torch.float32, device=dev)
         best_g = torch.empty((A, P, 3), dtype=torch.float32, device=dev)
-        x = torch.empty((A, P, 3), dtype=torch.float32, device=dev)
-        for i, sdf in enumerate(self.sdfs):
-            tf_i = m[i].contiguous()
-            with _lib.on_device(dev):
-                _lib.check(lib.pvamd_transform_points(_lib.ptr(tf_i), A, _lib.ptr(flat), P, _lib.ptr(x), _lib.stream_ptr()),
-                           "pvamd_transform_points")
-            v, g = sdf(x)
-            v = v.to(device=dev, dtype=torch.float32).reshape(A, P).contiguous()
-            g = g.to(device=dev, dtype=torch.float32).reshape(A, P, 3).contiguous()
-            with _lib.on_device(dev):
-                _lib.check(lib.pvamd_compose_merge(_lib.ptr(tf_i), A, P, _lib.ptr(v), _lib.ptr(g), i, 1 if i == 0 else 0,
-                                                   _lib.ptr(best_v), _lib.ptr(best_g), None, _lib.stream_ptr()),
-                           "pvamd_compose_merge")
+        slab = 65535  # the glue kernels carry the configuration in a grid dimension; the reference takes any batch
+        for a0 in range(0, A, slab):
+            An = min(slab, A - a0)
+            x = torch.empty((An, P, 3), dtype=torch.float32, device=dev)
+            bv, bg = best_v[a0:a0 + An], best_g[a0:a0 + An]  # contiguous row blocks of the outputs
+            for i, sdf in enumerate(self.sdfs):
+                tf_i = m[i, a0:a0 + An].contiguous()
+                with _lib.on_device(dev):
+                    _lib.check(lib.pvamd_transform_points(_lib.ptr(tf_i), An, _lib.ptr(flat), P, _lib.ptr(x), _lib.stream_ptr()),
+                               "pvamd_transform_points")
+                v, g = sdf(x)
+                v = v.to(device=dev, dtype=torch.float32).reshape(An, P).contiguous()
+                g = g.to(device=dev, dtype=torch.float32).reshape(An, P, 3).contiguous()
+                with _lib.on_device(dev):
+                    _lib.check(lib.pvamd_compose_merge(_lib.ptr(tf_i), An, P, _lib.ptr(v), _lib.ptr(g), i, 1 if i == 0 else 0,
+                                                       _lib.ptr(bv), _lib.ptr(bg), None, _lib.stream_ptr()),
+                               "pvamd_compose_merge")
         return best_v, best_g
 
 

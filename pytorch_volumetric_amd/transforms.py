@@ -69,9 +69,11 @@ def rigid_inverse(m):
     return out
 
 
-def is_rigid(m, tol=1e-4):
+def is_rigid(m, tol=1e-5):
     """True when every (...,4,4) matrix is a rigid transform: last row 0 0 0 1 and R R^T = I, det R = +1, to `tol`
-    (absolute; rotation matrices built in float32 are orthonormal to ~1e-6)."""
+    (absolute; rotation matrices built in float32 are orthonormal to ~1e-6, a chain of eight of them to a few 1e-6).
+    The tolerance is what the fused kernel's leaf-culling bounds absorb: they carry 1e-4 of relative slack
+    (composed.hip build_cull_spheres / tile_leaf_mask), ten times what a matrix accepted here can stretch a distance by."""
     m = torch.as_tensor(m)
     if m.numel() == 0:
         return True

@@ -293,3 +293,32 @@ def test_planar_cache_two_dimensional_points(numpy_range):
     assert torch.equal(c.outside_surface(pts.cuda(), 0.0).cpu().reshape(-1)[clear], (cell_val[flat[clear]] > 0))
     with pytest.raises(ValueError):
         c(torch.zeros(4, 3).cuda())
+
+
+def test_planar_cache_with_a_cell_count_that_three_does_not_divide_and_its_pickle(tmp_path):
+    """20 x 20 = 400 cells: the gradient of a planar ground truth is (N, 2) and is stored and pickled as such (the
+    reference: sdf.py:505 `sdf_grad.squeeze(0)`); round 2 reshaped it to (-1, 3), which 800 numbers do not allow.  The
+    pickle is read back without querying the ground truth (sdf.py:484-500) and answers the same."""
+    gt = CircleSDF(0.3)
+    path = str(tmp_path / "planar_cache.pkl")
+    rng = [(-0.5, 0.45), (-0.4, 0.55)]
+    c = pv.CachedSDF("circle", 0.05, rng, gt, device="cuda", cache_path=path)
+    assert c.voxels.shape == (20, 20)
+    data = torch.load(path, weights_only=False)
+    val, grad = data[c.name]
+    assert tuple(val.shape) == (20, 20) and tuple(grad.shape) == (400, 2)
+    pts = (torch.rand(4000, 2, generator=torch.Generator().manual_seed(3)) * 1.4 - 0.7).cuda()
+    class BoxOnly(pv.ObjectFrameSDF):  # the cache must make querying the ground truth unnecessary
+        def __call__(self, p):
+            raise AssertionError("served from the pickle")
+
+        def surface_bounding_box(self, **kw):
+            return gt.surface_bounding_box(**kw)
+
+    again = pv.CachedSDF("circle", 0.05, rng, BoxOnly(), device="cuda", cache_path=path)
+    v1, g1 = c(pts)
+    assert torch.equal(again._packed, c._packed)
+    inside = c.voxels.get_valid_values(pts)
+    v2, g2 = again(pts)
+    assert torch.equal(v1, v2) and torch.equal(g1.nan_to_num(7.0), g2.nan_to_num(7.0)) and g1.shape == (4000, 2)
+    assert inside.any() and (~inside).any()

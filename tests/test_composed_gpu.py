@@ -127,13 +127,13 @@ def test_full_size_c3_properties():
 
 def test_leaf_culling_is_exact_on_coherent_and_far_queries():
     """Grid-ordered points (whole waves far from most leaves -> leaves skipped) and points far outside every leaf must
-    still match the oracle bit for bit; so must a scene where a leaf's grid range is SMALLER than its bounding box.
-    Sizes are chosen so that the wave-tile kernel (the one that culls; used once tiles x configurations >= 4096) runs."""
+    still match the oracle bit for bit; so must a scene where a leaf's grid range is SMALLER than its bounding box."""
     S, A = 8, 10
     leaves = [make_leaf(f64=(s % 2 == 0), padding=0.05) for s in range(S)]
     tfm = H.random_rigid(S * A, seed=77, trans=1.5)
     comp = pv.ComposedSDF(leaves, None)
     comp.set_transforms(pv.Transform3d(matrix=tfm), batch_dim=(A,))
+    _force_flags(comp, 4)  # the wave-tile kernel (the one that culls), whatever the entry point would pick at this size
     ax = torch.linspace(-2.0, 2.0, 48)
     pts = torch.cartesian_prod(ax, ax, ax)[: 48 * 48 * 48 // 256 * 256]
     far = H.uniform_points(2048, [30.0] * 3, [40.0] * 3, seed=1)
@@ -156,12 +156,13 @@ def test_leaf_culling_is_exact_on_coherent_and_far_queries():
 
 def test_more_leaves_than_the_culling_table_holds():
     """S = 70 > 64: leaves beyond the LDS culling table take the un-culled branch of the same loop (wave-tile kernel:
-    256 tiles x 16 configurations; the 4 leftover points go through the one-point-per-lane kernel)."""
+    257 tiles x 16 configurations, the last tile with 4 points)."""
     S, A = 70, 16
     leaf = make_leaf(res=0.02)
     tfm = H.random_rigid(S * A, seed=9, trans=0.8)
     comp = pv.ComposedSDF([leaf] * S, None)
     comp.set_transforms(pv.Transform3d(matrix=tfm), batch_dim=(A,))
+    _force_flags(comp, 4)
     pts = scene_points(65_536 + 4, seed=4, extent=1.0)
     val, grad = comp(pts.cuda())
     og = H.oracle_grid_from_cached(leaf)
@@ -274,7 +275,7 @@ def _force_flags(comp, flags):
     comp._query_flags = flags
 
 
-@pytest.mark.parametrize("A,P,flags", [(200, 15_251, 0), (20, 15_251, 4), (20, 15_251, 0), (24, 20_481, 4 | 1), (5, 255, 4),
+@pytest.mark.parametrize("A,P,flags", [(200, 15_251, 0), (200, 15_251, 4), (20, 15_251, 4), (20, 15_251, 0), (24, 20_481, 4 | 1), (5, 255, 4),
                                        (5, 257, 4), (3, 3, 4), (7, 513, 4), (2, 1, 4)])
 def test_any_point_count_goes_through_the_wave_tile_kernel_bitwise(A, P, flags):
     """The reference README's own query has M = 15,251 points (README.md:177-200): (A, P) rows that start at any dword,
@@ -296,7 +297,7 @@ def test_any_point_count_goes_through_the_wave_tile_kernel_bitwise(A, P, flags):
     assert np.array_equal(grad.cpu().numpy(), ograd, equal_nan=True)
 
 
-@pytest.mark.parametrize("flags", [4, 2])
+@pytest.mark.parametrize("flags", [4, 2, 2 | 8])
 def test_buffers_at_any_dword_address(flags):
     """points / out_val / out_grad that are only 4-byte aligned (views into larger buffers), odd P, both kernels; the
     floats around the outputs must stay untouched."""

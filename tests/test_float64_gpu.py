@@ -124,3 +124,26 @@ def test_lookup_gt_strategy_keeps_the_query_dtype():
     inb = c.voxels.get_valid_values(pts.cuda())
     # out of range: ground truth from the mesh kernel (float32 arithmetic, sdf.py:132) widened to the query dtype
     assert torch.equal(val[~inb], v32[~inb].double()) and (~inb).any()
+
+
+def test_outside_surface_compares_in_float32_whatever_the_query_dtype():
+    """sdf.py:601 `raw_data[flat] > surface_level`: the cache is a float32 tensor and a python scalar does not promote it,
+    so a level that float32 cannot represent (0.1) is rounded first -- a voxel holding float32(0.1) is NOT above level 0.1,
+    for float32 and float64 query points alike (round 2 compared in float64 for float64 points)."""
+
+    class Constant(pv.ObjectFrameSDF):
+        def __call__(self, p):
+            return torch.full(p.shape[:-1], 0.1, dtype=p.dtype, device=p.device), torch.zeros_like(p)
+
+        def surface_bounding_box(self, **kw):
+            return torch.tensor([[-0.1, 0.1]] * 3, dtype=torch.float64)
+
+    c = pv.CachedSDF("const", 0.05, np.array([[-0.5, 0.5]] * 3), Constant(), device="cuda", cache_path=None)
+    assert float(c.voxels.raw_data[0]) == float(np.float32(0.1)) > 0.1
+    pts = (torch.rand(1000, 3, dtype=torch.float64) - 0.5) * 0.9
+    for q in (pts, pts.float()):
+        out = c.outside_surface(q.cuda(), surface_level=0.1)
+        assert not out.any()
+        assert c.outside_surface(q.cuda(), surface_level=0.0999999).all()
+    og = H.oracle_grid_from_cached(c)
+    assert not oracle.cached_outside_f64(og, pts.numpy(), 0.1).any() and not oracle.cached_outside(og, pts.float().numpy(), 0.1).any()
