@@ -32,6 +32,11 @@ HBM_PEAK_GBS = 8000.0  # MI355X datasheet (MI355X_MICROARCH.md); 6.3-6.5 TB/s is
 BYTES_PER_QUERY = 28   # 12 B point read + 4 B value + 12 B gradient written
 BYTES_PER_PAIR_C4 = 16  # C4: 4 B value + 12 B gradient written per (configuration, point); points are re-read from L2
 KERNEL_GRAPH_LAUNCHES = 2000
+XGMI_LINK_GBS = 153.0   # per direction per peer link (7 links per GPU on an 8-GPU node; the task's hardware notes)
+VALU_FULL_RATE_PER_SIMD = 1.0e9   # wave64 v_fma/add/mul_f32 per second per SIMD (profiles/r02_valu_rate.txt: ~1.0 ns each)
+VALU_SLOW_RATE_PER_SIMD = 1.0e9 / 1.8  # compares, v_cndmask, min/max/med3, converts, int multiply, v_pk_*, f64: ~1.8 ns each
+N_SIMD = 1024
+README_PUBLISHED_MS = {20: 37.688577, 200: 128.645445}  # /root/reference README.md:196-200, RTX 2080 Ti, KUKA iiwa (8 links)
 
 
 def parse_args():
@@ -52,6 +57,8 @@ def parse_args():
     ap.add_argument("--force-pg", action="store_true",
                     help="test hook: create the process group and run the gather / all-reduce legs even with ONE rank "
                          "(exercises the RCCL calls on a 1-GPU box)")
+    ap.add_argument("--fail-rank", type=int, default=-1, help="test hook: this rank raises while preparing --fail-leg")
+    ap.add_argument("--fail-leg", default="", help="test hook: see --fail-rank")
     ap.add_argument("--launch-check", action="store_true",
                     help="no GPU work: start the ranks, all-reduce over gloo, print the rank count (CPU test of --gpus N)")
     return ap.parse_args()
@@ -175,6 +182,10 @@ def cpu_baseline(torch, np, cached, pts, seconds):
         if dt >= seconds and reps >= 3:
             break
     out = {"value": len(host_pts) * reps / dt, "unit": "queries/s", "cores": oracle.num_threads(), "kind": "port",
+           "what": "`value` = the FUSED C/OpenMP restatement of sdf.py:535-571 (oracle/pvamd_oracle.c): one pass per point, "
+                   "no intermediates -- faster than anything the reference executes.  The op-for-op restatement of what the "
+                   "reference runs on CPU (its ~25 torch ops with their intermediates, oracle/torch_opforop.py) is "
+                   "`torch_opforop`; the reference itself cannot be imported here (third-party packages absent)",
            "host_cpus": os.cpu_count(),
            "sample": f"{reps} x {len(host_pts)} of the same query points through oracle/pvamd_oracle.c "
                      f"(OpenMP, {oracle.num_threads()} threads), {dt:.1f} s wall"}
@@ -201,10 +212,77 @@ def cpu_baseline(torch, np, cached, pts, seconds):
     return out
 
 
+def time_calls(torch, np, fn, reps=400):
+    """The drop-in call as a user makes it: (a) `reps` calls back to back, one synchronize at the end (what a loop that
+    consumes the results on the GPU sees), (b) synchronize after every call (what a loop that reads them back sees)."""
+    for _ in range(20):
+        fn()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        fn()
+    torch.cuda.synchronize()
+    back_to_back = (time.perf_counter() - t0) / reps
+    each = []
+    for _ in range(min(reps, 200)):
+        t0 = time.perf_counter()
+        fn()
+        torch.cuda.synchronize()
+        each.append(time.perf_counter() - t0)
+    return back_to_back * 1e3, float(np.median(each)) * 1e3
+
+
+def valu_roofline(kernel_key, ms, launches_per_step=1):
+    """Roofline object of a vector-ALU-bound leg: wave64 VALU instructions per second against the per-opcode issue ceilings
+    of profiles/r02_valu_rate.txt.  The instruction count per launch comes from the committed rocprofv3 --pmc pass
+    (SQ_INSTS_VALU; it cannot be collected inside this run), the time is this run's."""
+    path = os.path.join(ROOT, "profiles", "r03_valu_counts.json")
+    try:
+        entry = json.load(open(path))[kernel_key]
+    except Exception:
+        return {"bound": "valu", "achieved": None, "note": f"no committed SQ_INSTS_VALU pass for {kernel_key} ({path})"}
+    inst = entry["SQ_INSTS_VALU"] * launches_per_step
+    achieved = inst / (ms * 1e-3)
+    peak = N_SIMD * VALU_FULL_RATE_PER_SIMD
+    return {"bound": "valu", "achieved": achieved / 1e9, "peak": peak / 1e9, "unit": "G wave64 VALU inst/s", "frac": achieved / peak,
+            "slow_opcode_group_ceiling": N_SIMD * VALU_SLOW_RATE_PER_SIMD / 1e9,
+            "frac_of_slow_group_ceiling": achieved / (N_SIMD * VALU_SLOW_RATE_PER_SIMD),
+            "valu_inst_per_step": inst, "active_lanes_per_inst": entry.get("active_lanes"),
+            "source": f"profiles/r03_valu_counts.json[{kernel_key}] = SQ_INSTS_VALU of {entry.get('workload')} "
+                      f"({entry.get('command')}); ceilings: profiles/r02_valu_rate.txt (1024 SIMDs x 1 / 1.0 ns for "
+                      "v_fma/add/mul/mov, x 1 / 1.8 ns for cmp/cndmask/min/max/med3/cvt/int-mul/pk/f64); read from the "
+                      "committed file, not measured in this run"}
+
+
+class LegSkipped(Exception):
+    pass
+
+
+class Gate:
+    """Every leg calls its gate ONCE, after its set-up and before its first collective: one tiny all-reduce tells every rank
+    whether all ranks got there.  A rank whose set-up raised reports that instead (main's handler), so the others skip the
+    leg together rather than wait in a barrier for a rank that will never arrive."""
+
+    def __init__(self, torch, dist, active):
+        self.torch, self.dist, self.active, self.passed = torch, dist, active, False
+
+    def agree(self, ok):
+        if not self.active:
+            return ok
+        t = self.torch.tensor([1 if ok else 0], dtype=self.torch.int32, device="cuda")
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.MIN)
+        return bool(t.item())
+
+    def __call__(self):
+        self.passed = True
+        if not self.agree(True):
+            raise LegSkipped()
+
+
 def read_traffic(P):
     """HBM-side bytes per launch from the committed PMC passes (NOT measured in this run: rocprofv3 --pmc cannot run
     inside the benchmark)."""
-    for name in ("r02_traffic.json", "traffic.json"):
+    for name in ("r03_traffic.json", "r02_traffic.json", "traffic.json"):
         path = os.path.join(ROOT, "profiles", name)
         if os.path.exists(path):
             try:
@@ -220,13 +298,20 @@ def read_traffic(P):
 
 
 # ------------------------------------------------------------------------------------------------ legs: C4 and C5
-def leg_c4(torch, dist, Wk, pv, timer, rank, world, steps, padding, with_gather, small=False, use_pg=False):
+def build_robot(Wk, cache, padding):
+    if padding not in cache:
+        cache[padding] = Wk.build_c4(resolution=0.02, padding=padding)
+    return cache[padding]
+
+
+def leg_c4(torch, dist, Wk, pv, timer, gate, robots, rank, world, steps, padding, with_gather, small=False, use_pg=False):
     """BASELINE configs[3]: RobotSDF (7-DOF, 8 links), A=200 joint configurations x P=262,144 points, the POINTS
     sharded over the ranks (strong scaling: the total work is fixed).  Leg 1 leaves (val, grad) sharded -- no
     collective; leg 2 times ShardedSDF.__call__: query into packed records + ONE RCCL all-gather + the unpack kernel that
-    writes (A, P[, 3]) order (model_to_sdf.py:117-125 on every rank's slice)."""
+    writes (A, P[, 3]) order (model_to_sdf.py:117-125 on every rank's slice); leg 3 shards the CONFIGURATIONS instead
+    (rows gathered in place, no unpack: SURVEY.md 8(e))."""
     A, P = (8, 1 << 14) if small else (200, 1 << 18)
-    robot = Wk.build_c4(resolution=0.02, padding=padding)
+    robot = build_robot(Wk, robots, padding)
     robot.set_joint_configuration(Wk.c4_joint_configs(A))
     pts = Wk.c4_points(P)
     start, stop, chunk = pv.shard_range(P, world, rank)
@@ -251,6 +336,7 @@ def leg_c4(torch, dist, Wk, pv, timer, rank, world, steps, padding, with_gather,
 
     for _ in range(3):
         one_step()
+    gate()
     t = timer(sharded_steps)
     pairs = A * P * steps
     out = {"config": f"C4: RobotSDF 8 links, link grids res 0.02 padding {padding}, A={A} x P={P}, points sharded x{world}",
@@ -259,9 +345,11 @@ def leg_c4(torch, dist, Wk, pv, timer, rank, world, steps, padding, with_gather,
            "call": "robot(points): Morton-bucketed fused kernel + un-permute, output allocation included" if bucketed
                    else "robot.query_into(points, val, grad): fused kernel, caller's buffers",
            "sharded": {"gather": False, "value": pairs / t, "ms_per_step": t / steps * 1e3,
-                       "roofline": {"bound": "hbm", "achieved": BYTES_PER_PAIR_C4 * pairs / t / 1e9, "peak": HBM_PEAK_GBS * world,
-                                    "unit": "GB/s", "frac": BYTES_PER_PAIR_C4 * pairs / t / 1e9 / (HBM_PEAK_GBS * world),
-                                    "note": "16 B written per pair; the kernel itself is VALU-bound (DESIGN.md 3.2)"}}}
+                       "hbm_write_rate": {"achieved_GBs": BYTES_PER_PAIR_C4 * pairs / t / 1e9,
+                                          "frac_of_hbm_peak": BYTES_PER_PAIR_C4 * pairs / t / 1e9 / (HBM_PEAK_GBS * world),
+                                          "note": "16 B written per pair; NOT what bounds this kernel"}}}
+    if not bucketed and not small and world == 1:
+        out["sharded"]["roofline"] = valu_roofline("c4_composed_query_wave", t / steps * 1e3)
     if with_gather and (world > 1 or use_pg):
         sharded = pv.ShardedSDF(robot, gather=True, compute_device=torch.device("cuda"))
         gsteps = max(2, steps // 4)
@@ -276,18 +364,67 @@ def leg_c4(torch, dist, Wk, pv, timer, rank, world, steps, padding, with_gather,
         tg = timer(gather_steps)
         ref = robot(pts[:65536])  # after timing: the gathered result against the unsharded call, bit for bit
         same = bool(torch.equal(full[0][:, :65536], ref[0]) and torch.equal(full[1][:, :65536], ref[1]))
+        recv = getattr(sharded, "bytes_received_per_rank", None)
         out["gathered"] = {"gather": True, "value": A * P * gsteps / tg, "ms_per_step": tg / gsteps * 1e3, "steps": gsteps,
                            "collective": f"packed (val, grad) records, all_gather_into_tensor x1 ({dist.get_backend()}), "
-                                         f"{A * (-(-chunk // 256) * 256) * 16 * (world - 1)} B received per rank per step, "
                                          "unpack kernel writes (A, P) / (A, P, 3)",
+                           "bytes_received_per_rank": recv,
+                           "xgmi_lower_bound_ms": None if not recv or world < 2 else recv / (world - 1) / (XGMI_LINK_GBS * 1e9) * 1e3,
+                           "xgmi_note": f"each of the {world - 1} peers sends its slab over its own ~{XGMI_LINK_GBS:.0f} GB/s link, "
+                                        "in parallel (full mesh): time >= one slab / link rate; a ring would take (W - 1) x that",
                            "path": getattr(sharded, "last_path", None), "equals_unsharded_call": same,
                            "output_shape": [list(full[0].shape), list(full[1].shape)]}
+        if not bucketed:
+            by_cfg = pv.ShardedSDF(robot, gather=True, compute_device=torch.device("cuda"), shard="configs")
+            cfull = None
+
+            def config_steps():
+                nonlocal cfull
+                for _ in range(gsteps):
+                    cfull = by_cfg(pts)
+
+            by_cfg(pts)
+            tc = timer(config_steps)
+            same_c = bool(torch.equal(cfull[0][:, :65536], ref[0]) and torch.equal(cfull[1][:, :65536], ref[1]))
+            out["gathered_by_configs"] = {"gather": True, "shard": "configs", "value": A * P * gsteps / tc,
+                                          "ms_per_step": tc / gsteps * 1e3, "steps": gsteps,
+                                          "collective": f"all_gather_into_tensor x2 (val rows, grad rows; {dist.get_backend()}) "
+                                                        "straight into (A, P) / (A, P, 3): no packed records, no unpack pass",
+                                          "bytes_received_per_rank": getattr(by_cfg, "bytes_received_per_rank", None),
+                                          "equals_unsharded_call": same_c}
     else:
         out["gathered"] = None if world > 1 else {"gather": True, "note": "single rank: nothing to gather, same as `sharded`"}
     return out
 
 
-def leg_c5(torch, dist, Wk, pv, timer, rank, world, steps, small=False, use_pg=False):
+def leg_readme(torch, np, Wk, pv, timer, gate, robots, rank, world, A):
+    """The reference README's own benchmark shape (/root/reference README.md:150-200): link caches at resolution 0.02 with
+    padding 1.0, A joint configurations (q0 + 0.1 N(0,1)), the README's M = 15,251 query points -- the ordered 151 x 1 x
+    101 slice `get_coordinates_and_points_in_grid(0.01, [[-1, 0.5], [0.02, 0.02], [-0.2, 0.8]])` -- through the drop-in
+    call `robot(points)` (output allocation included).  Every rank runs the whole case (replicas: it is far too small to
+    shard).  NOT like for like with the published figure: synthetic 7-DOF arm (the KUKA assets are not available
+    offline), one MI355X against an RTX 2080 Ti."""
+    robot = build_robot(Wk, robots, 1.0)
+    th = Wk.c4_joint_configs(A)
+    _, pts = pv.get_coordinates_and_points_in_grid(0.01, np.array([[-1, 0.5], [0.02, 0.02], [-0.2, 0.8]]))
+    pts = pts.cuda()
+    M = pts.shape[0]
+    robot.set_joint_configuration(th)
+    gate()
+    call_ms, synced_ms = time_calls(torch, np, lambda: robot(pts), reps=200)
+    sjc_ms, _ = time_calls(torch, np, lambda: robot.set_joint_configuration(th), reps=100)
+    val, grad = robot(pts)
+    return {"config": f"reference README case: RobotSDF 8 links, link grids res 0.02 padding 1.0, A={A} x M={M} "
+                      "(README.md:177-183 slice points), robot(points)",
+            "scaling": "replicas", "n_gpus": world, "unit": "ms per robot(points) call",
+            "ms_per_call": call_ms, "ms_per_call_synchronized_each": synced_ms, "pairs_per_s": A * M / (call_ms * 1e-3),
+            "set_joint_configuration_ms": sjc_ms, "output_shapes": [list(val.shape), list(grad.shape)],
+            "published_ms": README_PUBLISHED_MS.get(A), "published_on": "RTX 2080 Ti, KUKA iiwa (README.md:196-200)",
+            "like_for_like": False,
+            "why_not": "synthetic 7-DOF arm with 8 ellipsoid links (KUKA assets unavailable offline); different GPU"}
+
+
+def leg_c5(torch, dist, Wk, pv, timer, gate, rank, world, steps, small=False, use_pg=False):
     """BASELINE configs[4]: unidirectional chamfer, 2,097,152 source points -> 99,500-triangle mesh, the source
     points sharded over the ranks; each rank reduces its slice, then ONE all-reduce of B float64 partial sums (+ the
     count) -- chamfer.py:79-94 with the mean taken over the global N."""
@@ -305,6 +442,8 @@ def leg_c5(torch, dist, Wk, pv, timer, rank, world, steps, small=False, use_pg=F
             else:
                 err = pv.batch_chamfer_dist(W, pts, obj_factory=mesh, scale=1000.0)
 
+    mesh._mesh_desc()  # upload + prepare the mesh: set-up, before the gate
+    gate()
     run()
     t = timer(run)
     F = mesh.num_faces
@@ -312,6 +451,9 @@ def leg_c5(torch, dist, Wk, pv, timer, rank, world, steps, small=False, use_pg=F
     return {"config": f"C5: chamfer, {N} points -> {F}-triangle sphere mesh, points sharded x{world}, B=1",
             "scaling": "strong", "n_gpus": world, "steps": steps, "unit": "points/s", "value": N * steps / t,
             "ms_per_step": t / steps * 1e3, "brute_force_equivalent_pairs_per_s": N * F * steps / t,
+            "brute_force_note": "pairs a plain double loop would evaluate; the kernel culls, so this is a throughput "
+                                "equivalent, not work done (no fraction of the fp32 peak is quoted from it)",
+            "roofline": valu_roofline("c5_chamfer_mesh", t / steps * 1e3) if (world == 1 and not small) else None,
             "collective": None if (world == 1 and not use_pg) else f"all_reduce of B=1 float64 sums + count ({dist.get_backend()})",
             "chamfer_mm2": float(err[0]), "analytic_sphere_mm2": analytic,
             "rel_err_vs_analytic": abs(float(err[0]) - analytic) / analytic}
@@ -346,10 +488,12 @@ def main():
         os.environ.setdefault("MASTER_PORT", str(free_port()))
         os.environ.setdefault("RANK", "0")
         os.environ.setdefault("WORLD_SIZE", "1")
+        import datetime
+        limit = datetime.timedelta(seconds=180)  # a rank lost inside a collective ends the run in minutes, not the default half hour
         if backend == "nccl":
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank), timeout=limit)
         else:
-            dist.init_process_group(backend)
+            dist.init_process_group(backend, timeout=limit)
     import pytorch_volumetric_amd as pv
     import workloads as Wk
     timer = Timer(torch, dist, world if not args.force_pg else max(world, 2))  # force-pg: barriers / all-reduce run too
@@ -400,6 +544,8 @@ def main():
     k_ms = graph_ms_per_launch(torch, kgraph, kg_n)
     del kgraph
     e_mean, e_med, e_min = time_eager_kernel(torch, np, step, 200)
+    # the drop-in call itself -- what a user of the reference writes: val, grad = sdf(points) (sdf.py:535-591), outputs allocated
+    d_call, d_sync = time_calls(torch, np, lambda: cached(pts), reps=400)
 
     out = None
     if rank == 0:
@@ -425,6 +571,11 @@ def main():
                                    f"same call on the same buffers, / {kg_n} (best of 3 replays); NOT the K timed steps, "
                                    "so it does not change with --steps",
                          "eager_launch_ms": {"mean": e_mean, "median": e_med, "min": e_min},
+                         "dropin_call": {"call": "val, grad = cached(points)  # CachedSDF.__call__, outputs allocated per call",
+                                         "ms_per_call": d_call, "queries_per_s": P / (d_call * 1e-3),
+                                         "ms_per_call_synchronized_each": d_sync,
+                                         "timing": "400 calls back to back + one synchronize, wall clock / 400; and the median "
+                                                   "of 200 calls each followed by a synchronize"},
                          "algorithmic_bytes_per_launch": BYTES_PER_QUERY * P,
                          "frac_of_wall_ms_per_step": BYTES_PER_QUERY * P / (elapsed / args.steps) / 1e9 / HBM_PEAK_GBS},
         }
@@ -433,14 +584,34 @@ def main():
     if not args.no_legs:
         leg_steps = 20
         sm = args.small_legs
-        for name, fn in (("c4", lambda: leg_c4(torch, dist, Wk, pv, timer, rank, world, leg_steps, 0.1, True, sm, use_pg)),
-                         ("c4_readme_grid", lambda: leg_c4(torch, dist, Wk, pv, timer, rank, world, leg_steps, 1.0, False, sm)),
-                         ("c5", lambda: leg_c5(torch, dist, Wk, pv, timer, rank, world, 5, sm, use_pg))):
+        robots = {}
+        spec = [("c4", lambda g: leg_c4(torch, dist, Wk, pv, timer, g, robots, rank, world, leg_steps, 0.1, True, sm, use_pg)),
+                ("c4_readme_grid", lambda g: leg_c4(torch, dist, Wk, pv, timer, g, robots, rank, world, leg_steps, 1.0, False, sm)),
+                ("c5", lambda g: leg_c5(torch, dist, Wk, pv, timer, g, rank, world, 5, sm, use_pg))]
+        if not sm:
+            spec += [("readme_a20", lambda g: leg_readme(torch, np, Wk, pv, timer, g, robots, rank, world, 20)),
+                     ("readme_a200", lambda g: leg_readme(torch, np, Wk, pv, timer, g, robots, rank, world, 200))]
+        for name, fn in spec:
+            gate = Gate(torch, dist, use_pg)
             try:
-                legs[name] = fn()
+                if rank == args.fail_rank and name == args.fail_leg:
+                    raise RuntimeError(f"--fail-rank {rank} --fail-leg {name}: forced failure before the leg's gate")
+                legs[name] = fn(gate)
+            except LegSkipped:
+                legs[name] = {"skipped": "another rank failed while preparing this leg; every rank skipped it together"}
             except Exception as exc:  # a failing leg must not take the headline line with it
                 legs[name] = {"error": repr(exc)}
+                if not gate.passed:
+                    gate.agree(False)  # the other ranks are waiting at their gate: let them skip the leg
             torch.cuda.empty_cache()
+    if use_pg and not args.no_legs:
+        # rank 0 prints the line: let it say which legs some OTHER rank lost
+        mine = torch.tensor([1 if ("error" in legs.get(n, {}) or "skipped" in legs.get(n, {})) else 0 for n, _ in spec],
+                            dtype=torch.int32, device="cuda")
+        dist.all_reduce(mine, op=dist.ReduceOp.SUM)
+        for (n, _), k in zip(spec, mine.tolist()):
+            if k and isinstance(legs.get(n), dict):
+                legs[n]["ranks_without_a_result"] = int(k)
     if rank == 0:
         out["legs"] = legs
 

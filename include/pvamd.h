@@ -213,6 +213,14 @@ int pvamd_composed_query(const pvamd_grid_t* grids, int32_t S, const float* tf, 
                          const float* points, int64_t P,
                          float* out_val, float* out_grad, int32_t* out_leaf, int32_t flags, void* stream);
 
+/* The same query for FLOAT64 points with a float64 transform stack (sdf.py:392-433 when the chain / the Transform3d is
+ * float64: the transform, every leaf's index arithmetic, range test and bounding-box branch -- sdf.py:545-547 -- and the
+ * gradient rotation are float64; cached records are widened exactly).  tf: device [S*A][4][4] float64.  points: device
+ * [P][3] float64.  out_val: device [A][P] float64.  out_grad: device [A][P][3] float64.  8-byte alignment.            */
+int pvamd_composed_query_f64(const pvamd_grid_t* grids, int32_t S, const double* tf, int32_t A,
+                             const double* points, int64_t P,
+                             double* out_val, double* out_grad, int32_t* out_leaf, void* stream);
+
 /* The glue of ComposedSDF.__call__ for leaves that are not cached grids (MeshSDF, SphereSDF, nested compositions;
  * sdf.py:392-433 around per-leaf queries), with the fused kernel's rounding so that both paths state the same numbers:
  * pvamd_transform_points: out[a][p] = tf[a] p (sdf.py:399).  tf: device [A][4][4] -- the A transforms of ONE leaf.
@@ -242,7 +250,7 @@ int pvamd_composed_query_bucketed(const pvamd_grid_t* grids, int32_t S, const fl
  * (model_to_sdf.py:117-125 -> sdf.py:392-433) sharded over GPUs runs on each rank's slice of the points, gathers ONE
  * buffer of records instead of val and grad, then unpacks straight into the reference's (A, P) / (A, P, 3) layout:
  * pvamd_composed_query_packed: out_rec[a][k] = (val, gx, gy, gz) of configuration a at points[k].  points: device [Pp][3],
- *   Pp a multiple of 256, 16-byte aligned.  out_rec: device, A * Pp * 16 bytes, 16-byte aligned.  A <= 65535.
+ *   Pp a multiple of 256, at most 2^24 * 4.  out_rec: device, A * Pp * 16 bytes, 16-byte aligned.  Any A.
  * pvamd_unpack_records: out_val[a][j] / out_grad[a][j] = rec[a * stride + index[j]] for j < P (index[j] may point
  *   anywhere in the buffer, e.g. into another rank's slab).  rec: device float4 records.  index: device [P] int32.   */
 int pvamd_composed_query_packed(const pvamd_grid_t* grids, int32_t S, const float* tf, int32_t A, const float* points,

@@ -229,6 +229,21 @@ def composed_query(grids, tf, A, pts):
     return val, grad, leaf
 
 
+def composed_query_f64(grids, tf, A, pts):
+    """float64 points and a float64 [S*A,4,4] transform stack: val [A,P], grad [A,P,3] in float64, leaf [A,P]."""
+    S = len(grids)
+    arr = (OracleGrid * S)(*[g.c for g in grids])
+    tf = np.ascontiguousarray(tf, dtype=np.float64).reshape(S * A, 16)
+    pts = np.ascontiguousarray(pts, dtype=np.float64).reshape(-1, 3)
+    P = len(pts)
+    val = np.empty((A, P), np.float64)
+    grad = np.empty((A, P, 3), np.float64)
+    leaf = np.empty((A, P), np.int32)
+    load().oracle_composed_query_f64(arr, ctypes.c_int32(S), _p(tf), ctypes.c_int32(A), _p(pts), ctypes.c_int64(P), _p(val),
+                                     _p(grad), _p(leaf))
+    return val, grad, leaf
+
+
 class Mesh:
     def __init__(self, tri, normal, ray_dir):
         self.tri = _f32(tri).reshape(-1, 3, 3)

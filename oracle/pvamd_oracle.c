@@ -199,43 +199,46 @@ void oracle_voxel_index_f64(const oracle_grid_t* g, const double* pts, int64_t P
     }
 }
 
+/* one CachedSDF lookup for a float64 point (sdf.py:535-571 with every tensor op promoted to float64); returns validity */
+static int cached_lookup_f64(const oracle_grid_t* g, const double* p, double* val, double* grad) {
+    int64_t k[3];
+    int valid = 1;
+    for (int d = 0; d < 3; ++d) valid &= index_1d_f64(g, d, p[d], &k[d]);
+    if (valid) {
+        const int64_t flat = (k[0] * g->shape[1] + k[1]) * g->shape[2] + k[2];
+        *val = (double)g->val[flat];           /* :549 float32 cache assigned into a float64 tensor */
+        grad[0] = (double)g->grad[3 * flat];   /* :550 */
+        grad[1] = (double)g->grad[3 * flat + 1];
+        grad[2] = (double)g->grad[3 * flat + 2];
+    } else if (g->oob_mode == 1) {
+        double t[3];
+        for (int d = 0; d < 3; ++d) {
+            double dmin = g->dbb_min[d] - p[d];  /* :559 */
+            const int dmin_active = dmin > 0.0;  /* :560 */
+            if (!dmin_active) dmin = 0.0;        /* :561 */
+            double dmax = p[d] - g->dbb_max[d];  /* :562 */
+            if (!(dmax > 0.0)) dmax = 0.0;       /* :563-564 */
+            double dtotal = dmin + dmax;         /* :565 */
+            if (dmin_active) dtotal = -dtotal;   /* :567 */
+            t[d] = dtotal;
+        }
+        const double n = sqrt(fma(t[2], t[2], fma(t[1], t[1], t[0] * t[0]))); /* :568 */
+        grad[0] = t[0] / n; /* :570 */
+        grad[1] = t[1] / n;
+        grad[2] = t[2] / n;
+        *val = n; /* :571 */
+    } else {
+        *val = 0.0;
+        grad[0] = grad[1] = grad[2] = 0.0;
+    }
+    return valid;
+}
+
 void oracle_cached_query_f64(const oracle_grid_t* g, const double* pts, int64_t P, double* out_val, double* out_grad,
                              uint8_t* out_oob) {
 #pragma omp parallel for schedule(static)
     for (int64_t i = 0; i < P; ++i) {
-        const double* p = pts + 3 * i;
-        int64_t k[3];
-        int valid = 1;
-        for (int d = 0; d < 3; ++d) valid &= index_1d_f64(g, d, p[d], &k[d]);
-        double* val = out_val + i;
-        double* grad = out_grad + 3 * i;
-        if (valid) {
-            const int64_t flat = (k[0] * g->shape[1] + k[1]) * g->shape[2] + k[2];
-            *val = (double)g->val[flat];           /* :549 float32 cache assigned into a float64 tensor */
-            grad[0] = (double)g->grad[3 * flat];   /* :550 */
-            grad[1] = (double)g->grad[3 * flat + 1];
-            grad[2] = (double)g->grad[3 * flat + 2];
-        } else if (g->oob_mode == 1) {
-            double t[3];
-            for (int d = 0; d < 3; ++d) {
-                double dmin = g->dbb_min[d] - p[d];  /* :559 */
-                const int dmin_active = dmin > 0.0;  /* :560 */
-                if (!dmin_active) dmin = 0.0;        /* :561 */
-                double dmax = p[d] - g->dbb_max[d];  /* :562 */
-                if (!(dmax > 0.0)) dmax = 0.0;       /* :563-564 */
-                double dtotal = dmin + dmax;         /* :565 */
-                if (dmin_active) dtotal = -dtotal;   /* :567 */
-                t[d] = dtotal;
-            }
-            const double n = sqrt(fma(t[2], t[2], fma(t[1], t[1], t[0] * t[0]))); /* :568 */
-            grad[0] = t[0] / n; /* :570 */
-            grad[1] = t[1] / n;
-            grad[2] = t[2] / n;
-            *val = n; /* :571 */
-        } else {
-            *val = 0.0;
-            grad[0] = grad[1] = grad[2] = 0.0;
-        }
+        const int valid = cached_lookup_f64(g, pts + 3 * i, out_val + i, out_grad + 3 * i);
         if (out_oob) out_oob[i] = (uint8_t)!valid;
     }
 }
@@ -325,6 +328,42 @@ void oracle_composed_query(const oracle_grid_t* grids, int32_t S, const float* t
                     /* :409 transform_normals by leaf->obj = R^T of the (rigid) obj->leaf rotation */
                     for (int j = 0; j < 3; ++j)
                         best_g[j] = fmaf(M[8 + j], g[2], fmaf(M[4 + j], g[1], M[j] * g[0]));
+                }
+            }
+            const int64_t o = (int64_t)a * P + i;
+            out_val[o] = best_v;
+            out_grad[3 * o] = best_g[0];
+            out_grad[3 * o + 1] = best_g[1];
+            out_grad[3 * o + 2] = best_g[2];
+            if (out_leaf) out_leaf[o] = best_s;
+        }
+    }
+}
+
+/* The same composition for FLOAT64 query points and a float64 transform stack (a RobotSDF over a float64 chain, or a
+ * float64 Transform3d handed to ComposedSDF): sdf.py:399 transforms in float64, every leaf answers in the query dtype
+ * (sdf.py:545-547: index arithmetic, range test and bounding-box branch in float64), sdf.py:409 rotates the float64
+ * gradient back, sdf.py:421 takes the first minimum.  tf: [S*A][16] float64. */
+void oracle_composed_query_f64(const oracle_grid_t* grids, int32_t S, const double* tf, int32_t A, const double* pts,
+                               int64_t P, double* out_val, double* out_grad, int32_t* out_leaf) {
+#pragma omp parallel for schedule(static) collapse(2)
+    for (int32_t a = 0; a < A; ++a) {
+        for (int64_t i = 0; i < P; ++i) {
+            double best_v = 0.0, best_g[3] = {0.0, 0.0, 0.0};
+            int32_t best_s = -1;
+            const double* p = pts + 3 * i;
+            for (int32_t s = 0; s < S; ++s) {
+                const double* M = tf + 16 * ((int64_t)s * A + a);
+                double x[3], v, g[3];
+                for (int r = 0; r < 3; ++r) /* :399, the k-ordered chain of the float32 statement, in float64 */
+                    x[r] = fma(M[4 * r + 2], p[2], fma(M[4 * r + 1], p[1], M[4 * r] * p[0])) + M[4 * r + 3];
+                cached_lookup_f64(&grids[s], x, &v, g); /* :407 */
+                const int take = (best_s < 0) || (v < best_v) || (isnan(v) && !isnan(best_v)); /* :421 */
+                if (take) {
+                    best_v = v;
+                    best_s = s;
+                    for (int j = 0; j < 3; ++j) /* :409 */
+                        best_g[j] = fma(M[8 + j], g[2], fma(M[4 + j], g[1], M[j] * g[0]));
                 }
             }
             const int64_t o = (int64_t)a * P + i;

@@ -194,52 +194,14 @@ __global__ __launch_bounds__(256) void voxel_index_kernel(const pvamd_grid_t g, 
 
 // ---- float64 query points (sdf.py:545-547: output dtype = query dtype; torch promotion makes the index arithmetic,
 // the range test and the BOUNDING_BOX branch float64).  One point per lane; 24 B read + 32 B written per point. ----
-PVAMD_DEV bool voxel_key_f64(const pvamd_grid_t& g, const double p[3], long long key[3]) {
-    bool valid = true;
-#pragma unroll
-    for (int d = 0; d < 3; ++d) {
-        const double kq = round_by_rule<double>(g.rule, (p[d] - g.dmin[d]) / g.dres[d]);
-        key[d] = (long long)kq;
-        if (__builtin_expect(g.rule & PVAMD_RULE_VALID_ON_INDEX, 0)) valid &= (kq >= 0.0) && (kq <= (double)(g.shape[d] - 1));
-        else valid &= (g.dmin[d] <= p[d]) && (p[d] <= g.dmax[d]);
-    }
-    return valid;
-}
-
-PVAMD_DEV int clamped_flat(const pvamd_grid_t& g, const long long key[3]) {
-    const int kx = min(max((int)key[0], 0), g.shape[0] - 1);
-    const int ky = min(max((int)key[1], 0), g.shape[1] - 1);
-    const int kz = min(max((int)key[2], 0), g.shape[2] - 1);
-    return (kx * g.shape[1] + ky) * g.shape[2] + kz;
-}
-
 __global__ __launch_bounds__(256) void cached_query_f64_kernel(const pvamd_grid_t g, const double* __restrict__ pts,
                                                                 int64_t P, double* __restrict__ val,
                                                                 double* __restrict__ grad, uint8_t* __restrict__ oob) {
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < P; i += stride) {
         const double p[3] = {pts[3 * i], pts[3 * i + 1], pts[3 * i + 2]};
-        long long key[3];
-        const bool valid = voxel_key_f64(g, p, key);
-        double v = 0.0, gx = 0.0, gy = 0.0, gz = 0.0;
-        if (valid) {
-            const float4 r = reinterpret_cast<const float4*>(g.vox)[clamped_flat(g, key)];
-            v = (double)r.x; gx = (double)r.y; gy = (double)r.z; gz = (double)r.w;
-        } else if (g.oob_mode == PVAMD_OOB_BOUNDING_BOX) {
-            double t[3];
-#pragma unroll
-            for (int d = 0; d < 3; ++d) {
-                double lo = g.dbb_min[d] - p[d];
-                const bool lo_active = lo > 0.0;
-                lo = lo_active ? lo : 0.0;
-                double hi = p[d] - g.dbb_max[d];
-                hi = (hi > 0.0) ? hi : 0.0;
-                const double s = lo + hi;
-                t[d] = lo_active ? -s : s;
-            }
-            v = __builtin_sqrt(__builtin_fma(t[2], t[2], __builtin_fma(t[1], t[1], t[0] * t[0])));
-            gx = t[0] / v; gy = t[1] / v; gz = t[2] / v;
-        }
+        double v, gx, gy, gz;
+        const bool valid = cached_lookup_f64(g, p, v, gx, gy, gz);
         val[i] = v;
         grad[3 * i] = gx;
         grad[3 * i + 1] = gy;

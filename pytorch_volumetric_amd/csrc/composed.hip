@@ -474,6 +474,45 @@ __global__ __launch_bounds__(256) void composed_query_scalar(const pvamd_grid_t*
     }
 }
 
+// ---- float64 query points with a float64 transform stack (a RobotSDF over a float64 chain): sdf.py:399 transforms in
+// float64, every leaf answers in the query dtype (sdf.py:545-547), sdf.py:409 rotates the float64 gradient back.  One
+// (configuration, point) per lane, configuration fastest; 24 B read + 32 B written per pair, fp64 VALU: a correctness path
+// for the dtype contract, not a tuned one. ----
+__global__ __launch_bounds__(256) void composed_query_f64_kernel(const pvamd_grid_t* __restrict__ grids, int S,
+                                                                  const double* __restrict__ tf, int A,
+                                                                  const double* __restrict__ pts, int64_t P,
+                                                                  double* __restrict__ val, double* __restrict__ grad,
+                                                                  int* __restrict__ leaf) {
+    const int a = blockIdx.x;
+    const int64_t stride = (int64_t)gridDim.y * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.y * blockDim.x + threadIdx.x; i < P; i += stride) {
+        const double p[3] = {pts[3 * i], pts[3 * i + 1], pts[3 * i + 2]};
+        double bv = 0.0, bg[3] = {0.0, 0.0, 0.0};
+        int bs = -1;
+        for (int s = 0; s < S; ++s) {
+            const double* M = tf + 16 * ((int64_t)s * A + a);  // wave-uniform: scalar loads
+            double x[3], v, g0, g1, g2;
+#pragma unroll
+            for (int r = 0; r < 3; ++r)
+                x[r] = __builtin_fma(M[4 * r + 2], p[2], __builtin_fma(M[4 * r + 1], p[1], M[4 * r] * p[0])) + M[4 * r + 3];
+            cached_lookup_f64(grids[s], x, v, g0, g1, g2);
+            const bool take = (bs < 0) || (v < bv) || (v != v && bv == bv);  // sdf.py:421: first minimum, NaN counts as minimum
+            if (take) {
+                bv = v;
+                bs = s;
+#pragma unroll
+                for (int j = 0; j < 3; ++j) bg[j] = __builtin_fma(M[8 + j], g2, __builtin_fma(M[4 + j], g1, M[j] * g0));
+            }
+        }
+        const int64_t o = (int64_t)a * P + i;
+        val[o] = bv;
+        grad[3 * o] = bg[0];
+        grad[3 * o + 1] = bg[1];
+        grad[3 * o + 2] = bg[2];
+        if (leaf) leaf[o] = bs;
+    }
+}
+
 // ---- generic leaves (MeshSDF, SphereSDF, nested compositions): the glue of sdf.py:392-433 around per-leaf queries ----
 // x[a][p] = T[a] p with the fused kernel's rounding (k-ordered fma chain, sdf.py:399)
 __global__ __launch_bounds__(256) void transform_points_kernel(const float* __restrict__ tf, int A,
@@ -607,8 +646,8 @@ extern "C" int pvamd_composed_query_packed(const pvamd_grid_t* grids, int32_t S,
     hipStream_t s = (hipStream_t)stream;
     const int64_t ntiles = Pp / kTilePoints;
     const int64_t tile_blocks = (ntiles + kWavesPerBlock - 1) / kWavesPerBlock;
-    constexpr int kSlab = 65535;  // gridDim.y of the query kernel = tile blocks
-    if (tile_blocks > kSlab || A > kSlab) return PVAMD_E_SHAPE;  // > 67 M points per call: use the direct entry point
+    // gridDim.y of the query kernel = tile blocks (the configuration is blockIdx.x: any A)
+    if (tile_blocks > 65535) return PVAMD_E_SHAPE;  // > 67 M points per call: use the direct entry point
     if (flags & PVAMD_COMPOSED_INLINE_EXACT)
         hipLaunchKernelGGL((composed_query_wave<PVAMD_COMPOSED_PPP, kInlineExact, true>), dim3(A, (unsigned)tile_blocks),
                            dim3(kWavesPerBlock * 64), 0, s, grids, S, tf, A, points, ntiles, Pp, out_rec, nullptr, nullptr, 0);
@@ -676,11 +715,13 @@ extern "C" int pvamd_composed_query(const pvamd_grid_t* grids, int32_t S, const 
     // up to ~65536 blocks in total, split over the A configurations: about one 256-point tile per wave.  (Sweep on C4,
     // 200 x 262,144: 1024 blocks 1.40 ms, 4096 1.17, 8192 1.13, 32768 1.09, 65536 1.08 -- the hardware dispatcher
     // balances better than a grid-stride loop over unequal tiles.)
-    // The configuration is a grid dimension (blockIdx.x of the wave-tile kernel, blockIdx.y of the per-lane kernel): at
-    // most 65535 per launch, so larger batches go out in slabs (the kernels take the slab's first configuration and
-    // index transforms / outputs with the global one)
-    for (int a0 = 0; a0 < A; a0 += kConfigSlab) {
-        const int An = A - a0 < kConfigSlab ? A - a0 : kConfigSlab;
+    // The configuration is a grid dimension: blockIdx.x (any count) in the wave-tile kernel and in the per-lane kernel's
+    // default order; blockIdx.y (<= 65535) in the per-lane kernel's points-fastest order, whose larger batches go out in
+    // slabs (the kernels take the slab's first configuration and index transforms / outputs with the global one)
+    const bool a_is_y = !wave_tiles && (flags & 8);  // only this order carries the configuration in gridDim.y (<= 65535)
+    const int slab = a_is_y ? kConfigSlab : (kConfigSlab < 65535 ? kConfigSlab : A);
+    for (int a0 = 0; a0 < A; a0 += slab) {
+        const int An = A - a0 < slab ? A - a0 : slab;
         int64_t cap = ((int64_t)65536 + An - 1) / An;
         if (cap > 65535) cap = 65535;  // gridDim.y
         if (wave_tiles) {
@@ -702,6 +743,22 @@ extern "C" int pvamd_composed_query(const pvamd_grid_t* grids, int32_t S, const 
                                (int64_t)0, P, out_val, out_grad, out_leaf, a0, cf);
         }
     }
+    return (int)hipGetLastError();
+}
+
+extern "C" int pvamd_composed_query_f64(const pvamd_grid_t* grids, int32_t S, const double* tf, int32_t A,
+                                        const double* points, int64_t P, double* out_val, double* out_grad,
+                                        int32_t* out_leaf, void* stream) {
+    if (S < 1 || A < 1 || P < 0) return PVAMD_E_SHAPE;
+    if (P == 0) return 0;
+    if (!grids || !tf || !out_val || !out_grad || !points) return PVAMD_E_NULL;
+    if (!aligned_to(grids, 8) || !aligned_to(tf, 8) || !aligned_to(points, 8) || !aligned_to(out_val, 8) || !aligned_to(out_grad, 8))
+        return PVAMD_E_ALIGN;
+    int64_t gy = (P + 255) / 256;
+    const int64_t cap = ((int64_t)65536 + A - 1) / A;
+    if (gy > cap) gy = cap;
+    hipLaunchKernelGGL(composed_query_f64_kernel, dim3(A, (unsigned)(gy < 1 ? 1 : gy)), dim3(256), 0, (hipStream_t)stream, grids, S,
+                       tf, A, points, P, out_val, out_grad, out_leaf);
     return (int)hipGetLastError();
 }
 

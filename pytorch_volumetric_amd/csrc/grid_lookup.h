@@ -208,6 +208,53 @@ PVAMD_DEV float4 cached_lookup(const pvamd_grid_t& g, float x, float y, float z,
     return make_float4(0.f, 0.f, 0.f, 0.f);  // LOOKUP_GT_SDF: zeros (sdf.py:546-547), caller fills in
 }
 
+// ---- float64 query points (sdf.py:545-547: output dtype = query dtype; torch promotion makes the index arithmetic,
+// the range test and the BOUNDING_BOX branch float64) ----
+PVAMD_DEV bool voxel_key_f64(const pvamd_grid_t& g, const double p[3], long long key[3]) {
+    bool valid = true;
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+        const double kq = round_by_rule<double>(g.rule, (p[d] - g.dmin[d]) / g.dres[d]);
+        key[d] = (long long)kq;
+        if (__builtin_expect(g.rule & PVAMD_RULE_VALID_ON_INDEX, 0)) valid &= (kq >= 0.0) && (kq <= (double)(g.shape[d] - 1));
+        else valid &= (g.dmin[d] <= p[d]) && (p[d] <= g.dmax[d]);
+    }
+    return valid;
+}
+
+PVAMD_DEV int clamped_flat(const pvamd_grid_t& g, const long long key[3]) {
+    const int kx = min(max((int)key[0], 0), g.shape[0] - 1);
+    const int ky = min(max((int)key[1], 0), g.shape[1] - 1);
+    const int kz = min(max((int)key[2], 0), g.shape[2] - 1);
+    return (kx * g.shape[1] + ky) * g.shape[2] + kz;
+}
+
+// (val, gx, gy, gz) of one float64 point: the cached record widened exactly, or the bounding-box statements in float64
+PVAMD_DEV bool cached_lookup_f64(const pvamd_grid_t& g, const double p[3], double& v, double& gx, double& gy, double& gz) {
+    long long key[3];
+    const bool valid = voxel_key_f64(g, p, key);
+    v = gx = gy = gz = 0.0;
+    if (valid) {
+        const float4 r = reinterpret_cast<const float4*>(g.vox)[clamped_flat(g, key)];
+        v = (double)r.x; gx = (double)r.y; gy = (double)r.z; gz = (double)r.w;
+    } else if (g.oob_mode == PVAMD_OOB_BOUNDING_BOX) {
+        double t[3];
+#pragma unroll
+        for (int d = 0; d < 3; ++d) {
+            double lo = g.dbb_min[d] - p[d];
+            const bool lo_active = lo > 0.0;
+            lo = lo_active ? lo : 0.0;
+            double hi = p[d] - g.dbb_max[d];
+            hi = (hi > 0.0) ? hi : 0.0;
+            const double s = lo + hi;
+            t[d] = lo_active ? -s : s;
+        }
+        v = __builtin_sqrt(__builtin_fma(t[2], t[2], __builtin_fma(t[1], t[1], t[0] * t[0])));
+        gx = t[0] / v; gy = t[1] / v; gz = t[2] / v;
+    }
+    return valid;
+}
+
 // x' = M p for a row-major 4x4 (column-vector convention), k-ordered fma chain -- the rounding sequence of an
 // f32 MFMA / a bmm k-loop: ((m0*px (+) m1*py) (+) m2*pz) + m3.
 PVAMD_DEV float affine_row(float m0, float m1, float m2, float m3, float px, float py, float pz) {

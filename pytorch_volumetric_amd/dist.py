@@ -66,19 +66,33 @@ def _all_gather_cat(local, point_dim, group):
     return out.reshape(shape)
 
 
+def packed_index(P, chunk, A, Pp, device):
+    """Where caller point j sits in the gathered buffer of packed records, laid out (world, A, Pp, 4): in the slab of rank
+    j // chunk, at position j % chunk of configuration 0 -- the unpack adds a * Pp for configuration a."""
+    j = torch.arange(P, device=device, dtype=torch.int64)
+    return ((j // chunk) * (A * Pp) + j % chunk).to(torch.int32)
+
+
 class ShardedSDF:
-    """Wrap any ObjectFrameSDF so that __call__ evaluates only this rank's slice of the (flattened) query points and
-    all-gathers the results.
+    """Wrap any ObjectFrameSDF so that __call__ evaluates only this rank's share of the query and all-gathers the results.
+
+    shard="points" (BASELINE.json's split): this rank's slice of the (flattened) query points, all configurations.
+    shard="configs" (RobotSDF / batched ComposedSDF only): every point, this rank's slice of the configuration batch --
+    the rows of (A, P) / (A, P, 3) a rank produces are contiguous in the result, so the all-gather writes them in place:
+    no packed records, no unpack pass; worthwhile when A >= the number of ranks.
 
     Output shapes match the wrapped SDF's for the full input: leading configuration dims (RobotSDF / batched
     ComposedSDF) are preserved, the point dims come back in the original order.
     """
 
-    def __init__(self, sdf, group=None, gather=True, compute_device=None):
+    def __init__(self, sdf, group=None, gather=True, compute_device=None, shard="points"):
+        if shard not in ("points", "configs"):
+            raise ValueError(f"shard must be 'points' or 'configs', got {shard!r}")
         self.sdf = sdf
         self.group = group
         self.gather = gather
         self.compute_device = compute_device  # where gathered tensors live (nccl needs GPU tensors)
+        self.shard = shard
 
     def surface_bounding_box(self, **kwargs):
         return self.sdf.surface_bounding_box(**kwargs)
@@ -90,6 +104,8 @@ class ShardedSDF:
         self._query_dtype = points_in_object_frame.dtype if points_in_object_frame.dtype.is_floating_point else torch.float32
         flat = points_in_object_frame.reshape(-1, 3)
         P = flat.shape[0]
+        if self.shard == "configs":
+            return self._configs_call(flat, lead, world, rank)
         start, stop, chunk = shard_range(P, world, rank)
         packed = self._packed_call(flat, lead, world, start, stop, chunk)
         if packed is not None:
@@ -113,19 +129,52 @@ class ShardedSDF:
             return val.reshape(*batch, -1), grad.reshape(*batch, -1, 3)
         return val.reshape(*batch, *lead), grad.reshape(*batch, *lead, 3)
 
+    def _configs_call(self, flat, lead, world, rank):
+        """shard="configs": rank r evaluates configurations [r * per, (r + 1) * per) of the flattened batch at every point
+        (per = ceil(A / W); the last rank repeats configuration A - 1 to fill its share, trimmed after the gather)."""
+        inner = getattr(self.sdf, "sdf", self.sdf)  # RobotSDF -> its ComposedSDF
+        batch = getattr(inner, "tsf_batch", None)
+        if batch is None or not hasattr(inner, "query_configs"):
+            raise ValueError("shard='configs' needs a RobotSDF / ComposedSDF with a configuration batch")
+        A = math.prod(batch)
+        start, stop, per = shard_range(A, world, rank)
+        self.last_path = "configs"
+        val, grad = inner.query_configs(flat, start, per)  # (per, P), (per, P, 3)
+        if not self.gather:
+            return val[:stop - start], grad[:stop - start], (start, stop)
+        if self.compute_device is not None:
+            val, grad = val.to(self.compute_device), grad.to(self.compute_device)
+        P = flat.shape[0]
+        out_val = torch.empty((world, per, P), dtype=val.dtype, device=val.device)
+        out_grad = torch.empty((world, per, P, 3), dtype=grad.dtype, device=grad.device)
+        _gather_into(out_val, val.contiguous(), self.group)   # rows land where (A, P) wants them: no reorder pass
+        _gather_into(out_grad, grad.contiguous(), self.group)
+        self.bytes_received_per_rank = (world - 1) * per * P * 16
+        val, grad = out_val.reshape(world * per, P)[:A], out_grad.reshape(world * per, P, 3)[:A]
+        return val.reshape(*batch, *lead), grad.reshape(*batch, *lead, 3)
+
+    def _unpack_records(self, gathered, index, P, Pp, A, dev):
+        """(world, A, Pp, 4) packed records -> val (A, P), grad (A, P, 3) in caller point order: one kernel."""
+        val = torch.empty((A, P), dtype=torch.float32, device=dev)
+        grad = torch.empty((A, P, 3), dtype=torch.float32, device=dev)
+        with _lib.on_device(dev):
+            _lib.check(_lib.load().pvamd_unpack_records(_lib.ptr(gathered), _lib.ptr(index), P, Pp, A, _lib.ptr(val),
+                                                        _lib.ptr(grad), _lib.stream_ptr()), "pvamd_unpack_records")
+        return val, grad
+
     def _packed_call(self, flat, lead, world, start, stop, chunk):
         """The one-collective path (module docstring); None when it does not apply."""
         inner = getattr(self.sdf, "sdf", self.sdf)  # RobotSDF -> its ComposedSDF
         P = flat.shape[0]
         if not (self.gather and P > 0 and hasattr(inner, "query_packed") and inner._fusable() and torch.is_tensor(flat)
-                and flat.dtype == torch.float32 and torch.cuda.is_available()):
+                and flat.dtype == torch.float32):
             return None
         dev = inner._owner_device()
         if self.compute_device is not None and torch.device(self.compute_device).type != "cuda":
             return None
         A = math.prod(inner.tsf_batch) if inner.tsf_batch is not None else 1
         Pp = -(-chunk // 256) * 256
-        if world * A * Pp >= 2 ** 31 or A > 65535:
+        if world * A * Pp >= 2 ** 31:  # the unpack kernel indexes records with int32
             return None
         self.last_path = "packed"
         mine = flat[start:stop].to(dev)
@@ -134,16 +183,12 @@ class ShardedSDF:
         rec = inner.query_packed(mine.contiguous())
         gathered = torch.empty((world, A, Pp, 4), dtype=torch.float32, device=dev)
         _gather_into(gathered, rec, self.group)
+        self.bytes_received_per_rank = (world - 1) * A * Pp * 16
         key = (P, chunk, A, Pp, str(dev))
-        if getattr(self, "_index_key", None) != key:  # caller point j sits in rank j // chunk's slab, at j % chunk
-            j = torch.arange(P, device=dev, dtype=torch.int64)
-            self._index = ((j // chunk) * (A * Pp) + j % chunk).to(torch.int32)
+        if getattr(self, "_index_key", None) != key:
+            self._index = packed_index(P, chunk, A, Pp, dev)
             self._index_key = key
-        val = torch.empty((A, P), dtype=torch.float32, device=dev)
-        grad = torch.empty((A, P, 3), dtype=torch.float32, device=dev)
-        with _lib.on_device(dev):
-            _lib.check(_lib.load().pvamd_unpack_records(_lib.ptr(gathered), _lib.ptr(self._index), P, Pp, A, _lib.ptr(val),
-                                                        _lib.ptr(grad), _lib.stream_ptr()), "pvamd_unpack_records")
+        val, grad = self._unpack_records(gathered, self._index, P, Pp, A, dev)
         # the same device / dtype convention as ComposedSDF.__call__ (whatever path ran): results on the leaves' own
         # device (sdf.py:546), in the dtype of the query points
         out_device, out_dtype = inner.sdfs[0].device, self._query_dtype

@@ -615,7 +615,7 @@ class ComposedSDF(ObjectFrameSDF):
         (sdf.py:379) and cannot slice with it; only its explicit batch_dim path works."""
         if tsf is None:
             self.obj_frame_to_link_frame, self.link_frame_to_obj_frame = None, []
-            self.tsf_batch, self._tf_dev, self._rigid = batch_dim, None, True
+            self.tsf_batch, self._tf_dev, self._tf_dev64, self._rigid = batch_dim, None, None, True
             return
         m = tf.as_matrix(tsf)
         S, S_tsf = len(self.sdfs), m.shape[0]
@@ -628,7 +628,7 @@ class ComposedSDF(ObjectFrameSDF):
             if math.prod(batch_dim) * S != S_tsf:
                 raise ValueError(f"{S_tsf} transforms != {S} SDFs x batch {batch_dim}")
         # validated: now commit
-        self.tsf_batch, self._tf_dev = batch_dim, None
+        self.tsf_batch, self._tf_dev, self._tf_dev64 = batch_dim, None, None
         self.obj_frame_to_link_frame = tsf if hasattr(tsf, "get_matrix") else tf.Transform3d(matrix=m)
         # The reference inverts with a general matrix inverse (sdf.py:380).  Rigid stacks (every RobotSDF stack, and
         # what the fused kernel's leaf-culling spheres and R^T gradient rotation assume) use the exact R^T form;
@@ -781,6 +781,8 @@ class ComposedSDF(ObjectFrameSDF):
         pts_shape = points_in_object_frame.shape
         out_device = points_in_object_frame.device
         fused = self._fusable()
+        if fused and points_in_object_frame.dtype == torch.float64:
+            return self._call_f64(points_in_object_frame, S, A)
         flat, _, dtype, _ = _lib.as_query_points(points_in_object_frame, self._owner_device() if fused else None)
         P = flat.shape[0]
         dev = flat.device
@@ -816,6 +818,31 @@ class ComposedSDF(ObjectFrameSDF):
             val, grad = val.reshape(-1), grad.reshape(-1, 3)
         return val.to(device=out_device, dtype=dtype), grad.to(device=out_device, dtype=dtype)
 
+    def _call_f64(self, points, S, A):
+        """float64 query points: transform, lookups and gradient rotation in float64 (`pvamd_composed_query_f64`), results
+        in float64 -- the reference's output dtype is the query dtype (sdf.py:395-431 over sdf.py:545-547).  A float32
+        transform stack is widened exactly (the reference's own bmm would refuse the mixed dtypes)."""
+        dev = self._owner_device()
+        flat = points.detach().reshape(-1, 3).to(device=dev, dtype=torch.float64).contiguous()
+        P = flat.shape[0]
+        tf64 = self.__dict__.get("_tf_dev64")
+        if tf64 is None or tf64.device != dev:
+            tf64 = self._tf_dev64 = tf.as_matrix(self.obj_frame_to_link_frame).to(device=dev, dtype=torch.float64).contiguous()
+        val = torch.empty((A, P), dtype=torch.float64, device=dev)
+        grad = torch.empty((A, P, 3), dtype=torch.float64, device=dev)
+        with _lib.on_device(dev):
+            grids = self._leaf_grids(dev)
+            _lib.check(_lib.load().pvamd_composed_query_f64(_lib.ptr(grids), S, _lib.ptr(tf64), A, _lib.ptr(flat), P,
+                                                            _lib.ptr(val), _lib.ptr(grad), None, _lib.stream_ptr()),
+                       "pvamd_composed_query_f64")
+        out_device = self.sdfs[0].device
+        if self.tsf_batch is not None:
+            val = val.reshape(*self.tsf_batch, *points.shape[:-1])
+            grad = grad.reshape(*self.tsf_batch, *points.shape[:-1], 3)
+        else:
+            val, grad = val.reshape(-1), grad.reshape(-1, 3)
+        return val.to(device=out_device), grad.to(device=out_device)
+
     def query_packed(self, points, out=None):
         """Fused query that leaves one (val, gx, gy, gz) record per (configuration, point): (A, P, 4) fp32 for contiguous
         fp32 (P, 3) GPU points, P a multiple of 256.  What a query sharded over GPUs gathers (one buffer instead of two,
@@ -838,6 +865,27 @@ class ComposedSDF(ObjectFrameSDF):
                                                                A, _lib.ptr(points), P, _lib.ptr(out), self._query_flags,
                                                                _lib.stream_ptr()), "pvamd_composed_query_packed")
         return out
+
+    def query_configs(self, points, first, count):
+        """The fused query for configurations [first, first + count) of the flattened batch only (indices past the last
+        configuration repeat it): fp32 (count, P) / (count, P, 3) on the leaves' GPU.  What a query sharded over
+        configurations runs on each rank (dist.ShardedSDF(shard="configs")); same bits as the rows of __call__."""
+        if not self._fusable() or self.tsf_batch is None:
+            raise ValueError("query_configs needs BOUNDING_BOX CachedSDF leaves and a configuration batch")
+        S, A = len(self.sdfs), math.prod(self.tsf_batch)
+        dev = self._owner_device()
+        flat, _, _, _ = _lib.as_query_points(points, dev)
+        P = flat.shape[0]
+        pick = torch.arange(first, first + count, device=dev).clamp_max(A - 1)
+        sub = self._tf_device(dev).reshape(S, A, 4, 4)[:, pick].contiguous()
+        val = torch.empty((count, P), dtype=torch.float32, device=dev)
+        grad = torch.empty((count, P, 3), dtype=torch.float32, device=dev)
+        with _lib.on_device(dev):
+            grids = self._leaf_grids(dev)
+            _lib.check(_lib.load().pvamd_composed_query(_lib.ptr(grids), S, _lib.ptr(sub), count, _lib.ptr(flat), P,
+                                                        _lib.ptr(val), _lib.ptr(grad), None, self._query_flags,
+                                                        _lib.stream_ptr()), "pvamd_composed_query")
+        return val, grad
 
     def query_into(self, points, out_val, out_grad):
         """Allocation-free fused query for inner loops / graph capture: contiguous fp32 (P,3) GPU points, results into

@@ -82,28 +82,36 @@ random_rigid = workloads.random_rigid
 uniform_points = workloads.uniform_points
 
 
-def composed_disagreements_explained(leaves, tf, A, pts, val_a, val_b, ulps=16, atol=1e-6):
+def composed_disagreements_explained(leaves, tf, A, pts, val_a, val_b, ulps=8, atol=1e-6, report=None):
     """Two evaluations of the same ComposedSDF that round the obj->leaf transform differently (torch matmul vs the
     kernel's fma chain) must agree to `atol` EXCEPT where a last-place difference in a leaf-frame coordinate changes a
-    discrete decision: the coordinate sits within `ulps` float32 ulps (of its own terms' magnitude) of a half-voxel
-    plane -- the nearest-voxel index flips -- or of an edge of the cached range -- the in-range / bounding-box branch
-    flips.  Returns (number of disagreeing (config, point) pairs, how many of them no such plane or edge explains)."""
+    discrete decision: the coordinate sits within `ulps` units of a half-voxel plane -- the nearest-voxel index flips --
+    or of an edge of the cached range -- the in-range / bounding-box branch flips.  One unit = 2^-24 x (|m0 px| + |m1 py|
+    + |m2 pz| + |m3|), the bound of ONE float32 rounding of that coordinate; each evaluation makes four (three products
+    folded by two fmas and an add), so two evaluations differ by at most 8 units: that is the default, and what the
+    error analysis gives (round 2 allowed 16).  `report`, a dict, receives the largest number of units any disagreement
+    actually needed.  Returns (number of disagreeing (config, point) pairs, how many of them no plane or edge explains)."""
     pts = np.asarray(pts, dtype=np.float64).reshape(-1, 3)
     tf = np.asarray(tf, dtype=np.float64).reshape(len(leaves), A, 4, 4)
     va, vb = np.asarray(val_a, dtype=np.float64).reshape(A, -1), np.asarray(val_b, dtype=np.float64).reshape(A, -1)
     bad = ~(np.isclose(va, vb, rtol=0, atol=atol) | (np.isnan(va) & np.isnan(vb)))
-    explained = np.zeros_like(bad)
+    need = np.full(bad.shape, np.inf)  # units to the nearest plane / edge, over leaves
     for s, leaf in enumerate(leaves):
         v = leaf._view
         mn, mx, res = v.dmin.numpy(), v.dmax.numpy(), v.dres.numpy()
         for a in range(A):
+            if not bad[a].any():
+                continue
             R, t = tf[s, a, :3, :3], tf[s, a, :3, 3]
             x = pts @ R.T + t
-            eps = ulps * 2.0 ** -24 * (np.abs(pts) @ np.abs(R).T + np.abs(t))  # per coordinate
-            near_range = ((x >= mn - eps) & (x <= mx + eps)).all(axis=1)
+            unit = 2.0 ** -24 * (np.abs(pts) @ np.abs(R).T + np.abs(t))  # per coordinate
             cell = (x - mn) / res
             to_plane = np.abs(cell - np.floor(cell) - 0.5) * res
-            on_plane = (to_plane <= eps).any(axis=1)
-            on_edge = ((np.abs(x - mn) <= eps) | (np.abs(x - mx) <= eps)).any(axis=1)
-            explained[a] |= near_range & (on_plane | on_edge)
+            to_edge = np.minimum(np.abs(x - mn), np.abs(x - mx))
+            near = ((x >= mn - 64 * unit) & (x <= mx + 64 * unit)).all(axis=1)  # the leaf's range is in play at all
+            d = np.where(near[:, None], np.minimum(to_plane, to_edge) / unit, np.inf).min(axis=1)
+            need[a] = np.minimum(need[a], d)
+    explained = need <= ulps
+    if report is not None:
+        report["max_units_needed"] = float(need[bad].max()) if bad.any() else 0.0
     return int(bad.sum()), int((bad & ~explained).sum())

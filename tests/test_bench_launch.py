@@ -51,7 +51,21 @@ def test_two_ranks_share_the_gpu_and_every_leg_reports():
     assert legs["c4"]["sharded"]["gather"] is False and legs["c4"]["gathered"]["gather"] is True
     assert legs["c4"]["gathered"]["output_shape"] == [[8, 16384], [8, 16384, 3]]
     assert legs["c4"]["gathered"]["path"] == "packed" and legs["c4"]["gathered"]["equals_unsharded_call"] is True
+    assert legs["c4"]["gathered"]["bytes_received_per_rank"] == 8 * 8192 * 16 and legs["c4"]["gathered"]["xgmi_lower_bound_ms"] > 0
+    assert legs["c4"]["gathered_by_configs"]["equals_unsharded_call"] is True
     assert legs["c5"]["rel_err_vs_analytic"] < 1e-3
+
+
+@pytest.mark.gpu
+def test_a_rank_that_fails_before_a_legs_collectives_does_not_hang_the_others():
+    """Rank 1 raises while preparing the C4 leg (whose packed path all-gathers): every rank skips that leg together -- one
+    all-reduced flag before the leg's first collective -- and the remaining legs and the headline line still come out."""
+    line = run_bench("--gpus", "2", "--share-gpu", "--steps", "5", "--warmup", "2", "--points", "65536", "--small-legs",
+                     "--no-large", "--no-cpu-baseline", "--fail-rank", "1", "--fail-leg", "c4", timeout=300)
+    legs = line["legs"]
+    assert "skipped" in legs["c4"] and legs["c4"]["ranks_without_a_result"] == 2
+    assert "error" not in legs["c5"] and legs["c5"]["rel_err_vs_analytic"] < 1e-3 and "error" not in legs["c4_readme_grid"]
+    assert line["n_gpus"] == 2 and line["value"] > 0
 
 
 @pytest.mark.gpu
@@ -63,6 +77,8 @@ def test_single_rank_line_has_the_contract_fields():
     roof = line["roofline"]
     assert roof["bound"] == "hbm" and roof["unit"] == "GB/s" and abs(roof["frac"] - roof["achieved"] / roof["peak"]) < 1e-9
     assert "SEPARATE" in roof["timing"] and "traffic_source" in roof
+    assert roof["dropin_call"]["ms_per_call"] > 0 and roof["dropin_call"]["queries_per_s"] > 1e9
+    assert "torch_opforop" in line["cpu_baseline"] and "FUSED" in line["cpu_baseline"]["what"]
     assert line["steps"] == 20 and line["warmup"] == 5 and line["n_gpus"] == 1
     assert line["cpu_baseline"]["kind"] == "port" and line["cpu_baseline"]["cores"] >= 1
 

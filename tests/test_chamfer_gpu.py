@@ -49,10 +49,22 @@ def test_chamfer_matches_oracle_and_reference_properties(mesh):
     perturbed_pts = tf.Transform3d(matrix=pert).transform_points(pts)
     gt_manual = torch.cdist(pts_world.expand(B, N, 3), perturbed_pts).min(dim=2).values.square().sum(dim=1)
     assert torch.all(err < gt_manual)
-    # the reference asserts "< 5 % for every pose" with its own (irreproducible) samples; with 1000 surface samples the
-    # point-cloud discretisation is a few % of the smallest distances, so check the bulk and the mean
+    # the reference asserts gt - err < 5 % of gt for EVERY pose (tests/test_chamfer.py:65-66).  The gap is the point cloud's
+    # discretisation: the nearest of N surface SAMPLES is farther than the nearest surface POINT by about h^2 / (2 d) for a
+    # query at distance d and samples h apart, i.e. by a fraction ~ (h / d)^2 of d^2 -- 5 % is reached where the pose's rms
+    # distance is within ~3 sample spacings.  So: every pose satisfies the reference's bound, or is one of those near poses
+    # (measured per failing pose), and none fails by more than the (h / d)^2 estimate allows.
     rel_gap = (gt_manual - err) / gt_manual
-    assert rel_gap.mean() < 0.02 and (rel_gap < 0.05).float().mean() > 0.9
+    nn = torch.cdist(pts, pts)
+    nn.fill_diagonal_(float("inf"))
+    h = nn.min(dim=1).values.mean()  # mean nearest-neighbour spacing of the 1000 samples
+    rms = (gt_manual / N).sqrt()
+    failing = rel_gap >= 0.05
+    print(f"{mesh}: {int(failing.sum())} of {B} poses above 5 %; sample spacing h = {h * 1e3:.2f} mm; failing poses: rms distance / h = "
+          f"{[round(float(x), 2) for x in (rms[failing] / h)]}, gap = {[round(float(x), 3) for x in rel_gap[failing]]}")
+    assert rel_gap.mean() < 0.02
+    assert torch.all(rms[failing] < 3.5 * h), "a pose far from the object exceeds the reference's 5 % bound"
+    assert torch.all(rel_gap[failing] < 1.5 * (h / rms[failing]) ** 2)
 
 
 def test_chamfer_against_cached_sdf_matches_oracle():

@@ -97,9 +97,11 @@ def test_generic_path_with_uncached_leaves_agrees_with_fused_path():
     v2, g2 = generic(pts)
     # torch's matmul rounds differently from the kernel's fma chain: 1e-5 everywhere except where that last-place
     # difference crosses a half-voxel plane or a range edge in some leaf frame -- every such point is accounted for
+    rep = {}
     n_bad, n_unexplained = H.composed_disagreements_explained(leaves, tfm.numpy(), 1, pts.cpu().numpy(),
-                                                              v1.cpu().numpy(), v2.cpu().numpy(), atol=1e-5)
-    print(f"generic vs fused: {n_bad} of {v1.numel()} values differ by more than 1e-5, all on a voxel / range boundary")
+                                                              v1.cpu().numpy(), v2.cpu().numpy(), atol=1e-5, report=rep)
+    print(f"generic vs fused: {n_bad} of {v1.numel()} values differ by more than 1e-5, all within {rep['max_units_needed']:.2f} "
+          "rounding units (bound: 8) of a voxel / range boundary")
     assert n_unexplained == 0 and n_bad < 0.01 * v1.numel()
     close = torch.isclose(v1, v2, atol=1e-5)
     assert torch.allclose(g1[close].nan_to_num(0.), g2[close].nan_to_num(0.), atol=1e-4)

@@ -147,3 +147,31 @@ def test_outside_surface_compares_in_float32_whatever_the_query_dtype():
         assert c.outside_surface(q.cuda(), surface_level=0.0999999).all()
     og = H.oracle_grid_from_cached(c)
     assert not oracle.cached_outside_f64(og, pts.numpy(), 0.1).any() and not oracle.cached_outside(og, pts.float().numpy(), 0.1).any()
+
+
+@pytest.mark.parametrize("A", [1, 7])
+def test_composed_and_robot_keep_float64_points_in_float64(A):
+    """sdf.py:395-431 over sdf.py:545-547: a composition answers float64 points in float64 -- the transform, every leaf's
+    index arithmetic / range test / bounding-box branch and the gradient rotation (round 2 computed in float32 and cast
+    back, which picks other voxels near the half-voxel planes).  Bit-exact vs the oracle's float64 composition."""
+    S = 5
+    leaves = [make_cached(f64=(s % 2 == 0)) for s in range(S)]
+    tfm = H.random_rigid(S * A, seed=31 + A, trans=0.2).double()
+    tfm = tfm + 1e-11 * torch.randn(tfm.shape, dtype=torch.float64, generator=torch.Generator().manual_seed(1)) * \
+        torch.tensor([[1.0], [1.0], [1.0], [0.0]], dtype=torch.float64)  # digits only float64 carries; last row stays 0 0 0 1
+    comp = pv.ComposedSDF(leaves, None)
+    comp.set_transforms(pv.Transform3d(matrix=tfm), batch_dim=(A,) if A > 1 else None, known_rigid=True)
+    g = torch.Generator().manual_seed(3)
+    pts = (torch.rand(30_000, 3, dtype=torch.float64, generator=g) - 0.5) * 0.9
+    val, grad = comp(pts.cuda())
+    assert val.dtype == torch.float64 and grad.dtype == torch.float64
+    assert val.shape == ((A, 30_000) if A > 1 else (30_000,))
+    ogrids = [H.oracle_grid_from_cached(l) for l in leaves]
+    oval, ograd, oleaf = oracle.composed_query_f64(ogrids, tfm.numpy(), A, pts.numpy())
+    assert np.array_equal(val.cpu().numpy().reshape(A, -1), oval, equal_nan=True)
+    assert np.array_equal(grad.cpu().numpy().reshape(A, -1, 3), ograd, equal_nan=True)
+    assert len(np.unique(oleaf)) == S
+    # and it is NOT what the float32 path gives
+    v32, _ = comp(pts.float().cuda())
+    assert v32.dtype == torch.float32
+    assert (v32.double().cpu().numpy().reshape(A, -1) != oval).mean() > 0.01

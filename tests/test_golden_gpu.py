@@ -83,9 +83,11 @@ def test_composed_sdf_reproduces_the_reference_call():
         # 1e-6 everywhere, except where the shims' torch matmul and the kernel's fma chain -- a last-place difference in a
         # leaf-frame coordinate -- land on different sides of a half-voxel plane or a range edge; every such point is
         # accounted for individually (no percentage)
+        rep = {}
         n_bad, n_unexplained = H.composed_disagreements_explained([c, c, c], G[f"composed/{name}/tf"], A,
-                                                                  G["composed/points"], v.cpu().numpy(), rv)
-        print(f"composed/{name}: {n_bad} of {rv.size} values differ by more than 1e-6, all on a voxel / range boundary")
+                                                                  G["composed/points"], v.cpu().numpy(), rv, report=rep)
+        print(f"composed/{name}: {n_bad} of {rv.size} values differ by more than 1e-6, all within {rep['max_units_needed']:.2f} "
+              "rounding units (bound: 8) of a voxel / range boundary")
         assert n_unexplained == 0 and n_bad < 0.01 * rv.size
         close = np.isclose(v.cpu().numpy(), rv, rtol=0, atol=1e-6)
         # gradients of agreeing values: 2e-6, except where two leaves tie in value (either leaf's gradient is a valid

@@ -73,6 +73,23 @@ def _unused_synthetic_arm(tmp, n_links=8):
     return pv.build_serial_chain_from_urdf("\n".join(parts), f"link_{n_links - 1}")
 
 
+def exact_work(config, t):
+    """The work the culling mesh kernels really do: exact closest-point tests (~80 flop) and ray tests (~40 flop) counted by
+    the stats build (profiles/r03_exact_pairs.json, tools/exact_pairs.py), over this run's time.  Round 2 divided the
+    BRUTE-FORCE pair count by the fp32 peak and printed fractions above 1 -- a kernel that culls is not doing that work."""
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", "r03_exact_pairs.json")
+    try:
+        e = json.load(open(path))[config]
+    except Exception:
+        return {"exact_pairs": None, "exact_pairs_note": "profiles/r03_exact_pairs.json not found"}
+    flop = e["closest_pairs"] * FLOP_PER_PAIR_CLOSEST + e["ray_pairs"] * (FLOP_PER_PAIR_QUERY - FLOP_PER_PAIR_CLOSEST)
+    return {"exact_closest_pairs_per_point": e["closest_pairs"] / e["points"], "exact_ray_pairs_per_point": e["ray_pairs"] / e["points"],
+            "exact_test_tflops": flop / t / 1e12, "exact_test_frac_fp32_peak": flop / t / 1e12 / FP32_PEAK,
+            "exact_pairs_source": "profiles/r03_exact_pairs.json (stats build), not measured in this run",
+            "bound": "valu: the broad phase (sphere / rectangle tests, queues), not the exact tests, is most of the instruction "
+                     "stream; see the VALU roofline of bench.py's legs and profiles/r03_valu_counts.json"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--quick", action="store_true")
@@ -93,8 +110,7 @@ def main():
     pairs = 10_000 * obj.num_faces
     out["C1_meshsdf_drill_10k"] = {
         "points": 10_000, "triangles": obj.num_faces, "gpu_s": t, "gpu_points_per_s": 10_000 / t,
-        "gpu_pairs_per_s": pairs / t, "fp32_tflops_at_120flop": pairs * FLOP_PER_PAIR_QUERY / t / 1e12,
-        "frac_fp32_peak": pairs * FLOP_PER_PAIR_QUERY / t / 1e12 / FP32_PEAK,
+        "brute_force_equivalent_pairs_per_s": pairs / t, **exact_work("C1", t),
         "cpu_points_per_s": 2000 / tc, "cpu_note": f"brute-force oracle, {oracle.num_threads()} threads, 2000-point sample "
                                                    "(NOT Embree: not the reference's CPU engine)"}
 
@@ -208,9 +224,8 @@ def main():
     hs = src[:512].cpu().numpy()
     tc = cpu_time(lambda: oracle.chamfer_mesh(osphere, np.eye(4, dtype=np.float32)[None], hs, 1000.0))
     out["C5_chamfer_sphere_99500"] = {
-        "points": N5, "triangles": int(m.faces.shape[0]), "gpu_s": t, "gpu_pairs_per_s": pairs5 / t,
-        "fp32_tflops_at_80flop": pairs5 * FLOP_PER_PAIR_CLOSEST / t / 1e12,
-        "frac_fp32_peak": pairs5 * FLOP_PER_PAIR_CLOSEST / t / 1e12 / FP32_PEAK,
+        "points": N5, "triangles": int(m.faces.shape[0]), "gpu_s": t, "brute_force_equivalent_pairs_per_s": pairs5 / t,
+        **(exact_work("C5", t) if N5 == (1 << 21) else {}),
         "chamfer_vs_analytic_abs_err": abs(err.item() - ref.item()),
         "cpu_pairs_per_s": 512 * m.faces.shape[0] / tc}
     print(json.dumps(out, indent=1))

@@ -1,0 +1,28 @@
+"""One BASELINE workload CALLS times, for a rocprofv3 --pmc pass (tools/valu_counts.sh): c1 | c4 | c5."""
+import os, sys
+sys.path.insert(0, os.getcwd())
+import torch
+import pytorch_volumetric_amd as pv
+import workloads as Wk
+which, calls = sys.argv[1], int(sys.argv[2])
+if which == "c1":  # MeshSDF on the drill, 10k of the 0.002 m grid points (tests/test_sdf.py:46-48 of the reference)
+    drill = Wk.build_drill()
+    sdf = pv.MeshSDF(drill)
+    _, grid_pts = pv.get_coordinates_and_points_in_grid(0.002, drill.bounding_box(0.01))
+    pts = grid_pts[torch.randperm(len(grid_pts), generator=torch.Generator().manual_seed(0))[:10_000]].cuda()
+    fn = lambda: sdf(pts)
+elif which == "c4":
+    robot = Wk.build_c4(0.02, 0.1)
+    A, P = 200, 1 << 18
+    robot.set_joint_configuration(Wk.c4_joint_configs(A))
+    pts = Wk.c4_points(P)
+    val = torch.empty((A, P), dtype=torch.float32, device="cuda"); grad = torch.empty((A, P, 3), dtype=torch.float32, device="cuda")
+    fn = lambda: robot.query_into(pts, val, grad)
+else:
+    mesh = Wk.build_c5_mesh()
+    pts = Wk.c5_points(1 << 21)
+    W = torch.eye(4).unsqueeze(0).cuda()
+    fn = lambda: pv.batch_chamfer_dist(W, pts, obj_factory=mesh, scale=1000.0)
+for _ in range(calls):
+    fn()
+torch.cuda.synchronize()
