@@ -248,6 +248,11 @@ def valu_roofline(kernel_key, ms, launches_per_step=1):
             "slow_opcode_group_ceiling": N_SIMD * VALU_SLOW_RATE_PER_SIMD / 1e9,
             "frac_of_slow_group_ceiling": achieved / (N_SIMD * VALU_SLOW_RATE_PER_SIMD),
             "valu_inst_per_step": inst, "active_lanes_per_inst": entry.get("active_lanes"),
+            "valu_busy_frac_at_2p4GHz": (entry["SQ_ACTIVE_INST_VALU"] * launches_per_step * 4.0 / N_SIMD) / (ms * 1e-3 * 2.4e9)
+            if entry.get("SQ_ACTIVE_INST_VALU") else None,
+            "reading": "`frac` is against the ceiling of a stream of full-rate opcodes; a kernel made of both opcode groups has "
+                       "its own ceiling between `peak` and `slow_opcode_group_ceiling`; `valu_busy_frac_at_2p4GHz` = "
+                       "SQ_ACTIVE_INST_VALU (quad-cycles) x 4 / 1024 SIMDs over this run's time at the nominal clock",
             "source": f"profiles/r03_valu_counts.json[{kernel_key}] = SQ_INSTS_VALU of {entry.get('workload')} "
                       f"({entry.get('command')}); ceilings: profiles/r02_valu_rate.txt (1024 SIMDs x 1 / 1.0 ns for "
                       "v_fma/add/mul/mov, x 1 / 1.8 ns for cmp/cndmask/min/max/med3/cvt/int-mul/pk/f64); read from the "
@@ -322,7 +327,7 @@ def leg_c4(torch, dist, Wk, pv, timer, gate, robots, rank, world, steps, padding
 
     # 100 KB link grids: the allocation-free entry (query_into, what a planner loop would call).  README-size grids: the
     # drop-in call robot(points), which sorts the shared point set once per call and un-permutes (ComposedSDF.bucket_points)
-    bucketed = robot.sdf._bucketing_pays(A, n)
+    bucketed = robot.sdf._bucketing_pays(A, n, mine)
     if bucketed:
         def one_step():
             return robot(mine)

@@ -679,18 +679,45 @@ class ComposedSDF(ObjectFrameSDF):
 
     bucket_points = "auto"  # True / False / "auto": sort the query points spatially before the fused kernel (see __call__)
 
-    def _bucketing_pays(self, A, P):
-        """Sorting the points costs a sort + a second pass over the outputs (~0.5 ms for 200 x 262,144); it pays when
+    def _bucketing_pays(self, A, P, points=None):
+        """Sorting the points costs a sort + a second pass over the outputs (~0.6 ms for 200 x 262,144); it pays when
         the leaf grids are far larger than L2, so that gather locality decides the time, and the sort is shared by enough
         configurations.  Measured on the README-size robot (8 x 21 MB grids, A = 200, P = 262,144 random points):
-        4.9 ms direct, 1.6 ms bucketed; with 100 KB grids the kernel is instruction-bound and bucketing only adds its
-        overhead (0.82 -> 1.1 ms).  Spatially ordered input (grids, slices) needs no sort: pass bucket_points = False."""
+        4.9 ms direct, 1.7 ms bucketed; with 100 KB grids the kernel is instruction-bound and bucketing only adds its
+        overhead (0.82 -> 1.1 ms).  With `points`, "auto" also looks at what the query can touch at all: a planar slice
+        (512 x 512 points in grid order: 0.87 ms direct, 1.25 ms bucketed) cuts each leaf grid in a plane whose cells stay
+        in L2 whatever the order, so it is not sorted; a 64^3 grid in grid order (2.3 ms direct, 1.5 ms bucketed) fills
+        the volume and is (tools/coherent_probe.py, profiles/r03_probes.txt)."""
         if self.bucket_points != "auto":
             return bool(self.bucket_points) and P >= 256
         if not self._fusable():
             return False
         self._leaf_grids(self._owner_device())  # derives _query_flags from the grid sizes
-        return self._query_flags == _lib.COMPOSED_INLINE_EXACT and A >= 8 and P >= 32768 and A * P * 16 <= (8 << 30)
+        if not (self._query_flags & _lib.COMPOSED_INLINE_EXACT and A >= 8 and P >= 32768 and A * P * 16 <= (8 << 30)):
+            return False
+        return points is None or self._footprint_bytes(points) > (8 << 20)
+
+    def _footprint_bytes(self, flat):
+        """Upper estimate of the leaf-grid bytes one configuration's query touches: the cells of the finest leaf grid that
+        the points' bounding box covers (at least one cell thick per axis, at most one per point), a 64-byte line each,
+        for every leaf.  One small kernel + one device->host read (~25 us), remembered per point tensor."""
+        key = (flat.data_ptr(), flat._version, flat.shape[0])
+        hit = self.__dict__.get("_footprint_cache")
+        if hit is not None and hit[0] == key:
+            return hit[1]
+        box = torch.empty((2, 3), dtype=torch.float32, device=flat.device)
+        _lib.check(_lib.load().pvamd_points_aabb(_lib.ptr(flat), flat.shape[0], _lib.ptr(box), _lib.stream_ptr()),
+                   "pvamd_points_aabb")
+        lo, hi = box.cpu().double().unbind(0)
+        extent = (hi - lo).clamp_min(0.0)
+        res = min(float(s._view.dres.min()) for s in self.sdfs)
+        cells = 1.0
+        for d in range(3):
+            e = float(extent[d])
+            cells *= max(1.0, e / res) if math.isfinite(e) else float("inf")
+        out = min(cells, float(flat.shape[0])) * 64.0 * len(self.sdfs)
+        self._footprint_cache = (key, out)
+        return out
 
     def _owner_device(self):
         """The one GPU every leaf grid lives on (the fused kernel reads all of them through raw pointers)."""
@@ -793,7 +820,7 @@ class ComposedSDF(ObjectFrameSDF):
             grad = torch.empty((A, P, 3), dtype=torch.float32, device=dev)
             with _lib.on_device(dev):
                 grids = self._leaf_grids(dev)
-                if self._bucketing_pays(A, P):
+                if self._bucketing_pays(A, P, flat):
                     # one Morton sort of the shared point set, amortised over the A configurations; the kernel then
                     # sees spatially compact wave tiles and a second pass restores the caller's point order
                     _, inv, spts = _lib.morton_order(flat, min_points=0, want_inverse=True, want_sorted=True)

@@ -272,3 +272,32 @@ def test_bucketed_path_returns_the_direct_path_bits_in_caller_order(P):
         assert torch.equal(v_b, v_direct) and torch.equal(g_b.nan_to_num(4.0), g_direct.nan_to_num(4.0))
     robot.sdf.bucket_points = "auto"
     assert robot.sdf._bucketing_pays(200, 1 << 18) and not robot.sdf._bucketing_pays(2, 1 << 18)
+
+
+def test_auto_bucketing_looks_at_what_the_query_can_touch():
+    """bucket_points = "auto" with README-size link grids: random points over the workspace are Morton-sorted; a planar slice
+    in grid order -- the reference README's own query shape (README.md:177-183), larger -- is not (its cut through each leaf
+    grid stays in L2 whatever the order: 0.87 ms direct, 1.25 ms bucketed for 200 x 512 x 512); a 64^3 grid filling the
+    volume is.  Either way the results are the direct path's bits."""
+    import workloads as Wk
+    robot = Wk.build_c4(resolution=0.02, padding=1.0)
+    A = 9
+    robot.set_joint_configuration(Wk.c4_joint_configs(A, seed=5))
+    lo, hi = Wk.ARM_BOX
+    ax = [torch.linspace(lo[d], hi[d], 192) for d in range(3)]
+    slice_pts = torch.cartesian_prod(ax[0], torch.tensor([0.02]), ax[2]).cuda()   # 36,864 points, one plane
+    ax40 = [torch.linspace(lo[d], hi[d], 40) for d in range(3)]
+    cube_pts = torch.cartesian_prod(*ax40).cuda()                                  # 64,000 points, the volume
+    rand_pts = Wk.c4_points(1 << 16, seed=8)
+    comp = robot.sdf
+    assert comp.bucket_points == "auto"
+    assert not comp._bucketing_pays(A, slice_pts.shape[0], slice_pts)
+    assert comp._bucketing_pays(A, cube_pts.shape[0], cube_pts) and comp._bucketing_pays(A, rand_pts.shape[0], rand_pts)
+    assert not comp._bucketing_pays(2, rand_pts.shape[0], rand_pts)  # too few configurations to share a sort
+    for pts in (slice_pts, cube_pts):
+        comp.bucket_points = "auto"
+        v_auto, g_auto = robot(pts)
+        comp.bucket_points = True
+        v_b, g_b = robot(pts)
+        assert torch.equal(v_auto, v_b) and torch.equal(g_auto.nan_to_num(4.0), g_b.nan_to_num(4.0))
+    comp.bucket_points = "auto"

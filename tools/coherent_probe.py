@@ -20,5 +20,5 @@ for padding in (1.0, 0.1):
             robot.sdf.bucket_points = mode
             out.append(gpu_ms(lambda: robot(pts), reps=10)[0])
         robot.sdf.bucket_points = "auto"
-        picks = robot.sdf._bucketing_pays(200, pts.shape[0])
+        picks = robot.sdf._bucketing_pays(200, pts.shape[0], pts)
         print(f"padding {padding}, {name}: direct %.3f ms | bucketed %.3f ms | auto %.3f ms (auto sorts: {picks})" % tuple(out))
