@@ -22,6 +22,7 @@ import json
 import os
 import socket
 import sys
+import threading
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -57,6 +58,10 @@ def parse_args():
     ap.add_argument("--force-pg", action="store_true",
                     help="test hook: create the process group and run the gather / all-reduce legs even with ONE rank "
                          "(exercises the RCCL calls on a 1-GPU box)")
+    ap.add_argument("--legs-deadline", type=float, default=420.0,
+                    help="seconds after which a multi-rank run stops waiting for its legs: rank 0 prints the line with the legs "
+                         "it has and every rank exits (a rank lost INSIDE a collective must not cost the headline)")
+    ap.add_argument("--hang-rank", type=int, default=-1, help="test hook: this rank sleeps forever inside --fail-leg, after its gate")
     ap.add_argument("--fail-rank", type=int, default=-1, help="test hook: this rank raises while preparing --fail-leg")
     ap.add_argument("--fail-leg", default="", help="test hook: see --fail-rank")
     ap.add_argument("--launch-check", action="store_true",
@@ -494,7 +499,8 @@ def main():
         os.environ.setdefault("RANK", "0")
         os.environ.setdefault("WORLD_SIZE", "1")
         import datetime
-        limit = datetime.timedelta(seconds=180)  # a rank lost inside a collective ends the run in minutes, not the default half hour
+        # longer than --legs-deadline: the deadline (which keeps the headline) must fire before the watchdog tears the job down
+        limit = datetime.timedelta(seconds=args.legs_deadline + 120)
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank), timeout=limit)
         else:
@@ -586,6 +592,49 @@ def main():
         }
 
     legs = {}
+    emitted = threading.Lock()
+
+    def emit(final):
+        """rank 0: the ONE JSON line, last on stdout (RCCL prints a version banner through C stdio, which would otherwise be
+        flushed after Python's own buffer at exit)."""
+        if not emitted.acquire(blocking=False):
+            return
+        if rank == 0:
+            import ctypes
+            sys.stdout.flush()
+            try:
+                ctypes.CDLL(None).fflush(None)
+            except Exception:
+                pass
+            print(json.dumps(final), flush=True)
+
+    def on_deadline():
+        # a rank is lost inside a leg's collective (the gate only covers failures BEFORE it): keep the headline
+        if rank == 0:
+            out["legs"] = dict(legs)
+            out["legs_aborted"] = (f"deadline of {args.legs_deadline:.0f} s passed while the legs were running (a rank stuck in a "
+                                   "collective?); the legs listed are those that had finished on rank 0")
+        emit(out)
+        sys.stdout.flush()
+        os._exit(0)
+
+    guard = None
+    if use_pg and not args.no_legs:
+        guard = threading.Timer(args.legs_deadline, on_deadline)
+        guard.daemon = True
+        guard.start()
+        if world > 1:
+            # torchrun answers a worker that died (a crash inside a leg on another GPU) with SIGTERM to the others: rank 0 uses
+            # it to print what it has.  The main thread may be blocked inside a collective, where a Python signal handler
+            # would never run -- so SIGTERM is blocked in every thread and a helper thread waits for it.
+            import signal
+            signal.pthread_sigmask(signal.SIG_BLOCK, {signal.SIGTERM})
+
+            def on_sigterm():
+                signal.sigwait({signal.SIGTERM})
+                on_deadline()
+
+            threading.Thread(target=on_sigterm, daemon=True).start()
     if not args.no_legs:
         leg_steps = 20
         sm = args.small_legs
@@ -601,6 +650,9 @@ def main():
             try:
                 if rank == args.fail_rank and name == args.fail_leg:
                     raise RuntimeError(f"--fail-rank {rank} --fail-leg {name}: forced failure before the leg's gate")
+                if rank == args.hang_rank and name == args.fail_leg:
+                    gate()
+                    time.sleep(1e6)  # "lost inside the leg": the other ranks wait in its first collective
                 legs[name] = fn(gate)
             except LegSkipped:
                 legs[name] = {"skipped": "another rank failed while preparing this leg; every rank skipped it together"}
@@ -682,17 +734,11 @@ def main():
             out["cpu_baseline"] = cpu_baseline(torch, np, cached, pts, args.cpu_seconds)
     if use_pg:
         dist.barrier()
+    if guard is not None:
+        guard.cancel()
+    if use_pg:
         dist.destroy_process_group()
-    if rank == 0:
-        # the JSON line is the LAST thing on stdout: RCCL prints a version banner through C stdio, which would otherwise
-        # be flushed after Python's own buffer at exit
-        import ctypes
-        sys.stdout.flush()
-        try:
-            ctypes.CDLL(None).fflush(None)
-        except Exception:
-            pass
-        print(json.dumps(out), flush=True)
+    emit(out)
 
 
 if __name__ == "__main__":

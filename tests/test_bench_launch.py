@@ -69,6 +69,17 @@ def test_a_rank_that_fails_before_a_legs_collectives_does_not_hang_the_others():
 
 
 @pytest.mark.gpu
+def test_a_rank_lost_inside_a_leg_costs_the_legs_not_the_headline():
+    """Rank 1 passes the C4 leg's gate and then never arrives at its first collective (the case the gate cannot see): after
+    --legs-deadline rank 0 prints the line -- headline, roofline, the legs finished so far -- and every rank exits 0."""
+    line = run_bench("--gpus", "2", "--share-gpu", "--steps", "5", "--warmup", "2", "--points", "65536", "--small-legs",
+                     "--no-large", "--no-cpu-baseline", "--hang-rank", "1", "--fail-leg", "c4", "--legs-deadline", "45",
+                     timeout=300)
+    assert "legs_aborted" in line and line["n_gpus"] == 2 and line["value"] > 0 and "roofline" in line
+    assert "c4" not in line["legs"] or "error" in line["legs"]["c4"]
+
+
+@pytest.mark.gpu
 def test_single_rank_line_has_the_contract_fields():
     line = run_bench("--steps", "20", "--warmup", "5", "--small-legs", "--no-large", "--cpu-seconds", "0.5")
     for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
