@@ -434,6 +434,25 @@ def leg_readme(torch, np, Wk, pv, timer, gate, robots, rank, world, A):
             "why_not": "synthetic 7-DOF arm with 8 ellipsoid links (KUKA assets unavailable offline); different GPU"}
 
 
+def leg_c1(torch, np, Wk, pv, gate, world):
+    """BASELINE configs[0]: MeshSDF on the YCB drill (15,728 triangles), 10,000 of the 0.002 m grid points (the reference's
+    tests/test_sdf.py:46-48) -- the reference's CPU path (Embree) config, here one call of the GPU mesh query (point sort +
+    list / parts / finish launches).  Every rank runs the whole case (replicas)."""
+    drill = Wk.build_drill()
+    sdf = pv.MeshSDF(drill)
+    _, grid_pts = pv.get_coordinates_and_points_in_grid(0.002, drill.bounding_box(0.01))
+    pts = grid_pts[torch.randperm(len(grid_pts), generator=torch.Generator().manual_seed(0))[:10_000]].cuda()
+    sdf(pts)
+    gate()
+    call_ms, synced_ms = time_calls(torch, np, lambda: sdf(pts), reps=100)
+    return {"config": f"C1: MeshSDF on YcbPowerDrill ({drill.num_faces} triangles), 10,000 grid points, one call",
+            "scaling": "replicas", "n_gpus": world, "unit": "points/s", "value": 10_000 / (call_ms * 1e-3),
+            "ms_per_call": call_ms, "ms_per_call_synchronized_each": synced_ms,
+            "roofline": valu_roofline("c1_mesh_query", call_ms),
+            "note": "a 10,000-point call is latency- as much as throughput-bound (four dependent launches): the VALU roofline "
+                    "says how busy the ALUs are, not that they are the limit"}
+
+
 def leg_c5(torch, dist, Wk, pv, timer, gate, rank, world, steps, small=False, use_pg=False):
     """BASELINE configs[4]: unidirectional chamfer, 2,097,152 source points -> 99,500-triangle mesh, the source
     points sharded over the ranks; each rank reduces its slice, then ONE all-reduce of B float64 partial sums (+ the
@@ -643,7 +662,8 @@ def main():
                 ("c4_readme_grid", lambda g: leg_c4(torch, dist, Wk, pv, timer, g, robots, rank, world, leg_steps, 1.0, False, sm)),
                 ("c5", lambda g: leg_c5(torch, dist, Wk, pv, timer, g, rank, world, 5, sm, use_pg))]
         if not sm:
-            spec += [("readme_a20", lambda g: leg_readme(torch, np, Wk, pv, timer, g, robots, rank, world, 20)),
+            spec += [("c1", lambda g: leg_c1(torch, np, Wk, pv, g, world)),
+                     ("readme_a20", lambda g: leg_readme(torch, np, Wk, pv, timer, g, robots, rank, world, 20)),
                      ("readme_a200", lambda g: leg_readme(torch, np, Wk, pv, timer, g, robots, rank, world, 200))]
         for name, fn in spec:
             gate = Gate(torch, dist, use_pg)

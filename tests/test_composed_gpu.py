@@ -341,3 +341,24 @@ def test_seventy_thousand_configurations_go_out_in_slabs(flags):
     oval, ograd, _ = oracle.composed_query([H.oracle_grid_from_cached(l) for l in leaves], tfm.numpy(), A, pts.numpy())
     assert np.array_equal(val.cpu().numpy(), oval, equal_nan=True)
     assert np.array_equal(grad.cpu().numpy(), ograd, equal_nan=True)
+
+
+def test_bucketed_and_packed_paths_take_more_than_65535_configurations():
+    """The packed / bucketed entries carry the configuration in blockIdx.x, like the direct one: no 65,535 limit (round 2
+    returned PVAMD_E_SHAPE and ShardedSDF fell back to its two-collective path)."""
+    S, A, P = 2, 66_000, 300
+    leaves = [make_leaf(res=0.02) for _ in range(S)]
+    tfm = H.random_rigid(S * A, seed=16, trans=0.3)
+    comp = pv.ComposedSDF(leaves, None)
+    comp.set_transforms(pv.Transform3d(matrix=tfm), batch_dim=(A,), known_rigid=True)
+    pts = scene_points(P, seed=12, extent=0.4).cuda()
+    comp.bucket_points = True
+    val, grad = comp(pts)
+    comp.bucket_points = False
+    v_direct, g_direct = comp(pts)
+    assert torch.equal(val, v_direct) and torch.equal(grad.nan_to_num(3.0), g_direct.nan_to_num(3.0))
+    pick = [0, 1, 65_534, 65_535, 65_536, A - 1]
+    oval, ograd, _ = oracle.composed_query([H.oracle_grid_from_cached(l) for l in leaves],
+                                           tfm.reshape(S, A, 4, 4)[:, pick].reshape(-1, 4, 4).numpy(), len(pick), pts.cpu().numpy())
+    assert np.array_equal(val[pick].cpu().numpy(), oval, equal_nan=True)
+    assert np.array_equal(grad[pick].cpu().numpy(), ograd, equal_nan=True)
