@@ -73,7 +73,7 @@ def test_a_rank_lost_inside_a_leg_costs_the_legs_not_the_headline():
     """Rank 1 passes the C4 leg's gate and then never arrives at its first collective (the case the gate cannot see): after
     --legs-deadline rank 0 prints the line -- headline, roofline, the legs finished so far -- and every rank exits 0."""
     line = run_bench("--gpus", "2", "--share-gpu", "--steps", "5", "--warmup", "2", "--points", "65536", "--small-legs",
-                     "--no-large", "--no-cpu-baseline", "--hang-rank", "1", "--fail-leg", "c4", "--legs-deadline", "45",
+                     "--no-large", "--no-cpu-baseline", "--hang-rank", "1", "--fail-leg", "c4", "--legs-deadline", "20",
                      timeout=300)
     assert "legs_aborted" in line and line["n_gpus"] == 2 and line["value"] > 0 and "roofline" in line
     assert "c4" not in line["legs"] or "error" in line["legs"]["c4"]
