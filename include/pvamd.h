@@ -328,6 +328,16 @@ int pvamd_sample_surface(const float* tri, const double* cdf, int32_t F, int64_t
 int pvamd_chamfer_mesh(const pvamd_mesh_t* mesh, const float* W, int32_t B, const float* points,
                        const int32_t* order, int64_t N, float scale, double* out_sum, void* scratch, void* stream);
 
+/* The same sums when the caller has ALREADY transformed the points: points holds x[b][n] = W[b] p[n] for all B transforms
+ * ([B][per][3], e.g. from pvamd_transform_points, whose rounding is the chamfer kernel's), and `order` walks all B * per
+ * of them in ONE spatial order (pvamd_morton_order over the flat array).  Point i adds to out_sum[i / per].  What
+ * pairwise_distance_chamfer / PlausibleDiversity want (chamfer.py:20-59,173-183: 10^4 transforms x 500 model points): with
+ * few points per transform the 64 points a wave of pvamd_chamfer_mesh shares are a whole patch of the object apart and its
+ * bounds cull little; in one global order they are neighbours (100 x 100 poses x 500 points on the drill: 12.3 -> 3.5 ms).
+ * out_sum: device [B] float64, zeroed by this call.  scratch: PVAMD_MESH_SCRATCH_BYTES(B * per) bytes or NULL.          */
+int pvamd_chamfer_mesh_flat(const pvamd_mesh_t* mesh, int32_t B, const float* points, const int32_t* order, int64_t per,
+                            float scale, double* out_sum, void* scratch, void* stream);
+
 /* Same against a cached grid (obj_sdf branch, chamfer.py:84-85).  grid: host.                            */
 int pvamd_chamfer_grid(const pvamd_grid_t* grid, const float* W, int32_t B, const float* points, int64_t N,
                        float scale, double* out_sum, void* stream);

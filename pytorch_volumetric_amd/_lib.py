@@ -156,6 +156,8 @@ SIGNATURES = {
     "pvamd_chamfer_mesh": (ctypes.c_int, [ctypes.POINTER(MeshDesc), ctypes.c_void_p, ctypes.c_int32, ctypes.c_void_p,
                                           ctypes.c_void_p, ctypes.c_int64, ctypes.c_float, ctypes.c_void_p, ctypes.c_void_p,
                                           ctypes.c_void_p]),
+    "pvamd_chamfer_mesh_flat": (ctypes.c_int, [ctypes.POINTER(MeshDesc), ctypes.c_int32, ctypes.c_void_p, ctypes.c_void_p,
+                                               ctypes.c_int64, ctypes.c_float, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]),
     "pvamd_chamfer_grid": (ctypes.c_int, [ctypes.POINTER(GridDesc), ctypes.c_void_p, ctypes.c_int32, ctypes.c_void_p,
                                           ctypes.c_int64, ctypes.c_float, ctypes.c_void_p, ctypes.c_void_p]),
     "pvamd_chain_fk": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int32, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,

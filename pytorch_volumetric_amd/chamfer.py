@@ -23,6 +23,16 @@ def pairwise_distance(world_to_link_tfs):
     return torch.cdist(cont_rep, cont_rep)
 
 
+FLAT_MAX_POINTS_PER_TRANSFORM = 16384  # above this a transform's own points fill its waves with neighbours
+FLAT_MAX_TOTAL_POINTS = 1 << 26        # the transformed copy is B * N * 12 bytes
+
+
+def flat_call_pays(B, N):
+    """Whether batch_chamfer_dist against a mesh transforms all B x N points first and queries them in one spatial order
+    (pvamd_chamfer_mesh_flat) instead of launching per (transform, 64 points of that transform)."""
+    return B >= 2 and 0 < N <= FLAT_MAX_POINTS_PER_TRANSFORM and B * N <= FLAT_MAX_TOTAL_POINTS
+
+
 def batch_chamfer_dist(world_to_object: torch.tensor, model_points_world_frame_eval: torch.tensor,
                        obj_factory: ObjectFactory = None, obj_sdf: ObjectFrameSDF = None, viewing_delay=0, scale=1000.,
                        print_err=False, vis=None, reduce_group=None):
@@ -66,12 +76,28 @@ def batch_chamfer_dist(world_to_object: torch.tensor, model_points_world_frame_e
             sums = ((float(scale) * d.to(device=dev, dtype=torch.float32)) ** 2).double().sum(dim=-1)
         else:
             desc = obj_factory._mesh_desc()
-            order = _lib.morton_order(pts)
-            # slots for the point groups the kernel hands over (those about equidistant to much of the mesh)
-            scratch = torch.empty((_lib.mesh_scratch_bytes(N) // 8,), dtype=torch.int64, device=dev)
-            _lib.check(lib.pvamd_chamfer_mesh(ctypes.byref(desc), _lib.ptr(Wd), B, _lib.ptr(pts), _lib.ptr(order), N,
-                                              float(scale), _lib.ptr(sums), _lib.ptr(scratch), _lib.stream_ptr()),
-                       "pvamd_chamfer_mesh")
+            if flat_call_pays(B, N):
+                # many transforms x few points (pairwise_distance_chamfer / PlausibleDiversity: 10^4 x 500): transform all
+                # B * N points once, walk them in ONE spatial order (the 64 points of a wave are then neighbours in space,
+                # whichever transform they came from) and let every point add to its own transform's sum
+                x = torch.empty((B, N, 3), dtype=torch.float32, device=dev)
+                for b0 in range(0, B, 65535):  # the transform kernel carries the transform in a grid dimension
+                    nb = min(65535, B - b0)
+                    _lib.check(lib.pvamd_transform_points(_lib.ptr(Wd[b0:b0 + nb]), nb, _lib.ptr(pts), N, _lib.ptr(x[b0:b0 + nb]),
+                                                          _lib.stream_ptr()), "pvamd_transform_points")
+                flat = x.view(-1, 3)
+                order = _lib.morton_order(flat)
+                scratch = torch.empty((_lib.mesh_scratch_bytes(B * N) // 8,), dtype=torch.int64, device=dev)
+                _lib.check(lib.pvamd_chamfer_mesh_flat(ctypes.byref(desc), B, _lib.ptr(flat), _lib.ptr(order), N, float(scale),
+                                                       _lib.ptr(sums), _lib.ptr(scratch), _lib.stream_ptr()),
+                           "pvamd_chamfer_mesh_flat")
+            else:
+                order = _lib.morton_order(pts)
+                # slots for the point groups the kernel hands over (those about equidistant to much of the mesh)
+                scratch = torch.empty((_lib.mesh_scratch_bytes(N) // 8,), dtype=torch.int64, device=dev)
+                _lib.check(lib.pvamd_chamfer_mesh(ctypes.byref(desc), _lib.ptr(Wd), B, _lib.ptr(pts), _lib.ptr(order), N,
+                                                  float(scale), _lib.ptr(sums), _lib.ptr(scratch), _lib.stream_ptr()),
+                           "pvamd_chamfer_mesh")
     total_n = N
     if reduce_group is not None:
         import torch.distributed as dist

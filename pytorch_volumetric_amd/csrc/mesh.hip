@@ -865,8 +865,11 @@ PVAMD_DEV V3 chamfer_point(const float* __restrict__ M, const float* __restrict_
               add_rn(fmaf(M[10], pz, fmaf(M[9], py, mul_rn(M[8], px))), M[11]));
 }
 
-// one wave's share of sum((scale * d)^2) from the winning (d2, face) of each of its points
-PVAMD_DEV void chamfer_accumulate(const MeshArgs& m, V3 p, bool live, unsigned long long found, float scale, double* __restrict__ sum) {
+// one wave's share of sum((scale * d)^2) from the winning (d2, face) of each of its points.  per == 0: the wave's points
+// belong to ONE transform, whose sum is `sum`: a wave reduction and one atomic.  per > 0 (flat call: the points of all
+// transforms, already transformed, in ONE spatial order): point i belongs to transform i / per -- one atomic per lane.
+PVAMD_DEV void chamfer_accumulate(const MeshArgs& m, V3 p, bool live, unsigned long long found, float scale, double* __restrict__ sum,
+                                  int64_t i = 0, int64_t per = 0) {
     const int best_f = (unsigned)(found >> 32) == 0x7F800000u ? -1 : (int)(unsigned)found;
     double acc = 0.0;
     if (live && best_f >= 0) {
@@ -874,26 +877,32 @@ PVAMD_DEV void chamfer_accumulate(const MeshArgs& m, V3 p, bool live, unsigned l
         const float sd = mul_rn(scale, norm3_unfused(sub(q, p)));  // chamfer.py:92
         acc = (double)mul_rn(sd, sd);
     }
+    if (per > 0) {
+        if (live && best_f >= 0) atomicAdd(sum + i / per, acc);
+        return;
+    }
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off, 64);
     if ((threadIdx.x & 63) == 0) atomicAdd(sum, acc);
 }
 
-// grid: x = groups of 64 points, y = transform b (b0 = the slab's first transform)
+// grid: x = groups of 64 points, y = transform b (b0 = the slab's first transform).  W == nullptr: the flat call (see
+// chamfer_accumulate) -- `pts` are the N = B * per transformed points of all transforms, y = 1.
 template <int SLICES>
 __global__ __launch_bounds__(64 * SLICES) void chamfer_mesh_kernel(MeshArgs m, const int* __restrict__ order,
                                                                   const float* __restrict__ W, int b0,
                                                                   const float* __restrict__ pts, int64_t N, float scale,
-                                                                  double* __restrict__ out_sum, HandOver ho) {
+                                                                  double* __restrict__ out_sum, HandOver ho, int64_t per) {
     __shared__ __attribute__((aligned(16))) MeshShared<SLICES, false> sh;
     const int b = b0 + (int)blockIdx.y;
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int64_t k = (int64_t)blockIdx.x * 64 + lane;
+    const int64_t i = point_index(order, k, N);
     Wave<false> wv;
-    wv.s.p = chamfer_point(W + 16 * (int64_t)b, pts, point_index(order, k, N));
+    wv.s.p = W ? chamfer_point(W + 16 * (int64_t)b, pts, i) : v3(pts[3 * i], pts[3 * i + 1], pts[3 * i + 2]);
     if (scan_mesh<SLICES, false>(m, sh, wv, wave, 0, 0, ho, (int)blockIdx.x, b)) return;
     if (wave != 0) return;
-    chamfer_accumulate(m, wv.s.p, k < N, sh.g.best[lane], scale, out_sum + b);
+    chamfer_accumulate(m, wv.s.p, k < N, sh.g.best[lane], scale, W ? out_sum + b : out_sum, i, W ? 0 : per);
 }
 
 // ---- the listed groups: tiles spread over blocks ----------------------------------------------------------------
@@ -1027,13 +1036,14 @@ __global__ __launch_bounds__(64) void mesh_query_finish_kernel(MeshArgs m, const
 
 __global__ __launch_bounds__(64) void chamfer_finish_kernel(MeshArgs m, const int* __restrict__ order, const float* __restrict__ W,
                                                             const float* __restrict__ pts, int64_t N, float scale, HandOver ho,
-                                                            double* __restrict__ out_sum) {
+                                                            double* __restrict__ out_sum, int64_t per) {
     const int listed = min(*ho.count, ho.cap);
     for (int slot = blockIdx.x; slot < listed; slot += gridDim.x) {
         const int64_t k = (int64_t)ho.entries[2 * slot] * 64 + threadIdx.x;
         const int b = ho.entries[2 * slot + 1];
-        const V3 p = chamfer_point(W + 16 * (int64_t)b, pts, point_index(order, k, N));
-        chamfer_accumulate(m, p, k < N, ho.best[(int64_t)slot * 64 + threadIdx.x], scale, out_sum + b);
+        const int64_t i = point_index(order, k, N);
+        const V3 p = W ? chamfer_point(W + 16 * (int64_t)b, pts, i) : v3(pts[3 * i], pts[3 * i + 1], pts[3 * i + 2]);
+        chamfer_accumulate(m, p, k < N, ho.best[(int64_t)slot * 64 + threadIdx.x], scale, W ? out_sum + b : out_sum, i, W ? 0 : per);
     }
 }
 
@@ -1251,8 +1261,9 @@ extern "C" int pvamd_mesh_query(const pvamd_mesh_t* mesh, const float* points, c
     return (int)hipGetLastError();
 }
 
-extern "C" int pvamd_chamfer_mesh(const pvamd_mesh_t* mesh, const float* W, int32_t B, const float* points,
-                                  const int32_t* order, int64_t N, float scale, double* out_sum, void* scratch, void* stream) {
+// W != nullptr: B transforms x N points, grid (groups, B).  W == nullptr: the flat call -- N = B * per transformed points.
+static int launch_chamfer_mesh(const pvamd_mesh_t* mesh, const float* W, int32_t B, const float* points, const int32_t* order,
+                               int64_t N, int64_t per, float scale, double* out_sum, void* scratch, void* stream) {
     if (B < 0 || N < 0) return PVAMD_E_SHAPE;
     if (B == 0) return 0;
     if (!mesh || !out_sum) return PVAMD_E_NULL;
@@ -1261,7 +1272,7 @@ extern "C" int pvamd_chamfer_mesh(const pvamd_mesh_t* mesh, const float* W, int3
     hipStream_t s = (hipStream_t)stream;
     hipLaunchKernelGGL(zero_f64_kernel, dim3((B + 255) / 256), dim3(256), 0, s, out_sum, B);
     if (N == 0 || mesh->F == 0) return (int)hipGetLastError();
-    if (!W || !points || !mesh->rec || !mesh->tiles || !mesh->rec_of_face) return PVAMD_E_NULL;
+    if (!points || !mesh->rec || !mesh->tiles || !mesh->rec_of_face) return PVAMD_E_NULL;
     if (mesh->F > kMaxFaces) return PVAMD_E_SHAPE;
     const MeshArgs m = mesh_args(*mesh);
     const int64_t groups = (N + 63) / 64;
@@ -1269,23 +1280,36 @@ extern "C" int pvamd_chamfer_mesh(const pvamd_mesh_t* mesh, const float* W, int3
     const int ntiles = (mesh->F + kTile - 1) / kTile;
     const int cap = (int)(groups < kHandOverCap ? groups : kHandOverCap);
     const HandOver ho = hand_over(ntiles >= kHeavyMinTiles ? scratch : nullptr, cap);
-    const int slices = pick_slices(groups * (int64_t)B, ntiles, ho.cap > 0);
+    const int32_t ny = W ? B : 1;
+    const int slices = pick_slices(groups * (int64_t)ny, ntiles, ho.cap > 0);
     if (ho.cap > 0) hipLaunchKernelGGL(hand_over_none_kernel, dim3(1), dim3(1), 0, s, ho);
     // y-dimension of a HIP grid is limited to 65535: walk B in slabs
-    for (int32_t b0 = 0; b0 < B; b0 += 65535) {
-        const int32_t nb = (B - b0) < 65535 ? (B - b0) : 65535;
+    for (int32_t b0 = 0; b0 < ny; b0 += 65535) {
+        const int32_t nb = (ny - b0) < 65535 ? (ny - b0) : 65535;
         const dim3 grid((unsigned)groups, nb);
         switch (slices) {
-            case 8: hipLaunchKernelGGL((chamfer_mesh_kernel<8>), grid, dim3(512), 0, s, m, order, W, b0, points, N, scale, out_sum, ho); break;
-            case 4: hipLaunchKernelGGL((chamfer_mesh_kernel<4>), grid, dim3(256), 0, s, m, order, W, b0, points, N, scale, out_sum, ho); break;
-            case 2: hipLaunchKernelGGL((chamfer_mesh_kernel<2>), grid, dim3(128), 0, s, m, order, W, b0, points, N, scale, out_sum, ho); break;
-            default: hipLaunchKernelGGL((chamfer_mesh_kernel<1>), grid, dim3(64), 0, s, m, order, W, b0, points, N, scale, out_sum, ho); break;
+            case 8: hipLaunchKernelGGL((chamfer_mesh_kernel<8>), grid, dim3(512), 0, s, m, order, W, b0, points, N, scale, out_sum, ho, per); break;
+            case 4: hipLaunchKernelGGL((chamfer_mesh_kernel<4>), grid, dim3(256), 0, s, m, order, W, b0, points, N, scale, out_sum, ho, per); break;
+            case 2: hipLaunchKernelGGL((chamfer_mesh_kernel<2>), grid, dim3(128), 0, s, m, order, W, b0, points, N, scale, out_sum, ho, per); break;
+            default: hipLaunchKernelGGL((chamfer_mesh_kernel<1>), grid, dim3(64), 0, s, m, order, W, b0, points, N, scale, out_sum, ho, per); break;
         }
     }
     if (ho.cap > 0) {
         hipLaunchKernelGGL((mesh_parts_kernel<false>), dim3(list_blocks(ho.cap), kHeavyParts), dim3(kTile), 0, s, m, order, W, points,
                            N, (uint64_t)0, (int64_t)0, ho);
-        hipLaunchKernelGGL(chamfer_finish_kernel, dim3(list_blocks(ho.cap)), dim3(64), 0, s, m, order, W, points, N, scale, ho, out_sum);
+        hipLaunchKernelGGL(chamfer_finish_kernel, dim3(list_blocks(ho.cap)), dim3(64), 0, s, m, order, W, points, N, scale, ho, out_sum, per);
     }
     return (int)hipGetLastError();
+}
+
+extern "C" int pvamd_chamfer_mesh(const pvamd_mesh_t* mesh, const float* W, int32_t B, const float* points,
+                                  const int32_t* order, int64_t N, float scale, double* out_sum, void* scratch, void* stream) {
+    if (B > 0 && N > 0 && !W) return PVAMD_E_NULL;
+    return launch_chamfer_mesh(mesh, W, B, points, order, N, 0, scale, out_sum, scratch, stream);
+}
+
+extern "C" int pvamd_chamfer_mesh_flat(const pvamd_mesh_t* mesh, int32_t B, const float* points, const int32_t* order,
+                                       int64_t per, float scale, double* out_sum, void* scratch, void* stream) {
+    if (per < 0) return PVAMD_E_SHAPE;
+    return launch_chamfer_mesh(mesh, nullptr, B, points, order, (int64_t)B * per, per, scale, out_sum, scratch, stream);
 }

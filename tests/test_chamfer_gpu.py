@@ -149,3 +149,25 @@ def test_full_size_c5_properties():
     ea = pv.batch_chamfer_dist(W, pts[:half], obj, scale=1.0)
     eb = pv.batch_chamfer_dist(W, pts[half:], obj, scale=1.0)
     assert abs(0.5 * (ea.item() + eb.item()) - e1.item()) <= 1e-6 * e1.item()
+
+
+def test_flat_call_equals_the_per_transform_call(monkeypatch):
+    """Many transforms x few points (pairwise_distance_chamfer, chamfer.py:20-59): batch_chamfer_dist transforms all B x N
+    points once and queries them in one spatial order (pvamd_chamfer_mesh_flat).  Every point's distance is the same
+    float32 number either way -- the sums differ only by the order of the float64 additions -- and both match the oracle."""
+    from pytorch_volumetric_amd import chamfer
+    obj = pv.MeshObjectFactory(H.mesh_path("ycb_power_drill.npz"))
+    pts, _, _ = pv.sample_mesh_points(obj, name="drill", num_points=500, dbpath=None)
+    T = H.random_rigid(40, seed=1, trans=0.05)
+    W = torch.einsum("bij,pjk->bpik", tf.rigid_inverse(T), H.random_rigid(30, seed=2, trans=0.05)).reshape(-1, 4, 4)
+    assert chamfer.flat_call_pays(W.shape[0], 500)
+    flat = pv.batch_chamfer_dist(W, pts, obj).double()
+    monkeypatch.setattr(chamfer, "FLAT_MAX_POINTS_PER_TRANSFORM", 0)
+    assert not chamfer.flat_call_pays(W.shape[0], 500)
+    per_tf = pv.batch_chamfer_dist(W, pts, obj).double()
+    assert torch.allclose(flat, per_tf, rtol=1e-12, atol=0)
+    oerr = oracle.chamfer_mesh(H.oracle_mesh_from_factory(obj), W.numpy()[:64], pts.numpy(), scale=1000.0) / 500
+    assert np.allclose(flat[:64].numpy(), oerr, rtol=1e-6)
+    # and through the caller: the (B, P) matrix of pairwise_distance_chamfer
+    m = pv.pairwise_distance_chamfer(T[:7], obj_factory=obj, model_points_eval=pts)
+    assert m.shape == (7, 7) and torch.allclose(m.diagonal(), torch.zeros(7), atol=1e-3)
