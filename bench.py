@@ -360,6 +360,11 @@ def leg_c4(torch, dist, Wk, pv, timer, gate, robots, rank, world, steps, padding
                                           "note": "16 B written per pair; NOT what bounds this kernel"}}}
     if not bucketed and not small and world == 1:
         out["sharded"]["roofline"] = valu_roofline("c4_composed_query_wave", t / steps * 1e3)
+    if bucketed:
+        out["sharded"]["bound"] = ("L1->L2 request rate: the un-permute pass is A x P 16-byte gathers (one request each) at the "
+                                   "chip's gather ceiling of ~1.15e11/s (profiles/r03_cq64_counters.md) = "
+                                   f"{A * n / 1.15e11 * 1e3:.2f} ms of this step, the sorted query kernel is gather-bound at ~90 % L2 "
+                                   "hits (profiles/r02_readme_grid_counters.txt); the direct, unsorted call takes ~3x as long")
     if with_gather and (world > 1 or use_pg):
         sharded = pv.ShardedSDF(robot, gather=True, compute_device=torch.device("cuda"))
         gsteps = max(2, steps // 4)
