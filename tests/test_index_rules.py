@@ -208,3 +208,42 @@ def test_the_rules_do_differ_where_they_should(index_rule):
     for rule in RULES[1:6]:
         index_rule(rule)
         assert torch.equal(_leaf(True)(inner.cuda())[0], base)
+
+
+@pytest.mark.parametrize("rule", [0, ON_INDEX, HALF_AWAY, FLOOR_HALF, ON_INDEX | HALF_AWAY, ON_INDEX | FLOOR_HALF])
+def test_the_rule_of_a_given_view_is_detected(rule):
+    """tools/detect_index_rule.py probes a value-range view (the real multidim_indexing one, once a maintainer has it) and
+    names the rule to set; here against stand-in views that implement each rule with torch ops."""
+    import importlib.util
+    import os
+    spec = importlib.util.spec_from_file_location("detect_index_rule", os.path.join(os.path.dirname(os.path.dirname(
+        os.path.abspath(__file__))), "tools", "detect_index_rule.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+
+    class View:
+        def __init__(self, source, value_ranges=None, invalid_value=-1):
+            self.shape = source.shape
+            self._min = torch.tensor([min(r) for r in value_ranges])
+            self._max = torch.tensor([max(r) for r in value_ranges])
+            self._resolution = (self._max - self._min) / (torch.tensor(self.shape) - 1)
+
+        def _rounded(self, key):
+            q = (key - self._min) / self._resolution
+            if rule & HALF_AWAY:
+                return torch.sign(q) * torch.floor(torch.abs(q) + 0.5)
+            if rule & FLOOR_HALF:
+                return torch.floor(q + 0.5)
+            return torch.round(q)
+
+        def ensure_index_key(self, key):
+            return self._rounded(key).long()
+
+        def get_valid_values(self, key):
+            if rule & ON_INDEX:
+                k = self._rounded(key)
+                return ((k >= 0) & (k <= torch.tensor(self.shape) - 1)).all(dim=-1)
+            return ((self._min <= key) & (key <= self._max)).all(dim=-1)
+
+    found, seen = mod.detect(View)
+    assert found == rule, seen
