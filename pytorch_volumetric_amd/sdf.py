@@ -181,7 +181,7 @@ class ObjectFactory(abc.ABC):
     def num_faces(self):
         return int(self._mesh.faces.shape[0])
 
-    def object_frame_closest_point(self, points_in_object_frame, compute_normal=False, index_base=0) -> SDFQuery:
+    def object_frame_closest_point(self, points_in_object_frame, compute_normal=False, index_base=0, order=None) -> SDFQuery:
         """
         Closest surface point, signed distance, gradient (and face normal) for points in the object frame
         (sdf.py:122-189).  Any leading batch dimensions; computed in float32 like the reference (sdf.py:132) and
@@ -190,6 +190,8 @@ class ObjectFactory(abc.ABC):
         :param points_in_object_frame: [...] x N x 3 tensor or ndarray
         :param compute_normal: also return the face normal at the closest point
         :param index_base: global index of the first point (keeps the sign jitter identical under sharding)
+        :param order: int32 processing order of the flattened points (a permutation that keeps neighbours in space together),
+            when the caller already has one; results do not depend on it
         """
         lib = _lib.load()
         if not torch.is_tensor(points_in_object_frame):
@@ -204,7 +206,8 @@ class ObjectFactory(abc.ABC):
         normal = torch.empty((P, 3), dtype=torch.float32, device=dev) if compute_normal else None
         desc = self._mesh_desc()
         with _lib.on_device(dev):
-            order = _lib.morton_order(flat)
+            if order is None:
+                order = _lib.morton_order(flat)
             scratch = None
             if P > 0 and getattr(self, "tile_split", True):
                 # lets the kernel spread a point group's tiles over several workgroups (every group of a small query, the
@@ -950,16 +953,29 @@ class ComposedSDF(ObjectFrameSDF):
         best_v = torch.empty((A, P), dtype=torch.float32, device=dev)
         best_g = torch.empty((A, P, 3), dtype=torch.float32, device=dev)
         slab = 65535  # the glue kernels carry the configuration in a grid dimension; the reference takes any batch
+        # MeshSDF leaves want their points in a spatial order; every leaf sees a rigid image of the SAME points, so ONE Morton
+        # order of the object-frame points (repeated per configuration) serves all of them instead of a sort per leaf
+        shared = None
+        if any(isinstance(s, MeshSDF) for s in self.sdfs) and getattr(self, "_rigid", True):
+            with _lib.on_device(dev):
+                shared = _lib.morton_order(flat)
         for a0 in range(0, A, slab):
             An = min(slab, A - a0)
             x = torch.empty((An, P, 3), dtype=torch.float32, device=dev)
+            order = None
+            if shared is not None and An * P < 2 ** 31:
+                order = shared if An == 1 else (shared.unsqueeze(0) + (torch.arange(An, device=dev, dtype=torch.int32) * P).unsqueeze(1)).reshape(-1)
             bv, bg = best_v[a0:a0 + An], best_g[a0:a0 + An]  # contiguous row blocks of the outputs
             for i, sdf in enumerate(self.sdfs):
                 tf_i = m[i, a0:a0 + An].contiguous()
                 with _lib.on_device(dev):
                     _lib.check(lib.pvamd_transform_points(_lib.ptr(tf_i), An, _lib.ptr(flat), P, _lib.ptr(x), _lib.stream_ptr()),
                                "pvamd_transform_points")
-                v, g = sdf(x)
+                if order is not None and isinstance(sdf, MeshSDF):
+                    res = sdf.obj_factory.object_frame_closest_point(x, order=order)
+                    v, g = res.distance, res.gradient
+                else:
+                    v, g = sdf(x)
                 v = v.to(device=dev, dtype=torch.float32).reshape(An, P).contiguous()
                 g = g.to(device=dev, dtype=torch.float32).reshape(An, P, 3).contiguous()
                 with _lib.on_device(dev):
