@@ -59,13 +59,18 @@ enum IndexMode { kEstimate = 0, kInlineExact = 1, kExact = 2 };
 
 // One leaf for one point: candidate (v, a, b, c) and whether it came from the grid (valid) or is the unnormalised
 // bounding-box vector.
+// The range test leaves as a LANE MASK (an SGPR pair), not as a bool: a bool that crosses basic blocks -- let alone one kept
+// in a `bool valid[PPP]` array -- is materialised as 0 / 1 in a VGPR (v_cndmask) and compared against 0 again at every use
+// (v_cmp_ne); the mask is tested wave-wide with scalar compares and turned back into a per-lane predicate for free
+// (inverse_ballot: the v_cndmask that consumes it reads the SGPR pair directly).
 template <int MODE>
 PVAMD_DEV void leaf_candidate(const pvamd_grid_t& g, const float* __restrict__ M, float px, float py, float pz,
-                               float& v, float& a, float& b, float& c, bool& valid, bool& unsure) {
+                               float& v, float& a, float& b, float& c, uint64_t& vmask, bool& unsure) {
     const float x = affine_row(M[0], M[1], M[2], M[3], px, py, pz);
     const float y = affine_row(M[4], M[5], M[6], M[7], px, py, pz);
     const float z = affine_row(M[8], M[9], M[10], M[11], px, py, pz);
-    valid = in_range(g, x, y, z);
+    vmask = in_range_mask(g, x, y, z);
+    const bool valid = __builtin_amdgcn_inverse_ballot_w64(vmask);
     auto gather = [&]() {
         int flat;
         if constexpr (MODE == kExact) {
@@ -76,10 +81,10 @@ PVAMD_DEV void leaf_candidate(const pvamd_grid_t& g, const float* __restrict__ M
         } else {
             flat = voxel_flat_estimate(g, x, y, z, unsure);
         }
-        const float4 r = reinterpret_cast<const float4*>(g.vox)[flat];
+        const float4 r = load_record(g.vox, flat);
         v = r.x; a = r.y; b = r.z; c = r.w;
     };
-    if (wave_all(valid)) {  // wave-uniform: the whole wave is inside this leaf's range
+    if (vmask == __builtin_amdgcn_ballot_w64(true)) {  // wave-uniform: the whole wave is inside this leaf's range
         gather();
         return;
     }
@@ -88,7 +93,7 @@ PVAMD_DEV void leaf_candidate(const pvamd_grid_t& g, const float* __restrict__ M
     b = __builtin_amdgcn_fmed3f(sub_rn(y, g.bb_min[1]), sub_rn(y, g.bb_max[1]), 0.f);
     c = __builtin_amdgcn_fmed3f(sub_rn(z, g.bb_min[2]), sub_rn(z, g.bb_max[2]), 0.f);
     v = sqrt_rn_sumsq(fmaf(c, c, fmaf(b, b, mul_rn(a, a))));  // sdf.py:568; the division of :570 waits for the winner
-    if (wave_any(valid)) {
+    if (vmask != 0) {
         if (valid) gather();
     }
 }
@@ -121,9 +126,9 @@ PVAMD_DEV void walk_leaves(const pvamd_grid_t* __restrict__ grids, int S, const 
     for (int s = 0; s < S; ++s) {
         if (s < 64 && !((todo >> s) & 1ull)) continue;  // wave-uniform
         float v, ga, gb, gc;
-        bool valid;
-        leaf_candidate<MODE>(grids[s], tf + 16 * ((int64_t)s * A + a), px, py, pz, v, ga, gb, gc, valid, unsure);
-        keep_first_minimum(best, s, v, ga, gb, gc, valid);
+        uint64_t vm;
+        leaf_candidate<MODE>(grids[s], tf + 16 * ((int64_t)s * A + a), px, py, pz, v, ga, gb, gc, vm, unsure);
+        keep_first_minimum(best, s, v, ga, gb, gc, __builtin_amdgcn_inverse_ballot_w64(vm));
     }
 }
 
@@ -306,12 +311,13 @@ PVAMD_DEV void tile_passes(const pvamd_grid_t* __restrict__ grids, int S, const 
             const pvamd_grid_t& g = grids[s];
             // all PPP candidates first, their comparisons after: the gathers of the PPP points are in flight together
             float v[PPP], ga[PPP], gb[PPP], gc[PPP];
-            bool valid[PPP];
+            uint64_t vm[PPP];
 #pragma unroll
             for (int k = 0; k < PPP; ++k)
-                leaf_candidate<MODE>(g, M, px[k], py[k], pz[k], v[k], ga[k], gb[k], gc[k], valid[k], unsure[k]);
+                leaf_candidate<MODE>(g, M, px[k], py[k], pz[k], v[k], ga[k], gb[k], gc[k], vm[k], unsure[k]);
 #pragma unroll
-            for (int k = 0; k < PPP; ++k) keep_first_minimum(best[k], s, v[k], ga[k], gb[k], gc[k], valid[k]);
+            for (int k = 0; k < PPP; ++k)
+                keep_first_minimum(best[k], s, v[k], ga[k], gb[k], gc[k], __builtin_amdgcn_inverse_ballot_w64(vm[k]));
             if (refine) {
                 float m = best[0].v;
 #pragma unroll

@@ -19,6 +19,16 @@ namespace pvamd {
 // The quotient -> index step and the validity test under a NON-default pvamd_grid_t::rule (include/pvamd.h).  Out of line
 // on purpose: these statements only run for descriptors that ask for them, and inlined into the query kernels they cost
 // every launch registers (composed_query_wave: 42 -> 242 spilled VGPRs with them inline).
+// One packed (val, gx, gy, gz) record.  The cache always lives in device (global) memory, but a pointer read out of a
+// descriptor that itself sits in memory is a generic one to the compiler, which then emits flat_load (aperture check, and the
+// load counts against lgkmcnt as well as vmcnt): say which address space it is.
+typedef float record_f32x4 __attribute__((ext_vector_type(4)));
+typedef const record_f32x4 __attribute__((address_space(1))) * global_record_ptr;
+PVAMD_DEV float4 load_record(const float* vox, int flat) {
+    const record_f32x4 r = ((global_record_ptr)(uintptr_t)vox)[flat];
+    return make_float4(r.x, r.y, r.z, r.w);
+}
+
 template <typename T>
 PVAMD_DEV T round_by_rule(int rule, T q) {
     if (rule & PVAMD_RULE_ROUND_HALF_AWAY) {
@@ -90,6 +100,15 @@ PVAMD_DEV bool voxel_flat(const pvamd_grid_t& g, float x, float y, float z, int&
 // in the index dtype with the bounds rounded inward to float32.
 PVAMD_DEV bool in_range(const pvamd_grid_t& g, float x, float y, float z) {
     return (g.vlo[0] <= x) & (x <= g.vhi[0]) & (g.vlo[1] <= y) & (y <= g.vhi[1]) & (g.vlo[2] <= z) & (z <= g.vhi[2]);
+}
+
+// The same test as a 64-bit LANE MASK, for the instruction-bound composed kernels: the ballot of ONE compare is that
+// compare's own SGPR result, and the six masks are combined with scalar ANDs -- whereas the ballot of an AND of compares
+// makes the backend materialise the bool (v_cndmask 0 / 1) and compare it with 0 again, two vector instructions per visit.
+PVAMD_DEV uint64_t in_range_mask(const pvamd_grid_t& g, float x, float y, float z) {
+    return __builtin_amdgcn_ballot_w64(g.vlo[0] <= x) & __builtin_amdgcn_ballot_w64(x <= g.vhi[0]) &
+           __builtin_amdgcn_ballot_w64(g.vlo[1] <= y) & __builtin_amdgcn_ballot_w64(y <= g.vhi[1]) &
+           __builtin_amdgcn_ballot_w64(g.vlo[2] <= z) & __builtin_amdgcn_ballot_w64(z <= g.vhi[2]);
 }
 
 // Index of an in-range coordinate: multiply-first estimate in fp32; unless it lies within its rounding bound of a
@@ -200,7 +219,7 @@ template <bool F64>
 PVAMD_DEV float4 cached_lookup(const pvamd_grid_t& g, float x, float y, float z, bool& valid) {
     valid = in_range(g, x, y, z);
     if (valid) {
-        return reinterpret_cast<const float4*>(g.vox)[voxel_flat_in_range<F64>(g, x, y, z)];
+        return load_record(g.vox, voxel_flat_in_range<F64>(g, x, y, z));
     }
     if (g.oob_mode == PVAMD_OOB_BOUNDING_BOX) {
         return bounding_box_sdf(g, x, y, z);
@@ -235,7 +254,7 @@ PVAMD_DEV bool cached_lookup_f64(const pvamd_grid_t& g, const double p[3], doubl
     const bool valid = voxel_key_f64(g, p, key);
     v = gx = gy = gz = 0.0;
     if (valid) {
-        const float4 r = reinterpret_cast<const float4*>(g.vox)[clamped_flat(g, key)];
+        const float4 r = load_record(g.vox, clamped_flat(g, key));
         v = (double)r.x; gx = (double)r.y; gy = (double)r.z; gz = (double)r.w;
     } else if (g.oob_mode == PVAMD_OOB_BOUNDING_BOX) {
         double t[3];
