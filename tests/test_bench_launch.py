@@ -57,6 +57,23 @@ def test_two_ranks_share_the_gpu_and_every_leg_reports():
 
 
 @pytest.mark.gpu
+def test_eight_ranks_share_the_gpu():
+    """The driver's 8-GPU run cannot be rehearsed on a 1-GPU box, but its world size can: 8 ranks on the one GPU (gloo) walk
+    the W = 8 partition / padding / index arithmetic of every leg; the gathered C4 results must equal the unsharded call."""
+    line = run_bench("--gpus", "8", "--share-gpu", "--steps", "5", "--warmup", "2", "--points", "65536", "--small-legs",
+                     "--no-large", "--no-cpu-baseline")
+    assert line["n_gpus"] == 8 and "legs_aborted" not in line
+    legs = line["legs"]
+    for name in ("c4", "c4_readme_grid", "c5"):
+        assert "error" not in legs[name] and "skipped" not in legs[name], legs[name]
+    g = legs["c4"]["gathered"]
+    assert g["path"] == "packed" and g["equals_unsharded_call"] is True and g["output_shape"] == [[8, 16384], [8, 16384, 3]]
+    assert g["bytes_received_per_rank"] == 7 * 8 * 2048 * 16  # 7 peers x 8 configurations x 2048 padded points x 16 B
+    assert legs["c4"]["gathered_by_configs"]["equals_unsharded_call"] is True  # one configuration per rank
+    assert legs["c5"]["rel_err_vs_analytic"] < 1e-3
+
+
+@pytest.mark.gpu
 def test_a_rank_that_fails_before_a_legs_collectives_does_not_hang_the_others():
     """Rank 1 raises while preparing the C4 leg (whose packed path all-gathers): every rank skips that leg together -- one
     all-reduced flag before the leg's first collective -- and the remaining legs and the headline line still come out."""
