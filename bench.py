@@ -439,6 +439,35 @@ def leg_readme(torch, np, Wk, pv, timer, gate, robots, rank, world, A):
             "why_not": "synthetic 7-DOF arm with 8 ellipsoid links (KUKA assets unavailable offline); different GPU"}
 
 
+def leg_c3(torch, Wk, pv, timer, gate, cached, rank, world, steps, small=False):
+    """BASELINE configs[2]: ComposedSDF of 8 transformed drills (the C2 cache under 8 rigid transforms), 4,194,304 query
+    points, transform + lookup + min over leaves fused (sdf.py:392-433); the points sharded over the ranks, results left
+    sharded (a single configuration: the one-point-per-lane kernel)."""
+    P = (1 << 16) if small else (1 << 22)
+    comp = Wk.build_c3(cached)
+    pts = Wk.c3_points(P)
+    start, stop, _ = pv.shard_range(P, world, rank)
+    mine = pts[start:stop].contiguous()
+    n = mine.shape[0]
+    val = torch.empty((1, n), dtype=torch.float32, device="cuda")
+    grad = torch.empty((1, n, 3), dtype=torch.float32, device="cuda")
+
+    def run():
+        for _ in range(steps):
+            comp.query_into(mine, val, grad)
+
+    run()
+    gate()
+    t = timer(run)
+    gbs = BYTES_PER_QUERY * P * steps / t / 1e9
+    return {"config": f"C3: ComposedSDF of 8 transformed drills (37x33x40 cache each), {P} points, points sharded x{world}",
+            "scaling": "strong", "n_gpus": world, "steps": steps, "unit": "queries/s", "value": P * steps / t,
+            "ms_per_step": t / steps * 1e3, "call": "comp.query_into(points, val, grad): fused kernel, caller's buffers",
+            "roofline": {"bound": "valu", "hbm_algorithmic_GBs": gbs, "frac_of_hbm_peak": gbs / (HBM_PEAK_GBS * world),
+                         "note": "28 B/query algorithmic, but 8 leaf visits per point at ~79 vector instructions per 64-point visit "
+                                 "(the C4 kernel family, legs.c4.sharded.roofline) bound it: the vector ALUs, not HBM"}}
+
+
 def leg_c1(torch, np, Wk, pv, gate, world):
     """BASELINE configs[0]: MeshSDF on the YCB drill (15,728 triangles), 10,000 of the 0.002 m grid points (the reference's
     tests/test_sdf.py:46-48) -- the reference's CPU path (Embree) config, here one call of the GPU mesh query (point sort +
@@ -663,7 +692,8 @@ def main():
         leg_steps = 20
         sm = args.small_legs
         robots = {}
-        spec = [("c4", lambda g: leg_c4(torch, dist, Wk, pv, timer, g, robots, rank, world, leg_steps, 0.1, True, sm, use_pg)),
+        spec = [("c3", lambda g: leg_c3(torch, Wk, pv, timer, g, cached, rank, world, leg_steps, sm)),
+                ("c4", lambda g: leg_c4(torch, dist, Wk, pv, timer, g, robots, rank, world, leg_steps, 0.1, True, sm, use_pg)),
                 ("c4_readme_grid", lambda g: leg_c4(torch, dist, Wk, pv, timer, g, robots, rank, world, leg_steps, 1.0, False, sm)),
                 ("c5", lambda g: leg_c5(torch, dist, Wk, pv, timer, g, rank, world, 5, sm, use_pg))]
         if not sm:

@@ -45,7 +45,7 @@ def test_two_ranks_share_the_gpu_and_every_leg_reports():
     assert line["n_gpus"] == 2 and line["config"]["ranks"] == 2 and line["scaling"] == "weak"
     assert line["parity"]["max_abs_val_err_vs_oracle"] == 0.0 and line["parity"]["grad_mismatches_vs_oracle"] == 0
     legs = line["legs"]
-    for name in ("c4", "c4_readme_grid", "c5"):
+    for name in ("c3", "c4", "c4_readme_grid", "c5"):
         assert "error" not in legs[name], legs[name]
         assert legs[name]["scaling"] == "strong" and legs[name]["n_gpus"] == 2
     assert legs["c4"]["sharded"]["gather"] is False and legs["c4"]["gathered"]["gather"] is True
