@@ -203,7 +203,8 @@ int pvamd_voxel_scatter_u8(const pvamd_grid_t* grid, uint8_t* storage, const flo
  * sit inline (cheapest for large, gather-bound grids, whose larger coordinate / resolution ratios also flag more visits).
  * The transforms must be RIGID (orthonormal 3x3, last row 0 0 0 1): the gradient is rotated back with R^T and the
  * leaf-culling bounds rely on distances being preserved.
- * Any P >= 0 and any A >= 1 (batches above 65535 configurations go out in slabs); points / out_val / out_grad need only
+ * Any P >= 0 and any A >= 1 (the configuration is blockIdx.x; only the points-fastest tuning order walks slabs of 65535);
+ * points / out_val / out_grad need only
  * their natural 4-byte alignment -- rows of an odd P (the reference README's M = 15,251) take the same kernel.      */
 #define PVAMD_COMPOSED_INLINE_EXACT 1
 #define PVAMD_COMPOSED_FORCE_PER_LANE 2   /* testing / tuning: take the one-point-per-lane kernel whatever the size */
