@@ -143,3 +143,46 @@ def test_mesh_query_and_chamfer_fuzz(seed):
     err = pv.batch_chamfer_dist(W, torch.from_numpy(pts), obj, scale=10.0)
     oerr = oracle.chamfer_mesh(om, W.numpy(), pts, scale=10.0) / n
     assert np.allclose(err.double().numpy(), oerr, rtol=1e-6, atol=1e-12)
+
+
+@pytest.mark.parametrize("seed", range(6 * FUZZ_SCALE))
+def test_rules_and_float64_compositions_fuzz(seed):
+    """Random compositions whose leaves were built under a random index rule (pvamd_grid_t.rule), queried with float32 points
+    through every kernel variant and with float64 points through pvamd_composed_query_f64: the oracle's bits each time."""
+    from pytorch_volumetric_amd import voxel
+    rng = np.random.default_rng(300 + seed)
+    rule = int(rng.choice([0, 1, 2, 4, 1 | 2, 1 | 4, 8, 1 | 8]))
+    prev = voxel.INDEX_RULE
+    voxel.INDEX_RULE = rule
+    try:
+        S, A = int(rng.integers(1, 7)), int(rng.choice([1, 3]))
+        leaves = [random_cached(rng, bool(rng.integers(0, 2)))[0] for _ in range(S)]
+        assert all(l._view.rule == rule for l in leaves)
+        tfm = H.random_rigid(S * A, seed=seed, trans=1.0)
+        comp = pv.ComposedSDF(leaves, None)
+        comp.set_transforms(tfm, batch_dim=(A,) if A > 1 else None)
+        n = int(rng.choice([9, 300, 2049]))
+        pts = (rng.random((n, 3)) * 4 - 2).astype(np.float32)
+        # leaf-frame half-voxel planes and range edges of leaf 0 under configuration 0, brought back to the object frame
+        v0 = leaves[0]._view
+        k = min(n, 64)
+        idx = rng.integers(-1, np.array(v0.shape) + 1, size=(k, 3))
+        leaf_pts = v0.dmin.numpy() + (idx + rng.choice([0.0, 0.5, -0.5], size=(k, 3))) * v0.dres.numpy()
+        inv = np.linalg.inv(tfm[0].double().numpy())
+        pts[:k] = (leaf_pts @ inv[:3, :3].T + inv[:3, 3]).astype(np.float32)
+        ogrids = [H.oracle_grid_from_cached(l) for l in leaves]
+        oval, ograd, _ = oracle.composed_query(ogrids, tfm.numpy(), A, pts)
+        comp._leaf_grids(torch.device("cuda", torch.cuda.current_device()))
+        for flags in (2, 4, 4 | 1):
+            comp._query_flags = flags
+            val, grad = comp(torch.from_numpy(pts).cuda())
+            assert np.array_equal(val.cpu().numpy().reshape(A, -1), oval, equal_nan=True), (rule, flags)
+            assert np.array_equal(grad.cpu().numpy().reshape(A, -1, 3), ograd, equal_nan=True), (rule, flags)
+        p64 = pts.astype(np.float64) + rng.normal(scale=1e-10, size=pts.shape)
+        v64, g64 = comp(torch.from_numpy(p64).cuda())
+        ov, og, _ = oracle.composed_query_f64(ogrids, tfm.double().numpy(), A, p64)
+        assert v64.dtype == torch.float64
+        assert np.array_equal(v64.cpu().numpy().reshape(A, -1), ov, equal_nan=True), rule
+        assert np.array_equal(g64.cpu().numpy().reshape(A, -1, 3), og, equal_nan=True), rule
+    finally:
+        voxel.INDEX_RULE = prev
