@@ -210,6 +210,7 @@ int pvamd_voxel_scatter_u8(const pvamd_grid_t* grid, uint8_t* storage, const flo
 #define PVAMD_COMPOSED_FORCE_PER_LANE 2   /* testing / tuning: take the one-point-per-lane kernel whatever the size */
 #define PVAMD_COMPOSED_FORCE_WAVE_TILE 4  /* testing / tuning: take the wave-tile kernel whatever the size                 */
 #define PVAMD_COMPOSED_POINTS_FASTEST 8   /* tuning: per-lane kernel with blocks ordered points-fastest (default: configuration-fastest) */
+#define PVAMD_COMPOSED_LEGACY_LEAF_LOOP 16 /* testing / tuning: wave-tile kernel with the round-3 leaf loop (lookups and exact roots inside the leaf loop) */
 int pvamd_composed_query(const pvamd_grid_t* grids, int32_t S, const float* tf, int32_t A,
                          const float* points, int64_t P,
                          float* out_val, float* out_grad, int32_t* out_leaf, int32_t flags, void* stream);

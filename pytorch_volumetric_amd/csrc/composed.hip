@@ -362,7 +362,327 @@ PVAMD_DEV void tile_passes(const pvamd_grid_t* __restrict__ grids, int S, const 
     }
 }
 
-template <int PPP, int MODE, bool PACKED>
+
+// ---- round 4: the in-range lookups of a pass leave the leaf loop ----
+// On scattered points (C3, C4) a leaf's range holds 1-5 % of the points, so most wave visits ran the ~29-instruction index
+// + gather path for one or two live lanes, and every visit paid an exact square root to order candidates that are almost
+// all bounding-box distances.  Here the leaf loop keeps the OUT-OF-RANGE candidates only, ordered by the SQUARED norm (sqrt
+// is monotone: n2_b < n2_a decides, except where the two correctly rounded roots could coincide -- a band of 2^-21
+// relative, re-decided with both exact roots behind a wave-uniform branch; exact ties keep the incumbent as torch.argmin
+// does); the winner's root is taken once per point.  An IN-RANGE visit only sets bit s of the lane's leaf mask (one
+// exec-masked v_or).  After the loop every lane walks ITS OWN set bits in ascending leaf order -- lanes work on different
+// leaves at the same time, so a wave iterates max-over-lanes popcount times (1-2 on C4) instead of once per leaf -- with the
+// leaf's constants (its 3x4 matrix for this configuration and the index-estimate numbers) read per lane from a table the
+// block built in LDS.  The two minima are then compared by (value, leaf): the reference's first minimum over all leaves
+// (sdf.py:421), bit for bit.  A first version compacted the in-range (point, leaf) pairs across lanes through an LDS queue
+// and 64-bit LDS atomics: fewer vector instructions still, but SLOWER than the round-3 loop (C4 0.754 vs 0.706 ms) -- every
+// drained pair read its leaf's 26 constants with per-lane global loads (64 distinct lines per instruction through the
+// TCP) and paid two fences; profiles/r04_composed_ab.txt.
+constexpr float kNearTie = 0.99999952316284179688f;  // 1 - 2^-21: sqrt_rn(n2_b) == sqrt_rn(n2_a) needs n2_b >= n2_a (1 - 2^-22)
+constexpr int kNoLeaf = kUnnormalised - 1;           // "no candidate yet": loses every (value, leaf) tie
+constexpr int kDeferredMaxLeaves = 256;              // rows of the block's LDS table (28 KB at 256; sized by S at launch)
+
+struct BestOut {
+    float n2, tx, ty, tz;  // squared bounding-box distance and the (unnormalised) bounding-box vector, leaf frame
+    int leaf;
+};
+
+// One row per leaf, for the block's configuration: what a per-lane lookup needs, 16-byte groups for ds_read_b128.
+//   [0..11] 3x4 obj->leaf matrix   [12..14] fmin  [15] shape[1]   [16..18] inv32  [19] shape[2]   [20..22] err32
+//   [23] nx*ny*nz - 1              [24,25] vox pointer            [26,27] unused
+constexpr int kLeafRow = 28;
+
+PVAMD_DEV void build_leaf_table(const pvamd_grid_t* __restrict__ grids, int S, const float* __restrict__ tf, int A, int a,
+                                float* table) {
+    for (int s = threadIdx.x; s < S; s += blockDim.x) {
+        const pvamd_grid_t& g = grids[s];
+        const float* M = tf + 16 * ((int64_t)s * A + a);
+        float* row = table + kLeafRow * s;
+#pragma unroll
+        for (int j = 0; j < 12; ++j) row[j] = M[j];
+#pragma unroll
+        for (int d = 0; d < 3; ++d) {
+            row[12 + d] = g.fmin[d];
+            row[16 + d] = g.inv32[d];
+            row[20 + d] = g.err32[d];
+        }
+        row[15] = __int_as_float(g.shape[1]);
+        row[19] = __int_as_float(g.shape[2]);
+        row[23] = __int_as_float(g.shape[0] * g.shape[1] * g.shape[2] - 1);
+        const uint64_t vox = (uint64_t)(uintptr_t)g.vox;
+        row[24] = __uint_as_float((uint32_t)vox);
+        row[25] = __uint_as_float((uint32_t)(vox >> 32));
+        row[26] = row[27] = 0.f;
+    }
+}
+
+// ---- in-range (point, leaf) pairs compacted across lanes and visits ----
+// float -> uint32 whose unsigned order is the float order, -0 == +0, NaN below everything (argmin counts NaN as minimum)
+PVAMD_DEV uint32_t ordered_key(float v) {
+    const uint32_t u = __float_as_uint(add_rn(v, 0.f));  // -0 + 0 = +0
+    const uint32_t k = (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+    return (v != v) ? 0u : k;
+}
+PVAMD_DEV unsigned long long candidate_key(float v, int s) { return ((unsigned long long)ordered_key(v) << 32) | (unsigned)s; }
+
+typedef unsigned long long u64_lds __attribute__((may_alias));
+typedef uint32_t u32_lds __attribute__((may_alias));
+constexpr int kQueueDense = 16;     // a visit with this many lanes in range looks its records up itself (wave-uniform leaf)
+constexpr int kQueueLeafShift = 7;  // queue entry = local point (7 bits: 64 * PPP = 128) | leaf << 7
+
+// Up to 64 queued pairs, one per lane: the point comes out of its owner's registers (ds_bpermute), the leaf's constants out
+// of the block's LDS table (a per-lane global read of them was what made the first version slower than the round-3 loop),
+// the candidate goes to the point's slot by a 64-bit LDS atomic min on (ordered value, leaf); whoever holds the minimum
+// afterwards leaves its flat index beside it.
+template <int PPP>
+PVAMD_DEV void drain_queue(const pvamd_grid_t* __restrict__ grids, const float* table, const float (&px)[PPP],
+                           const float (&py)[PPP], const float (&pz)[PPP], u64_lds* keys, u32_lds* flats,
+                           const u32_lds* queue, int& count, int lane) {
+    PVAMD_WAVE_SYNC();
+    const int n = count < 64 ? count : 64;
+    const bool active = lane < n;
+    const uint32_t e = active ? queue[count - n + lane] : (uint32_t)lane;  // inactive: own point, leaf 0, discarded
+    count -= n;
+    const int q = e & (64 * PPP - 1), s = (int)(e >> kQueueLeafShift);
+    const int src = (q & 63) << 2, k = q >> 6;
+    float x0 = 0.f, y0 = 0.f, z0 = 0.f;
+#pragma unroll
+    for (int j = 0; j < PPP; ++j) {
+        const float bx = __int_as_float(__builtin_amdgcn_ds_bpermute(src, __float_as_int(px[j])));
+        const float by = __int_as_float(__builtin_amdgcn_ds_bpermute(src, __float_as_int(py[j])));
+        const float bz = __int_as_float(__builtin_amdgcn_ds_bpermute(src, __float_as_int(pz[j])));
+        x0 = (k == j) ? bx : x0;
+        y0 = (k == j) ? by : y0;
+        z0 = (k == j) ? bz : z0;
+    }
+    const f32x4_alias* row = reinterpret_cast<const f32x4_alias*>(table + kLeafRow * s);
+    const f32x4 m0 = row[0], m1 = row[1], m2 = row[2], c0 = row[3], c1 = row[4], c2 = row[5], c3 = row[6];
+    const float x = affine_row(m0.x, m0.y, m0.z, m0.w, x0, y0, z0);  // the leaf loop's statement on the same numbers: same bits
+    const float y = affine_row(m1.x, m1.y, m1.z, m1.w, x0, y0, z0);
+    const float z = affine_row(m2.x, m2.y, m2.z, m2.w, x0, y0, z0);
+    const float p[3] = {x, y, z};
+    const float fmin[3] = {c0.x, c0.y, c0.z}, inv32[3] = {c1.x, c1.y, c1.z}, err32[3] = {c2.x, c2.y, c2.z};
+    int kk[3];
+    bool shaky = false;
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {  // voxel_flat_estimate's statements on the row's numbers
+        const float t = mul_rn(sub_rn(p[d], fmin[d]), inv32[d]);
+        const float kc = __builtin_rintf(t);
+        shaky |= !(sub_rn(0.5f, fabsf(sub_rn(t, kc))) > err32[d]);
+        kk[d] = (int)kc;
+    }
+    if (__builtin_expect(wave_any(shaky & active), 0)) {
+        if (shaky & active) {  // the reference's own statements (IEEE division in the leaf's index dtype); rare: per-lane reads
+            const pvamd_grid_t& g = grids[s];
+#pragma unroll 1
+            for (int d = 0; d < 3; ++d) {
+                long long kd;
+                if (g.index_f64) voxel_index_1d<true>(g, d, p[d], kd);
+                else voxel_index_1d<false>(g, d, p[d], kd);
+                kk[d] = (int)kd;
+            }
+        }
+    }
+    const int ny = __float_as_int(c0.w), nz = __float_as_int(c1.w);
+    const unsigned last = __float_as_uint(c2.w);
+    const unsigned flat_u = (unsigned)((kk[0] * ny + kk[1]) * nz + kk[2]);
+    const int flat = (int)(flat_u < last ? flat_u : last);
+    float v = 0.f;
+    if (active) {
+        const uint64_t vox = (uint64_t)__float_as_uint(c3.x) | ((uint64_t)__float_as_uint(c3.y) << 32);
+        v = load_record(reinterpret_cast<const float*>((uintptr_t)vox), flat).x;
+    }
+    const unsigned long long mine = active ? candidate_key(v, s) : ~0ull;
+    __hip_atomic_fetch_min(&keys[q], mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+    PVAMD_WAVE_SYNC();
+    const unsigned long long cur = keys[q];
+    if (active && cur == mine) flats[q] = (uint32_t)flat;  // one lane per point: (value, leaf) is unique per point
+    PVAMD_WAVE_SYNC();
+}
+
+struct BestIn {  // the in-range minimum of the dense visits, by the owning lane
+    float v;
+    int leaf, flat;
+};
+
+template <int PPP, bool PACKED, bool MASKED>
+PVAMD_DEV void tile_passes_deferred(const pvamd_grid_t* __restrict__ grids, int S, const float* __restrict__ tf, int A, int a,
+                                    int64_t first, int64_t P, float* __restrict__ val, int* __restrict__ leaf, float* spf,
+                                    const float* table, int lane, uint64_t todo, float lower) {
+    static_assert(PPP == 2, "queue capacity: 64 + PPP * (kQueueDense - 1) entries in the pass's 64 * PPP value slots");
+    float* svf = spf + 768;
+    const int first_leaf = todo ? __builtin_ctzll(todo) : 0;
+    const bool refine = MASKED && S <= 64 && todo != ((S >= 64) ? ~0ull : ((1ull << S) - 1ull));
+    const uint64_t everyone = __builtin_amdgcn_ballot_w64(true);
+    // ONE copy of the pass (the round-3 loop unrolls its passes): the body carries the drain as well
+#pragma unroll 1
+    for (int h = 0; h < 4; h += PPP) {
+        float px[PPP], py[PPP], pz[PPP];
+        BestOut best[PPP];
+        BestIn bin[PPP];
+        uint64_t unsure[PPP];
+#pragma unroll
+        for (int k = 0; k < PPP; ++k) {
+            const int p = lane + 64 * (h + k);
+            px[k] = spf[3 * p];
+            py[k] = spf[3 * p + 1];
+            pz[k] = spf[3 * p + 2];
+            best[k] = BestOut{__builtin_inff(), __builtin_nanf(""), __builtin_nanf(""), __builtin_nanf(""), kNoLeaf};
+            bin[k] = BestIn{__builtin_inff(), kNoLeaf, 0};
+            unsure[k] = 0;
+        }
+        // the pass's points are in registers: their LDS slots become the per-point keys + flat indices (xyz slots) and the
+        // queue (value slots)
+        u64_lds* keys = reinterpret_cast<u64_lds*>(spf + 192 * h);
+        u32_lds* flats = reinterpret_cast<u32_lds*>(spf + 192 * h + 128 * PPP);
+        u32_lds* queue = reinterpret_cast<u32_lds*>(svf + 64 * h);
+        PVAMD_WAVE_SYNC();
+#pragma unroll
+        for (int k = 0; k < PPP; ++k) keys[64 * k + lane] = ~0ull;
+        int count = 0;  // wave-uniform; < 64 at the top of every visit
+        uint64_t rem = todo;
+        // s == S is the drain of what is left: one call site for the drain
+        for (int s = 0; s <= S; ++s) {
+            if (s == S || count >= 64) {
+                // during the loop: down to fewer than 64 waiting pairs; after the last leaf: until none is left
+                const int keep = s == S ? 0 : 63;
+                while (count > keep) drain_queue<PPP>(grids, table, px, py, pz, keys, flats, queue, count, lane);
+                if (s == S) break;
+            }
+            if (MASKED && s < 64 && !((rem >> s) & 1ull)) continue;  // wave-uniform
+            const float* M = tf + 16 * ((int64_t)s * A + a);  // wave-uniform: scalar loads
+            const pvamd_grid_t& g = grids[s];
+#pragma unroll
+            for (int k = 0; k < PPP; ++k) {
+                const float x = affine_row(M[0], M[1], M[2], M[3], px[k], py[k], pz[k]);
+                const float y = affine_row(M[4], M[5], M[6], M[7], px[k], py[k], pz[k]);
+                const float z = affine_row(M[8], M[9], M[10], M[11], px[k], py[k], pz[k]);
+                const uint64_t vm = in_range_mask(g, x, y, z);
+                if (vm != 0) {
+                    const int n = __builtin_popcountll(vm);
+                    const bool valid = __builtin_amdgcn_inverse_ballot_w64(vm);
+                    if (n >= kQueueDense) {
+                        // many lanes in range: each looks its own value up (index estimate; shaky ones are redone below)
+                        bool shaky = false;
+                        const int flat = voxel_flat_estimate(g, x, y, z, shaky);
+                        unsure[k] |= vm & __builtin_amdgcn_ballot_w64(shaky);
+                        float v = __builtin_inff();
+                        if (valid) v = load_record(g.vox, flat).x;
+                        // ascending leaves: "strictly smaller, or the first" is the first minimum; NaN counts as minimum
+                        const bool t = valid & ((bin[k].leaf == kNoLeaf) | (!(v >= bin[k].v) & (bin[k].v == bin[k].v)));
+                        bin[k].v = t ? v : bin[k].v;
+                        bin[k].leaf = t ? s : bin[k].leaf;
+                        bin[k].flat = t ? flat : bin[k].flat;
+                    } else {
+                        const int rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(vm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)vm, 0));
+                        if (valid) queue[count + rank] = (uint32_t)(64 * k + lane) | ((uint32_t)s << kQueueLeafShift);
+                        count += n;  // < 64 + PPP * kQueueDense: drained at the top of the next visit
+                    }
+                    if (vm == everyone) continue;
+                }
+                // sdf.py:559-568 for every lane, squared (no exec masking; in-range lanes are masked out of the take)
+                const float ta = __builtin_amdgcn_fmed3f(sub_rn(x, g.bb_min[0]), sub_rn(x, g.bb_max[0]), 0.f);
+                const float tb = __builtin_amdgcn_fmed3f(sub_rn(y, g.bb_min[1]), sub_rn(y, g.bb_max[1]), 0.f);
+                const float tc = __builtin_amdgcn_fmed3f(sub_rn(z, g.bb_min[2]), sub_rn(z, g.bb_max[2]), 0.f);
+                const float n2 = fmaf(tc, tc, fmaf(tb, tb, mul_rn(ta, ta)));
+                // first minimum, NaN counts as minimum (keep_first_minimum), on the squared norms
+                uint64_t take = __builtin_amdgcn_ballot_w64(!(n2 >= best[k].n2)) &
+                                __builtin_amdgcn_ballot_w64(best[k].n2 == best[k].n2) & ~vm;
+                const uint64_t near = take & __builtin_amdgcn_ballot_w64(n2 >= mul_rn(best[k].n2, kNearTie));
+                if (__builtin_expect(near != 0, 0)) {
+                    // the two roots may round to the same float32, in which case the incumbent stays: decide exactly
+                    const float ra = sqrt_rn_sumsq(best[k].n2), rb = sqrt_rn_sumsq(n2);
+                    take &= ~(near & __builtin_amdgcn_ballot_w64(!(rb < ra)));
+                }
+                const bool t = __builtin_amdgcn_inverse_ballot_w64(take);
+                best[k].n2 = t ? n2 : best[k].n2;
+                best[k].tx = t ? ta : best[k].tx;
+                best[k].ty = t ? tb : best[k].ty;
+                best[k].tz = t ? tc : best[k].tz;
+                best[k].leaf = t ? s : best[k].leaf;
+            }
+            if (refine) {
+                // every point's final value is <= its out-of-range minimum and <= what its own dense look-ups found
+                float m = -__builtin_inff();
+#pragma unroll
+                for (int k = 0; k < PPP; ++k)
+                    m = __builtin_fmaxf(m, __builtin_fminf(fast_sqrt(best[k].n2) * 1.0001f + 1e-18f, bin[k].v));
+                const float ub = wave_max(m);  // NaN minima are ignored: nothing replaces them anyway
+                rem &= ~__builtin_amdgcn_ballot_w64(lower > ub + 1e-6f * fabsf(ub));
+            }
+        }
+        PVAMD_WAVE_SYNC();
+        Best fin[PPP];
+#pragma unroll
+        for (int k = 0; k < PPP; ++k) {
+            // out-of-range minimum: the root once; no candidate at all (every leaf answered +inf) = the first visited leaf
+            // with the NaN gradient, as the round-3 loop leaves it
+            fin[k].v = sqrt_rn_sumsq(best[k].n2);
+            fin[k].gx = best[k].tx;
+            fin[k].gy = best[k].ty;
+            fin[k].gz = best[k].tz;
+            fin[k].tag = (best[k].leaf == kNoLeaf ? first_leaf : best[k].leaf) | kUnnormalised;
+            // in-range minimum: the slot (drained pairs) against the lane's own dense look-ups, by (value, leaf)
+            const unsigned long long key_s = keys[64 * k + lane];
+            const unsigned long long key_d = bin[k].leaf != kNoLeaf ? candidate_key(bin[k].v, bin[k].leaf) : ~0ull;
+            const bool from_slot = key_s < key_d;
+            const unsigned long long key = from_slot ? key_s : key_d;
+            const bool has = key != ~0ull;
+            if (wave_any(has)) {
+                const int li = has ? (int)(uint32_t)key : 0;
+                int flat = bin[k].flat;
+                if (from_slot) flat = (int)flats[64 * k + lane];
+                float4 r = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (has) {
+                    const float* row = table + kLeafRow * li;
+                    const uint64_t vox = (uint64_t)__float_as_uint(row[24]) | ((uint64_t)__float_as_uint(row[25]) << 32);
+                    r = load_record(reinterpret_cast<const float*>((uintptr_t)vox), flat);
+                }
+                // (value, leaf) order with NaN as the smallest value: sdf.py:421 over all leaves
+                const float vi = r.x, vo = fin[k].v;
+                const bool vi_nan = vi != vi, vo_nan = vo != vo;
+                const bool less = (vi_nan & !vo_nan) | (vi < vo);
+                const bool same = (vi == vo) | (vi_nan & vo_nan);
+                const bool wins = has & (less | (same & (li < best[k].leaf)));
+                fin[k].v = wins ? vi : fin[k].v;
+                fin[k].gx = wins ? r.y : fin[k].gx;
+                fin[k].gy = wins ? r.z : fin[k].gy;
+                fin[k].gz = wins ? r.w : fin[k].gz;
+                fin[k].tag = wins ? li : fin[k].tag;
+            }
+        }
+        // the few points whose index estimate (dense visits) could not be trusted for some leaf: all over again, exactly
+#pragma unroll
+        for (int k = 0; k < PPP; ++k) {
+            if (__builtin_expect(unsure[k] != 0, 0)) {
+                Best redo = best_init(first_leaf);
+                bool dummy = false;
+                walk_leaves<kExact>(grids, S, tf, A, a, todo, px[k], py[k], pz[k], redo, dummy);
+                if (__builtin_amdgcn_inverse_ballot_w64(unsure[k])) fin[k] = redo;
+            }
+        }
+        PVAMD_WAVE_SYNC();  // every lane is done with the keys before results overwrite them
+#pragma unroll
+        for (int k = 0; k < PPP; ++k) {
+            const int p = lane + 64 * (h + k);
+            const int s_win = fin[k].tag & (kUnnormalised - 1);
+            const float* M = tf + 16 * ((int64_t)s_win * A + a);
+            float gx, gy, gz;
+            rotate_back(M, fin[k], gx, gy, gz);
+            if constexpr (PACKED) {
+                reinterpret_cast<f32x4*>(val)[(int64_t)a * P + first + p] = f32x4{fin[k].v, gx, gy, gz};
+            } else {
+                svf[p] = fin[k].v;  // a lane overwrites only the LDS slots of the points it owns
+                spf[3 * p] = gx;
+                spf[3 * p + 1] = gy;
+                spf[3 * p + 2] = gz;
+            }
+            if (leaf) leaf[(int64_t)a * P + first + p] = s_win;
+        }
+    }
+}
+
+template <int PPP, int MODE, bool PACKED, int DEFER>
 __global__ __launch_bounds__(kWavesPerBlock * 64, MODE == kEstimate ? PVAMD_COMPOSED_MINWAVES : PVAMD_COMPOSED_MINWAVES_INLINE) void composed_query_wave(const pvamd_grid_t* __restrict__ grids, int S,
                                                                            const float* __restrict__ tf, int A,
                                                                            const float* __restrict__ pts,
@@ -372,6 +692,7 @@ __global__ __launch_bounds__(kWavesPerBlock * 64, MODE == kEstimate ? PVAMD_COMP
                                                                            int* __restrict__ leaf, int a0) {
     __shared__ __attribute__((aligned(16))) float lds[kWavesPerBlock][1024];
     __shared__ float cull[kMaxCullLeaves][8];
+    extern __shared__ __attribute__((aligned(16))) float leaf_table[];  // DEFER: S rows of kLeafRow floats (dynamic: sized by S)
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     float* spf = lds[wave];
     f32x4_alias* sp = reinterpret_cast<f32x4_alias*>(spf);
@@ -380,6 +701,7 @@ __global__ __launch_bounds__(kWavesPerBlock * 64, MODE == kEstimate ? PVAMD_COMP
     // points stay in L2 -- what matters once the grids are far larger than L2 (README-size link grids)
     const int a = a0 + blockIdx.x;
     build_cull_spheres(grids, S, tf, A, a, cull);
+    if constexpr (DEFER != 0) build_leaf_table(grids, S, tf, A, a, leaf_table);
     __syncthreads();
     // The mask drops leaves only for tiles that are small against the scene, and costs ~150 instructions a tile (6 % of
     // C4 on random points, where it drops nothing: 0.834 -> 0.792 ms without it).  `scene` = radius about leaf 0's centre
@@ -428,8 +750,13 @@ __global__ __launch_bounds__(kWavesPerBlock * 64, MODE == kEstimate ? PVAMD_COMP
         // two copies of the leaf loop only where instructions are what binds (kEstimate: grids that live in L2); the
         // gather-bound kInlineExact build loses more to the larger body than the simpler loop gives (README-size robot,
         // sorted points: 1.00 -> 1.10 ms with both copies)
-        if (MODE != kEstimate || masked) tile_passes<PPP, MODE, PACKED, true>(grids, S, tf, A, a, first, P, val, leaf, spf, lane, todo, lower);
-        else tile_passes<PPP, MODE, PACKED, false>(grids, S, tf, A, a, first, P, val, leaf, spf, lane, todo, lower);
+        if constexpr (DEFER != 0) {
+            if (masked) tile_passes_deferred<PPP, PACKED, true>(grids, S, tf, A, a, first, P, val, leaf, spf, leaf_table, lane, todo, lower);
+            else tile_passes_deferred<PPP, PACKED, false>(grids, S, tf, A, a, first, P, val, leaf, spf, leaf_table, lane, todo, lower);
+        } else {
+            if (MODE != kEstimate || masked) tile_passes<PPP, MODE, PACKED, true>(grids, S, tf, A, a, first, P, val, leaf, spf, lane, todo, lower);
+            else tile_passes<PPP, MODE, PACKED, false>(grids, S, tf, A, a, first, P, val, leaf, spf, lane, todo, lower);
+        }
         PVAMD_WAVE_SYNC();
         if constexpr (PACKED) continue;
         // row a starts at a * P floats: 16-byte aligned only when P % 4 == 0 -- the stores take any dword address
@@ -644,6 +971,10 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void composed_unpermute_kernel
 
 using namespace pvamd;
 
+// the round-3 leaf loop (every candidate through the register minimum): on request, or for more leaves than a point's mask holds
+static inline bool legacy_leaf_loop(int32_t flags, int32_t S) { return (flags & PVAMD_COMPOSED_LEGACY_LEAF_LOOP) || S > kDeferredMaxLeaves; }
+static inline size_t leaf_table_bytes(int32_t S) { return (size_t)S * kLeafRow * sizeof(float); }
+
 extern "C" int pvamd_composed_query_packed(const pvamd_grid_t* grids, int32_t S, const float* tf, int32_t A,
                                            const float* points, int64_t Pp, float* out_rec, int32_t flags, void* stream) {
     if (S < 1 || A < 1 || Pp < 1 || Pp % kTilePoints != 0 || S >= kUnnormalised) return PVAMD_E_SHAPE;
@@ -655,11 +986,14 @@ extern "C" int pvamd_composed_query_packed(const pvamd_grid_t* grids, int32_t S,
     // gridDim.y of the query kernel = tile blocks (the configuration is blockIdx.x: any A)
     if (tile_blocks > 65535) return PVAMD_E_SHAPE;  // > 67 M points per call: use the direct entry point
     if (flags & PVAMD_COMPOSED_INLINE_EXACT)
-        hipLaunchKernelGGL((composed_query_wave<PVAMD_COMPOSED_PPP, kInlineExact, true>), dim3(A, (unsigned)tile_blocks),
+        hipLaunchKernelGGL((composed_query_wave<PVAMD_COMPOSED_PPP, kInlineExact, true, 0>), dim3(A, (unsigned)tile_blocks),
+                           dim3(kWavesPerBlock * 64), 0, s, grids, S, tf, A, points, ntiles, Pp, out_rec, nullptr, nullptr, 0);
+    else if (legacy_leaf_loop(flags, S))
+        hipLaunchKernelGGL((composed_query_wave<PVAMD_COMPOSED_PPP, kEstimate, true, 0>), dim3(A, (unsigned)tile_blocks),
                            dim3(kWavesPerBlock * 64), 0, s, grids, S, tf, A, points, ntiles, Pp, out_rec, nullptr, nullptr, 0);
     else
-        hipLaunchKernelGGL((composed_query_wave<PVAMD_COMPOSED_PPP, kEstimate, true>), dim3(A, (unsigned)tile_blocks),
-                           dim3(kWavesPerBlock * 64), 0, s, grids, S, tf, A, points, ntiles, Pp, out_rec, nullptr, nullptr, 0);
+        hipLaunchKernelGGL((composed_query_wave<PVAMD_COMPOSED_PPP, kEstimate, true, 1>), dim3(A, (unsigned)tile_blocks),
+                           dim3(kWavesPerBlock * 64), leaf_table_bytes(S), s, grids, S, tf, A, points, ntiles, Pp, out_rec, nullptr, nullptr, 0);
     return (int)hipGetLastError();
 }
 
@@ -734,11 +1068,14 @@ extern "C" int pvamd_composed_query(const pvamd_grid_t* grids, int32_t S, const 
             const int64_t need = (ntiles + kWavesPerBlock - 1) / kWavesPerBlock;
             const unsigned gy = (unsigned)(need < cap ? need : (cap < 1 ? 1 : cap));
             if (flags & PVAMD_COMPOSED_INLINE_EXACT)
-                hipLaunchKernelGGL((composed_query_wave<PVAMD_COMPOSED_PPP, kInlineExact, false>), dim3(An, gy), dim3(kWavesPerBlock * 64), 0, s,
+                hipLaunchKernelGGL((composed_query_wave<PVAMD_COMPOSED_PPP, kInlineExact, false, 0>), dim3(An, gy), dim3(kWavesPerBlock * 64), 0, s,
+                                   grids, S, tf, A, points, ntiles, P, out_val, out_grad, out_leaf, a0);
+            else if (legacy_leaf_loop(flags, S))
+                hipLaunchKernelGGL((composed_query_wave<PVAMD_COMPOSED_PPP, kEstimate, false, 0>), dim3(An, gy), dim3(kWavesPerBlock * 64), 0, s,
                                    grids, S, tf, A, points, ntiles, P, out_val, out_grad, out_leaf, a0);
             else
-                hipLaunchKernelGGL((composed_query_wave<PVAMD_COMPOSED_PPP, kEstimate, false>), dim3(An, gy), dim3(kWavesPerBlock * 64), 0, s,
-                                   grids, S, tf, A, points, ntiles, P, out_val, out_grad, out_leaf, a0);
+                hipLaunchKernelGGL((composed_query_wave<PVAMD_COMPOSED_PPP, kEstimate, false, 1>), dim3(An, gy), dim3(kWavesPerBlock * 64),
+                                   leaf_table_bytes(S), s, grids, S, tf, A, points, ntiles, P, out_val, out_grad, out_leaf, a0);
         } else {
             const int64_t need = (P + 255) / 256;
             const unsigned gx = (unsigned)(need < cap ? need : (cap < 1 ? 1 : cap));
@@ -761,7 +1098,8 @@ extern "C" int pvamd_composed_query_f64(const pvamd_grid_t* grids, int32_t S, co
     if (!aligned_to(grids, 8) || !aligned_to(tf, 8) || !aligned_to(points, 8) || !aligned_to(out_val, 8) || !aligned_to(out_grad, 8))
         return PVAMD_E_ALIGN;
     int64_t gy = (P + 255) / 256;
-    const int64_t cap = ((int64_t)65536 + A - 1) / A;
+    int64_t cap = ((int64_t)65536 + A - 1) / A;
+    if (cap > 65535) cap = 65535;  // gridDim.y; the kernel grid-strides over the points
     if (gy > cap) gy = cap;
     hipLaunchKernelGGL(composed_query_f64_kernel, dim3(A, (unsigned)(gy < 1 ? 1 : gy)), dim3(256), 0, (hipStream_t)stream, grids, S,
                        tf, A, points, P, out_val, out_grad, out_leaf);

@@ -16,9 +16,6 @@ namespace pvamd {
 // written with explicit fmaf / __f*_rn so that the CPU oracle can state the same sequence.
 #define PVAMD_DEV __device__ __forceinline__
 
-// The quotient -> index step and the validity test under a NON-default pvamd_grid_t::rule (include/pvamd.h).  Out of line
-// on purpose: these statements only run for descriptors that ask for them, and inlined into the query kernels they cost
-// every launch registers (composed_query_wave: 42 -> 242 spilled VGPRs with them inline).
 // One packed (val, gx, gy, gz) record.  The cache always lives in device (global) memory, but a pointer read out of a
 // descriptor that itself sits in memory is a generic one to the compiler, which then emits flat_load (aperture check, and the
 // load counts against lgkmcnt as well as vmcnt): say which address space it is.
@@ -29,6 +26,9 @@ PVAMD_DEV float4 load_record(const float* vox, int flat) {
     return make_float4(r.x, r.y, r.z, r.w);
 }
 
+// The quotient -> index step and the validity test under a NON-default pvamd_grid_t::rule (include/pvamd.h): inline, but
+// behind ONE wave-uniform branch per coordinate (voxel_index_1d), so that descriptors with the default rule never execute
+// them (a noinline call was worse: the by-value descriptor went through scratch).
 template <typename T>
 PVAMD_DEV T round_by_rule(int rule, T q) {
     if (rule & PVAMD_RULE_ROUND_HALF_AWAY) {

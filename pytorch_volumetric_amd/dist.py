@@ -139,7 +139,9 @@ class ShardedSDF:
         A = math.prod(batch)
         start, stop, per = shard_range(A, world, rank)
         self.last_path = "configs"
-        val, grad = inner.query_configs(flat, start, per)  # (per, P), (per, P, 3)
+        val, grad = inner.query_configs(flat, start, per)  # (per, P), (per, P, 3); float64 for float64 points
+        if val.dtype != self._query_dtype:  # e.g. float16 points: results in the query dtype, as ComposedSDF.__call__ returns them
+            val, grad = val.to(self._query_dtype), grad.to(self._query_dtype)
         if not self.gather:
             return val[:stop - start], grad[:stop - start], (start, stop)
         if self.compute_device is not None:

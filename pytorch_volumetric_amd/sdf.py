@@ -451,6 +451,11 @@ class CachedSDF(ObjectFrameSDF):
     def __setattr__(self, name, value):
         if name in CachedSDF._PLAN_ATTRS:
             _lib.EPOCH[0] += 1  # call plans (this object's and those of compositions over it) are rebuilt on next use
+            if name in ("bb", "_packed"):
+                # ... and so are the descriptors that hold the box / the cache pointer by value: this object's, and (through
+                # the generation number in ComposedSDF._leaf_grids' key) the device arrays of compositions over it
+                self.__dict__.pop("_desc_by_mode", None)
+                self.__dict__["_desc_gen"] = self.__dict__.get("_desc_gen", 0) + 1
         object.__setattr__(self, name, value)
 
     def surface_bounding_box(self, **kwargs):
@@ -703,11 +708,9 @@ class ComposedSDF(ObjectFrameSDF):
     def _footprint_bytes(self, flat):
         """Upper estimate of the leaf-grid bytes one configuration's query touches: the cells of the finest leaf grid that
         the points' bounding box covers (at least one cell thick per axis, at most one per point), a 64-byte line each,
-        for every leaf.  One small kernel + one device->host read (~25 us), remembered per point tensor."""
-        key = (flat.data_ptr(), flat._version, flat.shape[0])
-        hit = self.__dict__.get("_footprint_cache")
-        if hit is not None and hit[0] == key:
-            return hit[1]
+        for every leaf.  One small kernel + one device->host read (~25 us) per call: not remembered -- a planner that allocates
+        a fresh point tensor every step gets the same address back from the caching allocator, so no cheap key tells a new
+        query from the last one."""
         box = torch.empty((2, 3), dtype=torch.float32, device=flat.device)
         _lib.check(_lib.load().pvamd_points_aabb(_lib.ptr(flat), flat.shape[0], _lib.ptr(box), _lib.stream_ptr()),
                    "pvamd_points_aabb")
@@ -718,9 +721,7 @@ class ComposedSDF(ObjectFrameSDF):
         for d in range(3):
             e = float(extent[d])
             cells *= max(1.0, e / res) if math.isfinite(e) else float("inf")
-        out = min(cells, float(flat.shape[0])) * 64.0 * len(self.sdfs)
-        self._footprint_cache = (key, out)
-        return out
+        return min(cells, float(flat.shape[0])) * 64.0 * len(self.sdfs)
 
     def _owner_device(self):
         """The one GPU every leaf grid lives on (the fused kernel reads all of them through raw pointers)."""
@@ -730,7 +731,7 @@ class ComposedSDF(ObjectFrameSDF):
         return next(iter(devs))
 
     def _leaf_grids(self, dev):
-        key = tuple((id(s), s._packed.data_ptr()) for s in self.sdfs) + (str(dev),)
+        key = tuple((id(s), s._packed.data_ptr(), s.__dict__.get("_desc_gen", 0)) for s in self.sdfs) + (str(dev),)
         if self._grids_dev is None or self._grids_key != key:
             host = [s._grid_desc() for s in self.sdfs]
             descs = (_lib.GridDesc * len(self.sdfs))(*host)
@@ -904,9 +905,23 @@ class ComposedSDF(ObjectFrameSDF):
             raise ValueError("query_configs needs BOUNDING_BOX CachedSDF leaves and a configuration batch")
         S, A = len(self.sdfs), math.prod(self.tsf_batch)
         dev = self._owner_device()
+        pick = torch.arange(first, first + count, device=dev).clamp_max(A - 1)
+        if torch.is_tensor(points) and points.dtype == torch.float64:
+            # float64 query points stay float64 (sdf.py:395-431 over sdf.py:545-547), as in __call__ / _call_f64
+            flat = points.detach().reshape(-1, 3).to(device=dev, dtype=torch.float64).contiguous()
+            P = flat.shape[0]
+            sub = tf.as_matrix(self.obj_frame_to_link_frame).to(device=dev, dtype=torch.float64).reshape(S, A, 4, 4)[:, pick].contiguous()
+            val = torch.empty((count, P), dtype=torch.float64, device=dev)
+            grad = torch.empty((count, P, 3), dtype=torch.float64, device=dev)
+            if P > 0:
+                with _lib.on_device(dev):
+                    grids = self._leaf_grids(dev)
+                    _lib.check(_lib.load().pvamd_composed_query_f64(_lib.ptr(grids), S, _lib.ptr(sub), count, _lib.ptr(flat), P,
+                                                                    _lib.ptr(val), _lib.ptr(grad), None, _lib.stream_ptr()),
+                               "pvamd_composed_query_f64")
+            return val, grad
         flat, _, _, _ = _lib.as_query_points(points, dev)
         P = flat.shape[0]
-        pick = torch.arange(first, first + count, device=dev).clamp_max(A - 1)
         sub = self._tf_device(dev).reshape(S, A, 4, 4)[:, pick].contiguous()
         val = torch.empty((count, P), dtype=torch.float32, device=dev)
         grad = torch.empty((count, P, 3), dtype=torch.float32, device=dev)

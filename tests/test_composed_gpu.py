@@ -192,7 +192,7 @@ def test_compose_of_mesh_sdfs_like_the_reference_test():
     assert torch.allclose(grads, torch.where((v2 < v1).unsqueeze(-1), g2, g1), atol=1e-5)
 
 
-@pytest.mark.parametrize("flags", [4, 4 | 1, 2])
+@pytest.mark.parametrize("flags", [4, 4 | 16, 4 | 1, 2])
 def test_both_index_modes_give_the_reference_index_where_the_estimate_is_shaky(flags):
     """pvamd_composed_query's tuning hints must never change a result: wave-tile kernel with flagged points redone after the
     loop (4), with the exact statements inline (4 | 1), and the per-lane kernel (2).  A leaf far from its own origin (coordinates ~200 x the resolution -> a wide error bound on the
