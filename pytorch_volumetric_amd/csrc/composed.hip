@@ -363,159 +363,41 @@ PVAMD_DEV void tile_passes(const pvamd_grid_t* __restrict__ grids, int S, const 
 }
 
 
-// ---- round 4: the in-range lookups of a pass leave the leaf loop ----
-// On scattered points (C3, C4) a leaf's range holds 1-5 % of the points, so most wave visits ran the ~29-instruction index
-// + gather path for one or two live lanes, and every visit paid an exact square root to order candidates that are almost
-// all bounding-box distances.  Here the leaf loop keeps the OUT-OF-RANGE candidates only, ordered by the SQUARED norm (sqrt
-// is monotone: n2_b < n2_a decides, except where the two correctly rounded roots could coincide -- a band of 2^-21
-// relative, re-decided with both exact roots behind a wave-uniform branch; exact ties keep the incumbent as torch.argmin
-// does); the winner's root is taken once per point.  An IN-RANGE visit only sets bit s of the lane's leaf mask (one
-// exec-masked v_or).  After the loop every lane walks ITS OWN set bits in ascending leaf order -- lanes work on different
-// leaves at the same time, so a wave iterates max-over-lanes popcount times (1-2 on C4) instead of once per leaf -- with the
-// leaf's constants (its 3x4 matrix for this configuration and the index-estimate numbers) read per lane from a table the
-// block built in LDS.  The two minima are then compared by (value, leaf): the reference's first minimum over all leaves
-// (sdf.py:421), bit for bit.  A first version compacted the in-range (point, leaf) pairs across lanes through an LDS queue
-// and 64-bit LDS atomics: fewer vector instructions still, but SLOWER than the round-3 loop (C4 0.754 vs 0.706 ms) -- every
-// drained pair read its leaf's 26 constants with per-lane global loads (64 distinct lines per instruction through the
-// TCP) and paid two fences; profiles/r04_composed_ab.txt.
+// ---- round 4: two running minima instead of one ----
+// The round-3 loop keeps ONE first minimum over all candidates, so every visit pays an exact square root (11 vector
+// instructions) to bring its bounding-box candidate into the domain of the cached values, and a five-register update.
+// Here the OUT-OF-RANGE candidates have their own register minimum ordered by the SQUARED norm (sqrt is monotone: n2_b <
+// n2_a decides, except where the two correctly rounded roots could coincide -- a band of 2^-21 relative, re-decided with
+// both exact roots behind a wave-uniform branch; exact ties keep the incumbent as torch.argmin does) and the winner's root
+// is taken once per point; the IN-RANGE candidates keep (value, leaf, flat index) -- three registers, the record is
+// gathered once more for the winner -- and the two are compared by (value, leaf) at the end: the reference's first minimum
+// over all leaves (sdf.py:421), bit for bit.
+// Tried first and measured slower than the round-3 loop although they issue fewer vector instructions
+// (profiles/r04_composed_variants.txt): the in-range (point, leaf) pairs compacted across lanes and visits in an LDS queue,
+// drained 64 at a time with the leaf constants from per-lane global reads (v1) or an LDS table (v3), and a per-lane leaf
+// bitmask walked after the loop (v2) -- the queue's drains and merges are chains of dependent LDS / memory round trips
+// that the wave waits out (SQ_WAIT_ANY + 64 %), and the bitmask walk runs ~3 iterations at 2 live lanes.
 constexpr float kNearTie = 0.99999952316284179688f;  // 1 - 2^-21: sqrt_rn(n2_b) == sqrt_rn(n2_a) needs n2_b >= n2_a (1 - 2^-22)
 constexpr int kNoLeaf = kUnnormalised - 1;           // "no candidate yet": loses every (value, leaf) tie
-constexpr int kDeferredMaxLeaves = 256;              // rows of the block's LDS table (28 KB at 256; sized by S at launch)
 
 struct BestOut {
     float n2, tx, ty, tz;  // squared bounding-box distance and the (unnormalised) bounding-box vector, leaf frame
     int leaf;
 };
-
-// One row per leaf, for the block's configuration: what a per-lane lookup needs, 16-byte groups for ds_read_b128.
-//   [0..11] 3x4 obj->leaf matrix   [12..14] fmin  [15] shape[1]   [16..18] inv32  [19] shape[2]   [20..22] err32
-//   [23] nx*ny*nz - 1              [24,25] vox pointer            [26,27] unused
-constexpr int kLeafRow = 28;
-
-PVAMD_DEV void build_leaf_table(const pvamd_grid_t* __restrict__ grids, int S, const float* __restrict__ tf, int A, int a,
-                                float* table) {
-    for (int s = threadIdx.x; s < S; s += blockDim.x) {
-        const pvamd_grid_t& g = grids[s];
-        const float* M = tf + 16 * ((int64_t)s * A + a);
-        float* row = table + kLeafRow * s;
-#pragma unroll
-        for (int j = 0; j < 12; ++j) row[j] = M[j];
-#pragma unroll
-        for (int d = 0; d < 3; ++d) {
-            row[12 + d] = g.fmin[d];
-            row[16 + d] = g.inv32[d];
-            row[20 + d] = g.err32[d];
-        }
-        row[15] = __int_as_float(g.shape[1]);
-        row[19] = __int_as_float(g.shape[2]);
-        row[23] = __int_as_float(g.shape[0] * g.shape[1] * g.shape[2] - 1);
-        const uint64_t vox = (uint64_t)(uintptr_t)g.vox;
-        row[24] = __uint_as_float((uint32_t)vox);
-        row[25] = __uint_as_float((uint32_t)(vox >> 32));
-        row[26] = row[27] = 0.f;
-    }
-}
-
-// ---- in-range (point, leaf) pairs compacted across lanes and visits ----
-// float -> uint32 whose unsigned order is the float order, -0 == +0, NaN below everything (argmin counts NaN as minimum)
-PVAMD_DEV uint32_t ordered_key(float v) {
-    const uint32_t u = __float_as_uint(add_rn(v, 0.f));  // -0 + 0 = +0
-    const uint32_t k = (u & 0x80000000u) ? ~u : (u | 0x80000000u);
-    return (v != v) ? 0u : k;
-}
-PVAMD_DEV unsigned long long candidate_key(float v, int s) { return ((unsigned long long)ordered_key(v) << 32) | (unsigned)s; }
-
-typedef unsigned long long u64_lds __attribute__((may_alias));
-typedef uint32_t u32_lds __attribute__((may_alias));
-constexpr int kQueueDense = 16;     // a visit with this many lanes in range looks its records up itself (wave-uniform leaf)
-constexpr int kQueueLeafShift = 7;  // queue entry = local point (7 bits: 64 * PPP = 128) | leaf << 7
-
-// Up to 64 queued pairs, one per lane: the point comes out of its owner's registers (ds_bpermute), the leaf's constants out
-// of the block's LDS table (a per-lane global read of them was what made the first version slower than the round-3 loop),
-// the candidate goes to the point's slot by a 64-bit LDS atomic min on (ordered value, leaf); whoever holds the minimum
-// afterwards leaves its flat index beside it.
-template <int PPP>
-PVAMD_DEV void drain_queue(const pvamd_grid_t* __restrict__ grids, const float* table, const float (&px)[PPP],
-                           const float (&py)[PPP], const float (&pz)[PPP], u64_lds* keys, u32_lds* flats,
-                           const u32_lds* queue, int& count, int lane) {
-    PVAMD_WAVE_SYNC();
-    const int n = count < 64 ? count : 64;
-    const bool active = lane < n;
-    const uint32_t e = active ? queue[count - n + lane] : (uint32_t)lane;  // inactive: own point, leaf 0, discarded
-    count -= n;
-    const int q = e & (64 * PPP - 1), s = (int)(e >> kQueueLeafShift);
-    const int src = (q & 63) << 2, k = q >> 6;
-    float x0 = 0.f, y0 = 0.f, z0 = 0.f;
-#pragma unroll
-    for (int j = 0; j < PPP; ++j) {
-        const float bx = __int_as_float(__builtin_amdgcn_ds_bpermute(src, __float_as_int(px[j])));
-        const float by = __int_as_float(__builtin_amdgcn_ds_bpermute(src, __float_as_int(py[j])));
-        const float bz = __int_as_float(__builtin_amdgcn_ds_bpermute(src, __float_as_int(pz[j])));
-        x0 = (k == j) ? bx : x0;
-        y0 = (k == j) ? by : y0;
-        z0 = (k == j) ? bz : z0;
-    }
-    const f32x4_alias* row = reinterpret_cast<const f32x4_alias*>(table + kLeafRow * s);
-    const f32x4 m0 = row[0], m1 = row[1], m2 = row[2], c0 = row[3], c1 = row[4], c2 = row[5], c3 = row[6];
-    const float x = affine_row(m0.x, m0.y, m0.z, m0.w, x0, y0, z0);  // the leaf loop's statement on the same numbers: same bits
-    const float y = affine_row(m1.x, m1.y, m1.z, m1.w, x0, y0, z0);
-    const float z = affine_row(m2.x, m2.y, m2.z, m2.w, x0, y0, z0);
-    const float p[3] = {x, y, z};
-    const float fmin[3] = {c0.x, c0.y, c0.z}, inv32[3] = {c1.x, c1.y, c1.z}, err32[3] = {c2.x, c2.y, c2.z};
-    int kk[3];
-    bool shaky = false;
-#pragma unroll
-    for (int d = 0; d < 3; ++d) {  // voxel_flat_estimate's statements on the row's numbers
-        const float t = mul_rn(sub_rn(p[d], fmin[d]), inv32[d]);
-        const float kc = __builtin_rintf(t);
-        shaky |= !(sub_rn(0.5f, fabsf(sub_rn(t, kc))) > err32[d]);
-        kk[d] = (int)kc;
-    }
-    if (__builtin_expect(wave_any(shaky & active), 0)) {
-        if (shaky & active) {  // the reference's own statements (IEEE division in the leaf's index dtype); rare: per-lane reads
-            const pvamd_grid_t& g = grids[s];
-#pragma unroll 1
-            for (int d = 0; d < 3; ++d) {
-                long long kd;
-                if (g.index_f64) voxel_index_1d<true>(g, d, p[d], kd);
-                else voxel_index_1d<false>(g, d, p[d], kd);
-                kk[d] = (int)kd;
-            }
-        }
-    }
-    const int ny = __float_as_int(c0.w), nz = __float_as_int(c1.w);
-    const unsigned last = __float_as_uint(c2.w);
-    const unsigned flat_u = (unsigned)((kk[0] * ny + kk[1]) * nz + kk[2]);
-    const int flat = (int)(flat_u < last ? flat_u : last);
-    float v = 0.f;
-    if (active) {
-        const uint64_t vox = (uint64_t)__float_as_uint(c3.x) | ((uint64_t)__float_as_uint(c3.y) << 32);
-        v = load_record(reinterpret_cast<const float*>((uintptr_t)vox), flat).x;
-    }
-    const unsigned long long mine = active ? candidate_key(v, s) : ~0ull;
-    __hip_atomic_fetch_min(&keys[q], mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
-    PVAMD_WAVE_SYNC();
-    const unsigned long long cur = keys[q];
-    if (active && cur == mine) flats[q] = (uint32_t)flat;  // one lane per point: (value, leaf) is unique per point
-    PVAMD_WAVE_SYNC();
-}
-
-struct BestIn {  // the in-range minimum of the dense visits, by the owning lane
+struct BestIn {
     float v;
     int leaf, flat;
 };
 
 template <int PPP, bool PACKED, bool MASKED>
-PVAMD_DEV void tile_passes_deferred(const pvamd_grid_t* __restrict__ grids, int S, const float* __restrict__ tf, int A, int a,
-                                    int64_t first, int64_t P, float* __restrict__ val, int* __restrict__ leaf, float* spf,
-                                    const float* table, int lane, uint64_t todo, float lower) {
-    static_assert(PPP == 2, "queue capacity: 64 + PPP * (kQueueDense - 1) entries in the pass's 64 * PPP value slots");
+PVAMD_DEV void tile_passes_split(const pvamd_grid_t* __restrict__ grids, int S, const float* __restrict__ tf, int A, int a,
+                                 int64_t first, int64_t P, float* __restrict__ val, int* __restrict__ leaf, float* spf,
+                                 int lane, uint64_t todo, float lower) {
     float* svf = spf + 768;
     const int first_leaf = todo ? __builtin_ctzll(todo) : 0;
     const bool refine = MASKED && S <= 64 && todo != ((S >= 64) ? ~0ull : ((1ull << S) - 1ull));
     const uint64_t everyone = __builtin_amdgcn_ballot_w64(true);
-    // ONE copy of the pass (the round-3 loop unrolls its passes): the body carries the drain as well
-#pragma unroll 1
+#pragma unroll
     for (int h = 0; h < 4; h += PPP) {
         float px[PPP], py[PPP], pz[PPP];
         BestOut best[PPP];
@@ -531,24 +413,8 @@ PVAMD_DEV void tile_passes_deferred(const pvamd_grid_t* __restrict__ grids, int 
             bin[k] = BestIn{__builtin_inff(), kNoLeaf, 0};
             unsure[k] = 0;
         }
-        // the pass's points are in registers: their LDS slots become the per-point keys + flat indices (xyz slots) and the
-        // queue (value slots)
-        u64_lds* keys = reinterpret_cast<u64_lds*>(spf + 192 * h);
-        u32_lds* flats = reinterpret_cast<u32_lds*>(spf + 192 * h + 128 * PPP);
-        u32_lds* queue = reinterpret_cast<u32_lds*>(svf + 64 * h);
-        PVAMD_WAVE_SYNC();
-#pragma unroll
-        for (int k = 0; k < PPP; ++k) keys[64 * k + lane] = ~0ull;
-        int count = 0;  // wave-uniform; < 64 at the top of every visit
         uint64_t rem = todo;
-        // s == S is the drain of what is left: one call site for the drain
-        for (int s = 0; s <= S; ++s) {
-            if (s == S || count >= 64) {
-                // during the loop: down to fewer than 64 waiting pairs; after the last leaf: until none is left
-                const int keep = s == S ? 0 : 63;
-                while (count > keep) drain_queue<PPP>(grids, table, px, py, pz, keys, flats, queue, count, lane);
-                if (s == S) break;
-            }
+        for (int s = 0; s < S; ++s) {
             if (MASKED && s < 64 && !((rem >> s) & 1ull)) continue;  // wave-uniform
             const float* M = tf + 16 * ((int64_t)s * A + a);  // wave-uniform: scalar loads
             const pvamd_grid_t& g = grids[s];
@@ -559,25 +425,19 @@ PVAMD_DEV void tile_passes_deferred(const pvamd_grid_t* __restrict__ grids, int 
                 const float z = affine_row(M[8], M[9], M[10], M[11], px[k], py[k], pz[k]);
                 const uint64_t vm = in_range_mask(g, x, y, z);
                 if (vm != 0) {
-                    const int n = __builtin_popcountll(vm);
+                    // the lanes in range look their value up (index estimate; shaky ones are redone exactly below)
                     const bool valid = __builtin_amdgcn_inverse_ballot_w64(vm);
-                    if (n >= kQueueDense) {
-                        // many lanes in range: each looks its own value up (index estimate; shaky ones are redone below)
-                        bool shaky = false;
-                        const int flat = voxel_flat_estimate(g, x, y, z, shaky);
-                        unsure[k] |= vm & __builtin_amdgcn_ballot_w64(shaky);
-                        float v = __builtin_inff();
-                        if (valid) v = load_record(g.vox, flat).x;
-                        // ascending leaves: "strictly smaller, or the first" is the first minimum; NaN counts as minimum
-                        const bool t = valid & ((bin[k].leaf == kNoLeaf) | (!(v >= bin[k].v) & (bin[k].v == bin[k].v)));
-                        bin[k].v = t ? v : bin[k].v;
-                        bin[k].leaf = t ? s : bin[k].leaf;
-                        bin[k].flat = t ? flat : bin[k].flat;
-                    } else {
-                        const int rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(vm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)vm, 0));
-                        if (valid) queue[count + rank] = (uint32_t)(64 * k + lane) | ((uint32_t)s << kQueueLeafShift);
-                        count += n;  // < 64 + PPP * kQueueDense: drained at the top of the next visit
-                    }
+                    bool shaky = false;
+                    const int flat = voxel_flat_estimate(g, x, y, z, shaky);
+                    unsure[k] |= vm & __builtin_amdgcn_ballot_w64(shaky);
+                    float v = __builtin_inff();
+                    if (valid) v = reinterpret_cast<const float __attribute__((address_space(1)))*>((uintptr_t)g.vox)[4 * (int64_t)flat];
+                    // ascending leaves: "strictly smaller, or the first" is the first minimum; NaN counts as the minimum
+                    const uint64_t better = __builtin_amdgcn_ballot_w64(!(v >= bin[k].v)) & __builtin_amdgcn_ballot_w64(bin[k].v == bin[k].v);
+                    const bool t = __builtin_amdgcn_inverse_ballot_w64(vm & (better | __builtin_amdgcn_ballot_w64(bin[k].leaf == kNoLeaf)));
+                    bin[k].v = t ? v : bin[k].v;
+                    bin[k].leaf = t ? s : bin[k].leaf;
+                    bin[k].flat = t ? flat : bin[k].flat;
                     if (vm == everyone) continue;
                 }
                 // sdf.py:559-568 for every lane, squared (no exec masking; in-range lanes are masked out of the take)
@@ -602,7 +462,7 @@ PVAMD_DEV void tile_passes_deferred(const pvamd_grid_t* __restrict__ grids, int 
                 best[k].leaf = t ? s : best[k].leaf;
             }
             if (refine) {
-                // every point's final value is <= its out-of-range minimum and <= what its own dense look-ups found
+                // every point's final value is <= its out-of-range minimum and <= its in-range minimum
                 float m = -__builtin_inff();
 #pragma unroll
                 for (int k = 0; k < PPP; ++k)
@@ -611,7 +471,6 @@ PVAMD_DEV void tile_passes_deferred(const pvamd_grid_t* __restrict__ grids, int 
                 rem &= ~__builtin_amdgcn_ballot_w64(lower > ub + 1e-6f * fabsf(ub));
             }
         }
-        PVAMD_WAVE_SYNC();
         Best fin[PPP];
 #pragma unroll
         for (int k = 0; k < PPP; ++k) {
@@ -622,22 +481,11 @@ PVAMD_DEV void tile_passes_deferred(const pvamd_grid_t* __restrict__ grids, int 
             fin[k].gy = best[k].ty;
             fin[k].gz = best[k].tz;
             fin[k].tag = (best[k].leaf == kNoLeaf ? first_leaf : best[k].leaf) | kUnnormalised;
-            // in-range minimum: the slot (drained pairs) against the lane's own dense look-ups, by (value, leaf)
-            const unsigned long long key_s = keys[64 * k + lane];
-            const unsigned long long key_d = bin[k].leaf != kNoLeaf ? candidate_key(bin[k].v, bin[k].leaf) : ~0ull;
-            const bool from_slot = key_s < key_d;
-            const unsigned long long key = from_slot ? key_s : key_d;
-            const bool has = key != ~0ull;
+            const bool has = bin[k].leaf != kNoLeaf;
             if (wave_any(has)) {
-                const int li = has ? (int)(uint32_t)key : 0;
-                int flat = bin[k].flat;
-                if (from_slot) flat = (int)flats[64 * k + lane];
+                const int li = has ? bin[k].leaf : 0;
                 float4 r = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (has) {
-                    const float* row = table + kLeafRow * li;
-                    const uint64_t vox = (uint64_t)__float_as_uint(row[24]) | ((uint64_t)__float_as_uint(row[25]) << 32);
-                    r = load_record(reinterpret_cast<const float*>((uintptr_t)vox), flat);
-                }
+                if (has) r = load_record(grids[li].vox, bin[k].flat);  // per-lane descriptor read: S distinct addresses at most
                 // (value, leaf) order with NaN as the smallest value: sdf.py:421 over all leaves
                 const float vi = r.x, vo = fin[k].v;
                 const bool vi_nan = vi != vi, vo_nan = vo != vo;
@@ -651,7 +499,7 @@ PVAMD_DEV void tile_passes_deferred(const pvamd_grid_t* __restrict__ grids, int 
                 fin[k].tag = wins ? li : fin[k].tag;
             }
         }
-        // the few points whose index estimate (dense visits) could not be trusted for some leaf: all over again, exactly
+        // the few points whose index estimate could not be trusted for some leaf: all over again, exactly
 #pragma unroll
         for (int k = 0; k < PPP; ++k) {
             if (__builtin_expect(unsure[k] != 0, 0)) {
@@ -661,7 +509,6 @@ PVAMD_DEV void tile_passes_deferred(const pvamd_grid_t* __restrict__ grids, int 
                 if (__builtin_amdgcn_inverse_ballot_w64(unsure[k])) fin[k] = redo;
             }
         }
-        PVAMD_WAVE_SYNC();  // every lane is done with the keys before results overwrite them
 #pragma unroll
         for (int k = 0; k < PPP; ++k) {
             const int p = lane + 64 * (h + k);
@@ -682,7 +529,69 @@ PVAMD_DEV void tile_passes_deferred(const pvamd_grid_t* __restrict__ grids, int 
     }
 }
 
-template <int PPP, int MODE, bool PACKED, int DEFER>
+// The same two minima for ONE point per lane (composed_query_scalar): all leaves, the exact index statements inline.
+PVAMD_DEV Best walk_leaves_split(const pvamd_grid_t* __restrict__ grids, int S, const float* __restrict__ tf, int A, int a,
+                                 float px, float py, float pz) {
+    BestOut best{__builtin_inff(), __builtin_nanf(""), __builtin_nanf(""), __builtin_nanf(""), kNoLeaf};
+    BestIn bin{__builtin_inff(), kNoLeaf, 0};
+    const uint64_t everyone = __builtin_amdgcn_ballot_w64(true);
+    for (int s = 0; s < S; ++s) {
+        const float* M = tf + 16 * ((int64_t)s * A + a);  // wave-uniform: scalar loads
+        const pvamd_grid_t& g = grids[s];
+        const float x = affine_row(M[0], M[1], M[2], M[3], px, py, pz);
+        const float y = affine_row(M[4], M[5], M[6], M[7], px, py, pz);
+        const float z = affine_row(M[8], M[9], M[10], M[11], px, py, pz);
+        const uint64_t vm = in_range_mask(g, x, y, z);
+        if (vm != 0) {
+            const bool valid = __builtin_amdgcn_inverse_ballot_w64(vm);
+            const int flat = voxel_flat_in_range_fused(g, x, y, z);
+            float v = __builtin_inff();
+            if (valid) v = reinterpret_cast<const float __attribute__((address_space(1)))*>((uintptr_t)g.vox)[4 * (int64_t)flat];
+            const uint64_t better = __builtin_amdgcn_ballot_w64(!(v >= bin.v)) & __builtin_amdgcn_ballot_w64(bin.v == bin.v);
+            const bool t = __builtin_amdgcn_inverse_ballot_w64(vm & (better | __builtin_amdgcn_ballot_w64(bin.leaf == kNoLeaf)));
+            bin.v = t ? v : bin.v;
+            bin.leaf = t ? s : bin.leaf;
+            bin.flat = t ? flat : bin.flat;
+            if (vm == everyone) continue;
+        }
+        const float ta = __builtin_amdgcn_fmed3f(sub_rn(x, g.bb_min[0]), sub_rn(x, g.bb_max[0]), 0.f);
+        const float tb = __builtin_amdgcn_fmed3f(sub_rn(y, g.bb_min[1]), sub_rn(y, g.bb_max[1]), 0.f);
+        const float tc = __builtin_amdgcn_fmed3f(sub_rn(z, g.bb_min[2]), sub_rn(z, g.bb_max[2]), 0.f);
+        const float n2 = fmaf(tc, tc, fmaf(tb, tb, mul_rn(ta, ta)));
+        uint64_t take = __builtin_amdgcn_ballot_w64(!(n2 >= best.n2)) & __builtin_amdgcn_ballot_w64(best.n2 == best.n2) & ~vm;
+        const uint64_t near = take & __builtin_amdgcn_ballot_w64(n2 >= mul_rn(best.n2, kNearTie));
+        if (__builtin_expect(near != 0, 0)) {
+            const float ra = sqrt_rn_sumsq(best.n2), rb = sqrt_rn_sumsq(n2);
+            take &= ~(near & __builtin_amdgcn_ballot_w64(!(rb < ra)));
+        }
+        const bool t = __builtin_amdgcn_inverse_ballot_w64(take);
+        best.n2 = t ? n2 : best.n2;
+        best.tx = t ? ta : best.tx;
+        best.ty = t ? tb : best.ty;
+        best.tz = t ? tc : best.tz;
+        best.leaf = t ? s : best.leaf;
+    }
+    Best fin{sqrt_rn_sumsq(best.n2), best.tx, best.ty, best.tz, (best.leaf == kNoLeaf ? 0 : best.leaf) | kUnnormalised};
+    const bool has = bin.leaf != kNoLeaf;
+    if (wave_any(has)) {
+        const int li = has ? bin.leaf : 0;
+        float4 r = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (has) r = load_record(grids[li].vox, bin.flat);
+        const float vi = r.x, vo = fin.v;
+        const bool vi_nan = vi != vi, vo_nan = vo != vo;
+        const bool less = (vi_nan & !vo_nan) | (vi < vo);
+        const bool same = (vi == vo) | (vi_nan & vo_nan);
+        const bool wins = has & (less | (same & (li < best.leaf)));
+        fin.v = wins ? vi : fin.v;
+        fin.gx = wins ? r.y : fin.gx;
+        fin.gy = wins ? r.z : fin.gy;
+        fin.gz = wins ? r.w : fin.gz;
+        fin.tag = wins ? li : fin.tag;
+    }
+    return fin;
+}
+
+template <int PPP, int MODE, bool PACKED, int SPLIT>
 __global__ __launch_bounds__(kWavesPerBlock * 64, MODE == kEstimate ? PVAMD_COMPOSED_MINWAVES : PVAMD_COMPOSED_MINWAVES_INLINE) void composed_query_wave(const pvamd_grid_t* __restrict__ grids, int S,
                                                                            const float* __restrict__ tf, int A,
                                                                            const float* __restrict__ pts,
@@ -692,7 +601,6 @@ __global__ __launch_bounds__(kWavesPerBlock * 64, MODE == kEstimate ? PVAMD_COMP
                                                                            int* __restrict__ leaf, int a0) {
     __shared__ __attribute__((aligned(16))) float lds[kWavesPerBlock][1024];
     __shared__ float cull[kMaxCullLeaves][8];
-    extern __shared__ __attribute__((aligned(16))) float leaf_table[];  // DEFER: S rows of kLeafRow floats (dynamic: sized by S)
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     float* spf = lds[wave];
     f32x4_alias* sp = reinterpret_cast<f32x4_alias*>(spf);
@@ -701,7 +609,6 @@ __global__ __launch_bounds__(kWavesPerBlock * 64, MODE == kEstimate ? PVAMD_COMP
     // points stay in L2 -- what matters once the grids are far larger than L2 (README-size link grids)
     const int a = a0 + blockIdx.x;
     build_cull_spheres(grids, S, tf, A, a, cull);
-    if constexpr (DEFER != 0) build_leaf_table(grids, S, tf, A, a, leaf_table);
     __syncthreads();
     // The mask drops leaves only for tiles that are small against the scene, and costs ~150 instructions a tile (6 % of
     // C4 on random points, where it drops nothing: 0.834 -> 0.792 ms without it).  `scene` = radius about leaf 0's centre
@@ -750,9 +657,9 @@ __global__ __launch_bounds__(kWavesPerBlock * 64, MODE == kEstimate ? PVAMD_COMP
         // two copies of the leaf loop only where instructions are what binds (kEstimate: grids that live in L2); the
         // gather-bound kInlineExact build loses more to the larger body than the simpler loop gives (README-size robot,
         // sorted points: 1.00 -> 1.10 ms with both copies)
-        if constexpr (DEFER != 0) {
-            if (masked) tile_passes_deferred<PPP, PACKED, true>(grids, S, tf, A, a, first, P, val, leaf, spf, leaf_table, lane, todo, lower);
-            else tile_passes_deferred<PPP, PACKED, false>(grids, S, tf, A, a, first, P, val, leaf, spf, leaf_table, lane, todo, lower);
+        if constexpr (SPLIT != 0) {
+            if (masked) tile_passes_split<PPP, PACKED, true>(grids, S, tf, A, a, first, P, val, leaf, spf, lane, todo, lower);
+            else tile_passes_split<PPP, PACKED, false>(grids, S, tf, A, a, first, P, val, leaf, spf, lane, todo, lower);
         } else {
             if (MODE != kEstimate || masked) tile_passes<PPP, MODE, PACKED, true>(grids, S, tf, A, a, first, P, val, leaf, spf, lane, todo, lower);
             else tile_passes<PPP, MODE, PACKED, false>(grids, S, tf, A, a, first, P, val, leaf, spf, lane, todo, lower);
@@ -770,6 +677,7 @@ __global__ __launch_bounds__(kWavesPerBlock * 64, MODE == kEstimate ? PVAMD_COMP
     }
 }
 
+template <bool SPLIT>
 __global__ __launch_bounds__(256) void composed_query_scalar(const pvamd_grid_t* __restrict__ grids, int S,
                                                               const float* __restrict__ tf, int A,
                                                               const float* __restrict__ pts, int64_t first,
@@ -791,8 +699,12 @@ __global__ __launch_bounds__(256) void composed_query_scalar(const pvamd_grid_t*
         const float nanv = __builtin_nanf("");
         const float px = live ? pts[3 * i] : nanv, py = live ? pts[3 * i + 1] : nanv, pz = live ? pts[3 * i + 2] : nanv;
         Best best = best_init(0);
-        bool unsure = false;
-        walk_leaves<kInlineExact>(grids, S, tf, A, a, ~0ull, px, py, pz, best, unsure);
+        if constexpr (SPLIT) {
+            best = walk_leaves_split(grids, S, tf, A, a, px, py, pz);
+        } else {
+            bool unsure = false;
+            walk_leaves<kInlineExact>(grids, S, tf, A, a, ~0ull, px, py, pz, best, unsure);
+        }
         if (live) {
             const int s_win = best.tag & (kUnnormalised - 1);
             float gx, gy, gz;
@@ -971,9 +883,8 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void composed_unpermute_kernel
 
 using namespace pvamd;
 
-// the round-3 leaf loop (every candidate through the register minimum): on request, or for more leaves than a point's mask holds
-static inline bool legacy_leaf_loop(int32_t flags, int32_t S) { return (flags & PVAMD_COMPOSED_LEGACY_LEAF_LOOP) || S > kDeferredMaxLeaves; }
-static inline size_t leaf_table_bytes(int32_t S) { return (size_t)S * kLeafRow * sizeof(float); }
+// the round-3 leaf loop (one register minimum over all candidates, exact roots inside the loop): on request
+static inline bool legacy_leaf_loop(int32_t flags, int32_t S) { return (flags & PVAMD_COMPOSED_LEGACY_LEAF_LOOP) || S >= kNoLeaf; }
 
 extern "C" int pvamd_composed_query_packed(const pvamd_grid_t* grids, int32_t S, const float* tf, int32_t A,
                                            const float* points, int64_t Pp, float* out_rec, int32_t flags, void* stream) {
@@ -993,7 +904,7 @@ extern "C" int pvamd_composed_query_packed(const pvamd_grid_t* grids, int32_t S,
                            dim3(kWavesPerBlock * 64), 0, s, grids, S, tf, A, points, ntiles, Pp, out_rec, nullptr, nullptr, 0);
     else
         hipLaunchKernelGGL((composed_query_wave<PVAMD_COMPOSED_PPP, kEstimate, true, 1>), dim3(A, (unsigned)tile_blocks),
-                           dim3(kWavesPerBlock * 64), leaf_table_bytes(S), s, grids, S, tf, A, points, ntiles, Pp, out_rec, nullptr, nullptr, 0);
+                           dim3(kWavesPerBlock * 64), 0, s, grids, S, tf, A, points, ntiles, Pp, out_rec, nullptr, nullptr, 0);
     return (int)hipGetLastError();
 }
 
@@ -1075,15 +986,22 @@ extern "C" int pvamd_composed_query(const pvamd_grid_t* grids, int32_t S, const 
                                    grids, S, tf, A, points, ntiles, P, out_val, out_grad, out_leaf, a0);
             else
                 hipLaunchKernelGGL((composed_query_wave<PVAMD_COMPOSED_PPP, kEstimate, false, 1>), dim3(An, gy), dim3(kWavesPerBlock * 64),
-                                   leaf_table_bytes(S), s, grids, S, tf, A, points, ntiles, P, out_val, out_grad, out_leaf, a0);
+                                   0, s, grids, S, tf, A, points, ntiles, P, out_val, out_grad, out_leaf, a0);
         } else {
             const int64_t need = (P + 255) / 256;
             const unsigned gx = (unsigned)(need < cap ? need : (cap < 1 ? 1 : cap));
             // configuration fastest unless flag 8 asks for the other order (tuning): with it the A = 200 README case runs
             // 0.076 instead of 0.079 ms on the slice and 0.265 instead of 0.323 ms on random points (21 MB link grids)
             const int cf = (flags & 8) ? 0 : 1;
-            hipLaunchKernelGGL(composed_query_scalar, cf ? dim3(An, gx) : dim3(gx, An), dim3(256), 0, s, grids, S, tf, A, points,
-                               (int64_t)0, P, out_val, out_grad, out_leaf, a0, cf);
+            // large, gather-bound grids (the inline-exact hint): the two minima cost a second gather of the winner's record
+            // and lose 6-12 % there (README-size link grids, 200 x 15,251: 0.087 vs 0.082 ms on the slice, 0.300 vs 0.268 ms
+            // on random points); L2-resident grids gain 7-18 % (C4 per-lane 0.975 -> 0.899 ms, README slice 0.062 -> 0.058)
+            if (legacy_leaf_loop(flags, S) || (flags & PVAMD_COMPOSED_INLINE_EXACT))
+                hipLaunchKernelGGL(composed_query_scalar<false>, cf ? dim3(An, gx) : dim3(gx, An), dim3(256), 0, s, grids, S, tf, A, points,
+                                   (int64_t)0, P, out_val, out_grad, out_leaf, a0, cf);
+            else
+                hipLaunchKernelGGL(composed_query_scalar<true>, cf ? dim3(An, gx) : dim3(gx, An), dim3(256), 0, s, grids, S, tf, A, points,
+                                   (int64_t)0, P, out_val, out_grad, out_leaf, a0, cf);
         }
     }
     return (int)hipGetLastError();

@@ -13,7 +13,7 @@ from tests import helpers as H
 
 pytestmark = pytest.mark.gpu
 
-WAVE, LEGACY, PER_LANE = 4, 4 | 16, 2
+WAVE, LEGACY, PER_LANE, PER_LANE_LEGACY = 4, 4 | 16, 2, 2 | 16
 
 
 def make_leaf(f64=True, res=0.01, padding=0.1, flip=False):
@@ -46,8 +46,8 @@ def check_all_kernels(leaves, tfm, A, pts):
     comp = pv.ComposedSDF(leaves, None)
     comp.set_transforms(pv.Transform3d(matrix=tfm), batch_dim=(A,) if A > 1 else None)
     oval, ograd, oleaf = oracle.composed_query([H.oracle_grid_from_cached(l) for l in leaves], tfm.numpy(), A, pts.numpy())
-    for flags in (WAVE, LEGACY, PER_LANE):
-        if flags != PER_LANE and pts.shape[0] < 256:
+    for flags in (WAVE, LEGACY, PER_LANE, PER_LANE_LEGACY):
+        if not (flags & 2) and pts.shape[0] < 256:
             continue
         val, grad, leaf = query_with_leaf_ids(comp, pts, flags)
         assert np.array_equal(val, oval, equal_nan=True), flags

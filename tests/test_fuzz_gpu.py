@@ -100,7 +100,7 @@ def test_composed_query_fuzz(seed):
     comp._leaf_grids(dev)
     # every kernel / index mode the dispatcher can pick (include/pvamd.h): per-lane, wave-tile x {queued leaf loop, round-3
     # leaf loop (16), inline exact}, and the bucketed path (sort, packed records, un-permute) -- all must give the oracle's bits
-    for flags, bucket in ((2, False), (4, False), (4 | 16, False), (4 | 1, False), (0, True), (1, True), (16, True)):
+    for flags, bucket in ((2, False), (2 | 16, False), (4, False), (4 | 16, False), (4 | 1, False), (0, True), (1, True), (16, True)):
         comp._query_flags = flags
         comp.bucket_points = bucket
         val, grad = comp(torch.from_numpy(pts).cuda())

@@ -1,4 +1,4 @@
-"""Composed kernel variants side by side in one process (round 4): dispatcher's choice (0), wave-tile with the queued leaf
+"""Composed kernel variants side by side in one process (round 4): dispatcher's choice (0), wave-tile with the two-minima leaf
 loop (4), wave-tile with the round-3 leaf loop (4 | 16), one point per lane (2) -- C3, C4 (100 KB grids), the README case and
 README-size grids, random and Morton-sorted points.  ms per call: the best of three interleaved rounds of a 12-call median (HIP events)."""
 import os, sys
@@ -10,7 +10,7 @@ import pytorch_volumetric_amd as pv
 from pytorch_volumetric_amd import _lib
 from bench_configs import gpu_time
 
-VARIANTS = ((0, "auto"), (4, "wave-tile queued"), (4 | 16, "wave-tile round-3 loop"), (2, "per-lane"))
+VARIANTS = ((0, "auto"), (4, "wave-tile split-minima"), (4 | 16, "wave-tile round-3 loop"), (2, "per-lane split-minima"), (2 | 16, "per-lane round-3 loop"))
 
 
 def run(name, sdf, pts, A, variants=VARIANTS):
@@ -54,3 +54,11 @@ if "big" in which:
     # base flags = inline exact (1): the queued loop is not used there; 4 and 4 | 16 are the same kernel
     run("C4 200x262144 pad 1.0 random", robot, p4, 200, ((0, "auto"), (2, "per-lane")))
     run("C4 200x262144 pad 1.0 sorted", robot, p4[_lib.morton_order(p4).long()].contiguous(), 200, ((0, "auto"), (2, "per-lane")))
+    _, slice_pts = pv.get_coordinates_and_points_in_grid(0.01, np.array([[-1, 0.5], [0.02, 0.02], [-0.2, 0.8]]))
+    slice_pts = slice_pts.cuda()
+    per_lane = ((0, "auto"), (2, "per-lane split-minima"), (2 | 16, "per-lane round-3 loop"))
+    run("README slice 200x15251 pad 1.0", robot, slice_pts, 200, per_lane)
+    rp = Wk.c4_points(15251)
+    run("README-size random 200x15251 pad 1.0", robot, rp, 200, per_lane)
+    robot.set_joint_configuration(Wk.c4_joint_configs(20))
+    run("README slice 20x15251 pad 1.0", robot, slice_pts, 20, per_lane)

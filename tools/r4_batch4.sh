@@ -1,7 +1,7 @@
 #!/bin/bash
 export TMPDIR=/tmp
-O=gpurun_out/r4b4; mkdir -p $O
+O=gpurun_out/r4b6; mkdir -p $O
 timeout 900 python -m pytest tests/test_composed_queue_gpu.py tests/test_composed_gpu.py tests/test_index_rules.py -q -m gpu > $O/pytest_composed.txt 2>&1; grep -E "^FAILED|passed|failed|AssertionError: " $O/pytest_composed.txt | head -30
 PVAMD_FUZZ_SCALE=4 timeout 600 python -m pytest tests/test_fuzz_gpu.py tests/test_robot_gpu.py tests/test_golden_gpu.py -q -m gpu > $O/pytest_more.txt 2>&1; grep -E "^FAILED|passed|failed|AssertionError: " $O/pytest_more.txt | head -20
-timeout 600 python tools/composed_ab.py c4 c3 > $O/composed_ab.txt 2>&1; grep -v "^RCCL\|^HIP ver\|^ROCm\|^Hostname\|^Librccl\|amdgpu.ids" $O/composed_ab.txt
-bash tools/pmc_composed.sh r4b4 c4 4 > /dev/null 2>&1; cat $O/pmc_c4_4.txt
+timeout 600 python tools/composed_ab.py c4 c3 big > $O/composed_ab.txt 2>&1; grep -v "^RCCL\|^HIP ver\|^ROCm\|^Hostname\|^Librccl\|amdgpu.ids" $O/composed_ab.txt
+bash tools/pmc_composed.sh r4b6 c4 4 > /dev/null 2>&1; cat $O/pmc_c4_4.txt
