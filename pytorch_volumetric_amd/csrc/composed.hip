@@ -423,7 +423,10 @@ PVAMD_DEV void tile_passes_split(const pvamd_grid_t* __restrict__ grids, int S, 
                 const float x = affine_row(M[0], M[1], M[2], M[3], px[k], py[k], pz[k]);
                 const float y = affine_row(M[4], M[5], M[6], M[7], px[k], py[k], pz[k]);
                 const float z = affine_row(M[8], M[9], M[10], M[11], px[k], py[k], pz[k]);
-                const uint64_t vm = in_range_mask(g, x, y, z);
+                uint64_t vm = in_range_mask(g, x, y, z);
+#if defined(PVAMD_ABLATE) && (PVAMD_ABLATE & 1)  // timing experiment only (tools/r4_ablate.sh): no in-range look-ups
+                vm = 0;
+#endif
                 if (vm != 0) {
                     // the lanes in range look their value up (index estimate; shaky ones are redone exactly below)
                     const bool valid = __builtin_amdgcn_inverse_ballot_w64(vm);
@@ -440,6 +443,10 @@ PVAMD_DEV void tile_passes_split(const pvamd_grid_t* __restrict__ grids, int S, 
                     bin[k].flat = t ? flat : bin[k].flat;
                     if (vm == everyone) continue;
                 }
+#if defined(PVAMD_ABLATE) && (PVAMD_ABLATE & 2)  // timing experiment only: no out-of-range candidates
+                best[k].n2 = __builtin_fminf(best[k].n2, x + y + z);  // keeps the affine alive
+                continue;
+#endif
                 // sdf.py:559-568 for every lane, squared (no exec masking; in-range lanes are masked out of the take)
                 const float ta = __builtin_amdgcn_fmed3f(sub_rn(x, g.bb_min[0]), sub_rn(x, g.bb_max[0]), 0.f);
                 const float tb = __builtin_amdgcn_fmed3f(sub_rn(y, g.bb_min[1]), sub_rn(y, g.bb_max[1]), 0.f);
