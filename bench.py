@@ -51,7 +51,7 @@ def parse_args():
     ap.add_argument("--no-large", action="store_true", help="skip the secondary 64M-point (cache-exceeding) run")
     ap.add_argument("--no-legs", action="store_true", help="skip the C4 / C5 legs")
     ap.add_argument("--small-legs", action="store_true", help="functional test: C4 with 8 x 16,384 and C5 with 65,536 points")
-    ap.add_argument("--cpu-seconds", type=float, default=4.0, help="wall budget of the CPU baseline sample")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="wall budget of the CPU baseline samples (both figures)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL over xGMI)")
     ap.add_argument("--share-gpu", action="store_true",
                     help="functional test on a 1-GPU box: every rank uses cuda:0 and collectives go through gloo")
@@ -146,17 +146,19 @@ def capture_graph(torch, fn, n):
     return graph
 
 
-def graph_ms_per_launch(torch, graph, n, reps=3):
-    """HIP events on the launch stream around one replay of an n-launch graph, / n; best of `reps`."""
-    best = float("inf")
+def graph_ms_per_launch(torch, graph, n, reps=3, stats=False):
+    """HIP events on the launch stream around one replay of an n-launch graph, / n: MEAN over `reps` replays (and, with
+    stats, also the best one -- round 3 printed the best under the name "mean")."""
+    each = []
     for _ in range(reps):
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         graph.replay()
         e1.record()
         torch.cuda.synchronize()
-        best = min(best, e0.elapsed_time(e1) / n)
-    return best
+        each.append(e0.elapsed_time(e1) / n)
+    mean = sum(each) / len(each)
+    return (mean, min(each)) if stats else mean
 
 
 def time_eager_kernel(torch, np, fn, reps):
@@ -173,48 +175,54 @@ def time_eager_kernel(torch, np, fn, reps):
 
 
 def cpu_baseline(torch, np, cached, pts, seconds):
-    """The oracle (CPU restatement) on the host cores, bounded sample.  Only reached after every GPU timing is done."""
+    """The reference's CPU path for this workload, restated (the reference itself cannot be imported: third-party packages
+    absent), on the host cores with the OpenMP / torch threads pinned (OMP_PROC_BIND=close, OMP_PLACES=cores: set in main()
+    before either runtime starts).  `value` = the OP-FOR-OP torch restatement of sdf.py:535-571 (oracle/torch_opforop.py: the
+    ~25 stock ops and their intermediates -- what a reference user runs on CPU); `fused_port` = the one-pass C/OpenMP
+    restatement (oracle/pvamd_oracle.c), faster than anything the reference executes.  Each figure is the MEDIAN of 5
+    samples of (budget / 5) seconds each.  Only reached after every GPU timing is done."""
     from oracle import oracle
+    from oracle.torch_opforop import CachedOpForOp
     from tests import helpers as H
     og = H.oracle_grid_from_cached(cached)
     host_pts = pts.cpu().numpy()
-    oracle.cached_query(og, host_pts[:1000])  # warm
-    reps, t0 = 0, time.perf_counter()
-    while True:
-        oracle.cached_query(og, host_pts)
-        reps += 1
-        dt = time.perf_counter() - t0
-        if dt >= seconds and reps >= 3:
-            break
-    out = {"value": len(host_pts) * reps / dt, "unit": "queries/s", "cores": oracle.num_threads(), "kind": "port",
-           "what": "`value` = the FUSED C/OpenMP restatement of sdf.py:535-571 (oracle/pvamd_oracle.c): one pass per point, "
-                   "no intermediates -- faster than anything the reference executes.  The op-for-op restatement of what the "
-                   "reference runs on CPU (its ~25 torch ops with their intermediates, oracle/torch_opforop.py) is "
-                   "`torch_opforop`; the reference itself cannot be imported here (third-party packages absent)",
-           "host_cpus": os.cpu_count(),
-           "sample": f"{reps} x {len(host_pts)} of the same query points through oracle/pvamd_oracle.c "
-                     f"(OpenMP, {oracle.num_threads()} threads), {dt:.1f} s wall"}
-    # second CPU figure: the reference's own op sequence (sdf.py:535-571) restated op for op in torch on the host cores
-    try:
-        from oracle.torch_opforop import CachedOpForOp
-        packed = cached._packed.cpu()
-        view = cached._view
-        ref = CachedOpForOp(packed[:, 0].reshape(view.shape).contiguous(), packed[:, 1:4].contiguous(), view.min, view.max,
-                            cached.bb.cpu())
-        tp = pts.cpu()
-        ref(tp[:1000])
-        n, t1 = 0, time.perf_counter()
-        while True:
-            ref(tp)
-            n += 1
-            d1 = time.perf_counter() - t1
-            if d1 >= seconds / 2 and n >= 2:
-                break
-        out["torch_opforop"] = {"value": len(tp) * n / d1, "unit": "queries/s", "threads": torch.get_num_threads(),
-                                "sample": f"{n} x {len(tp)} points, oracle/torch_opforop.py, {d1:.1f} s wall"}
-    except Exception as exc:  # never let the secondary baseline break the bench line
-        out["torch_opforop"] = {"error": repr(exc)}
-    return out
+    n_pts = len(host_pts)
+
+    def samples(fn, budget, count=5):
+        """median throughput of `count` samples, each as many whole passes over the points as fit budget / count seconds"""
+        for _ in range(3):
+            fn()  # warm: thread pools up, pages touched
+        per, t0 = [], time.perf_counter()
+        for _ in range(count):
+            a, passes = time.perf_counter(), 0
+            while passes == 0 or time.perf_counter() - a < budget / count:
+                fn()
+                passes += 1
+            per.append(n_pts * passes / (time.perf_counter() - a))
+        return float(np.median(per)), float(np.min(per)), float(np.max(per)), len(per), time.perf_counter() - t0
+
+    packed = cached._packed.cpu()
+    view = cached._view
+    ref = CachedOpForOp(packed[:, 0].reshape(view.shape).contiguous(), packed[:, 1:4].contiguous(), view.min, view.max,
+                        cached.bb.cpu())
+    tp = pts.cpu()
+    o_med, o_min, o_max, o_n, o_t = samples(lambda: ref(tp), seconds * 0.6)
+    oracle.cached_query(og, host_pts[:1000])
+    f_med, f_min, f_max, f_n, f_t = samples(lambda: oracle.cached_query(og, host_pts), seconds * 0.4)
+    pin = {k: os.environ.get(k) for k in ("OMP_PROC_BIND", "OMP_PLACES", "OMP_NUM_THREADS")}
+    return {"value": o_med, "unit": "queries/s", "cores": torch.get_num_threads(), "kind": "op-for-op restatement",
+            "what": "median of the samples of the op-for-op torch restatement of CachedSDF.__call__ (sdf.py:535-571, "
+                    "oracle/torch_opforop.py) on the host cores -- the reference's own op sequence with its intermediates; the "
+                    "absent third-party view (multidim_indexing) is replaced by the three expressions its call sites amount to",
+            "sample": f"median of {o_n} samples of whole passes over {n_pts} of the same query points, {o_t:.1f} s wall in all, "
+                      f"{torch.get_num_threads()} torch threads",
+            "spread": {"min": o_min, "max": o_max, "samples": o_n},
+            "host_cpus": os.cpu_count(), "thread_pinning": pin,
+            "fused_port": {"value": f_med, "unit": "queries/s", "cores": oracle.num_threads(), "kind": "port",
+                           "what": "oracle/pvamd_oracle.c: one fused pass per point (C, OpenMP), no intermediates",
+                           "sample": f"median of {f_n} samples of whole passes over {n_pts} points, {f_t:.1f} s wall in all, "
+                                     f"{oracle.num_threads()} OpenMP threads",
+                           "spread": {"min": f_min, "max": f_max, "samples": f_n}}}
 
 
 def time_calls(torch, np, fn, reps=400):
@@ -237,31 +245,42 @@ def time_calls(torch, np, fn, reps=400):
     return back_to_back * 1e3, float(np.median(each)) * 1e3
 
 
+VALU_PROFILE = "r04_valu_session.json"  # tools/valu_session.sh: counters, kernel time, opcode mix and issue rates of ONE session
+
+
 def valu_roofline(kernel_key, ms, launches_per_step=1):
-    """Roofline object of a vector-ALU-bound leg: wave64 VALU instructions per second against the per-opcode issue ceilings
-    of profiles/r02_valu_rate.txt.  The instruction count per launch comes from the committed rocprofv3 --pmc pass
-    (SQ_INSTS_VALU; it cannot be collected inside this run), the time is this run's."""
-    path = os.path.join(ROOT, "profiles", "r03_valu_counts.json")
+    """Roofline object of a vector-ALU-bound leg, every number from ONE committed rocprofv3 session (profiles/
+    r04_valu_session.json, tools/valu_session.sh): SQ_INSTS_VALU per call, the kernels' time in that session, the dynamic
+    opcode mix of the call (SQ_INSTS_VALU_* class counters) and the two issue rates measured by tools/valu_rate.bin on the
+    same box minutes apart.  `frac` = this run's time against the ceiling of the call's own mix (below);
+    `frac_same_session` = the session's own kernel time against it."""
+    path = os.path.join(ROOT, "profiles", VALU_PROFILE)
     try:
-        entry = json.load(open(path))[kernel_key]
-    except Exception:
-        return {"bound": "valu", "achieved": None, "note": f"no committed SQ_INSTS_VALU pass for {kernel_key} ({path})"}
+        prof = json.load(open(path))
+        entry = prof["workloads"][kernel_key]
+        rates = prof["issue_rates_ns"]
+    except Exception as exc:
+        return {"bound": "valu", "achieved": None, "note": f"no committed session for {kernel_key} in profiles/{VALU_PROFILE}: {exc!r}"}
     inst = entry["SQ_INSTS_VALU"] * launches_per_step
+    f_slow = entry["mix"]["slow_fraction"]
+    # ns per wave64 instruction per SIMD at which THIS mix can issue at best: its slow-group share alone (f_slow x t_slow), or
+    # the fastest stream the micro-benchmark found at all (fast- and slow-group opcodes issue side by side: a weighted sum
+    # of the two rates is NOT a ceiling -- C4 runs 9 % above it)
+    t_mix = max(f_slow * rates["slow"], rates["best_any"])
+    peak = N_SIMD / (t_mix * 1e-9)
     achieved = inst / (ms * 1e-3)
-    peak = N_SIMD * VALU_FULL_RATE_PER_SIMD
+    sess_ms = entry["kernel_ms_same_session"] * launches_per_step
     return {"bound": "valu", "achieved": achieved / 1e9, "peak": peak / 1e9, "unit": "G wave64 VALU inst/s", "frac": achieved / peak,
-            "slow_opcode_group_ceiling": N_SIMD * VALU_SLOW_RATE_PER_SIMD / 1e9,
-            "frac_of_slow_group_ceiling": achieved / (N_SIMD * VALU_SLOW_RATE_PER_SIMD),
+            "frac_same_session": inst / (sess_ms * 1e-3) / peak, "kernel_ms_same_session": sess_ms,
             "valu_inst_per_step": inst, "active_lanes_per_inst": entry.get("active_lanes"),
-            "valu_busy_frac_at_2p4GHz": (entry["SQ_ACTIVE_INST_VALU"] * launches_per_step * 4.0 / N_SIMD) / (ms * 1e-3 * 2.4e9)
-            if entry.get("SQ_ACTIVE_INST_VALU") else None,
-            "reading": "`frac` is against the ceiling of a stream of full-rate opcodes; a kernel made of both opcode groups has "
-                       "its own ceiling between `peak` and `slow_opcode_group_ceiling`; `valu_busy_frac_at_2p4GHz` = "
-                       "SQ_ACTIVE_INST_VALU (quad-cycles) x 4 / 1024 SIMDs over this run's time at the nominal clock",
-            "source": f"profiles/r03_valu_counts.json[{kernel_key}] = SQ_INSTS_VALU of {entry.get('workload')} "
-                      f"({entry.get('command')}); ceilings: profiles/r02_valu_rate.txt (1024 SIMDs x 1 / 1.0 ns for "
-                      "v_fma/add/mul/mov, x 1 / 1.8 ns for cmp/cndmask/min/max/med3/cvt/int-mul/pk/f64); read from the "
-                      "committed file, not measured in this run"}
+            "opcode_mix": entry["mix"], "issue_rates_ns": rates,
+            "reading": "ceiling = 1024 SIMDs / max(f_slow x t_slow, t_best) with the call's own dynamic opcode mix (f_slow: every "
+                       "instruction that is not an f32 add / mul / fma -- compares, v_cndmask, min/max/med3, converts, integer ops, "
+                       "transcendentals, f64) and the issue times tools/valu_rate.bin measured in the same session (t_slow: a "
+                       "stream of slow-group opcodes; t_best: the fastest stream of the whole table)",
+            "source": f"profiles/{VALU_PROFILE}[workloads][{kernel_key}]: {entry.get('workload')} ({entry.get('command')}); "
+                      "instruction counts, opcode mix, session kernel time and issue rates all read from that one committed "
+                      "file; `achieved` divides its SQ_INSTS_VALU by THIS run's time"}
 
 
 class LegSkipped(Exception):
@@ -292,7 +311,7 @@ class Gate:
 def read_traffic(P):
     """HBM-side bytes per launch from the committed PMC passes (NOT measured in this run: rocprofv3 --pmc cannot run
     inside the benchmark)."""
-    for name in ("r03_traffic.json", "r02_traffic.json", "traffic.json"):
+    for name in ("r04_traffic.json", "r03_traffic.json", "r02_traffic.json"):
         path = os.path.join(ROOT, "profiles", name)
         if os.path.exists(path):
             try:
@@ -305,6 +324,21 @@ def read_traffic(P):
             except Exception:
                 pass
     return None, "no committed PMC pass for this point count"
+
+
+def read_rocprof_kernel_us(P):
+    """Average duration of the dominant kernel's launches at this point count in the committed rocprofv3 --kernel-trace of
+    the driver-shaped command (tools/profile_bench.sh -> profiles/r04_kernel_stats.json), for `roofline.frac_rocprof`."""
+    path = os.path.join(ROOT, "profiles", "r04_kernel_stats.json")
+    try:
+        ks = json.load(open(path))
+        row = ks["dominant"]
+        if row.get("points") == P:
+            return row["avg_us"], (f"profiles/r04_kernel_stats.json: rocprofv3 --kernel-trace of `{ks.get('command')}`, "
+                                   f"{row['calls']} launches of {row['kernel']}; read from the committed file")
+    except Exception:
+        pass
+    return None, "no committed kernel trace for this point count"
 
 
 # ------------------------------------------------------------------------------------------------ legs: C4 and C5
@@ -427,13 +461,29 @@ def leg_readme(torch, np, Wk, pv, timer, gate, robots, rank, world, A):
     robot.set_joint_configuration(th)
     gate()
     call_ms, synced_ms = time_calls(torch, np, lambda: robot(pts), reps=200)
-    sjc_ms, _ = time_calls(torch, np, lambda: robot.set_joint_configuration(th), reps=100)
+    sjc_ms, _ = time_calls(torch, np, lambda: robot.set_joint_configuration(th), reps=100)       # joint values on the host
+    th_dev = th.cuda().contiguous()
+    sjc_dev_ms, _ = time_calls(torch, np, lambda: robot.set_joint_configuration(th_dev), reps=100)  # already on the GPU
     val, grad = robot(pts)
+    # a planner's step: new joint values (on the GPU) -> configure -> query, into the caller's buffers; eagerly and as one
+    # replayed hipGraph of the two kernels
+    both_ms, _ = time_calls(torch, np, lambda: robot.configure_and_query_into(th_dev, pts, val, grad), reps=200)
+    g = capture_graph(torch, lambda: robot.configure_and_query_into(th_dev, pts, val, grad), 100)
+    g.replay()
+    torch.cuda.synchronize()
+    both_graph_ms = graph_ms_per_launch(torch, g, 100)
+    del g
     return {"config": f"reference README case: RobotSDF 8 links, link grids res 0.02 padding 1.0, A={A} x M={M} "
                       "(README.md:177-183 slice points), robot(points)",
             "scaling": "replicas", "n_gpus": world, "unit": "ms per robot(points) call",
             "ms_per_call": call_ms, "ms_per_call_synchronized_each": synced_ms, "pairs_per_s": A * M / (call_ms * 1e-3),
-            "set_joint_configuration_ms": sjc_ms, "output_shapes": [list(val.shape), list(grad.shape)],
+            "set_joint_configuration_ms": sjc_ms, "set_joint_configuration_device_q_ms": sjc_dev_ms,
+            "configure_plus_query_ms": both_ms, "configure_plus_query_graph_ms": both_graph_ms,
+            "configure": "pvamd_configure_chain: sin / cos + forward kinematics + offset^-1 o world^-1 (f32 MFMA) in ONE launch "
+                         "(round 3: H2D + sin + cos + chain_fk + transform_stack = 0.048 ms); `configure_plus_query_ms` = "
+                         "robot.configure_and_query_into(q_on_gpu, points, val, grad) back to back, `_graph_ms` = the same two "
+                         "kernels replayed from a hipGraph (HIP events / 100)",
+            "output_shapes": [list(val.shape), list(grad.shape)],
             "published_ms": README_PUBLISHED_MS.get(A), "published_on": "RTX 2080 Ti, KUKA iiwa (README.md:196-200)",
             "like_for_like": False,
             "why_not": "synthetic 7-DOF arm with 8 ellipsoid links (KUKA assets unavailable offline); different GPU"}
@@ -463,9 +513,10 @@ def leg_c3(torch, Wk, pv, timer, gate, cached, rank, world, steps, small=False):
     return {"config": f"C3: ComposedSDF of 8 transformed drills (37x33x40 cache each), {P} points, points sharded x{world}",
             "scaling": "strong", "n_gpus": world, "steps": steps, "unit": "queries/s", "value": P * steps / t,
             "ms_per_step": t / steps * 1e3, "call": "comp.query_into(points, val, grad): fused kernel, caller's buffers",
-            "roofline": {"bound": "valu", "hbm_algorithmic_GBs": gbs, "frac_of_hbm_peak": gbs / (HBM_PEAK_GBS * world),
-                         "note": "28 B/query algorithmic, but 8 leaf visits per point at ~79 vector instructions per 64-point visit "
-                                 "(the C4 kernel family, legs.c4.sharded.roofline) bound it: the vector ALUs, not HBM"}}
+            "roofline": dict(valu_roofline("c3_composed_query", t / steps * 1e3) if (world == 1 and not small) else {"bound": "valu"},
+                             hbm_algorithmic_GBs=gbs, frac_of_hbm_peak=gbs / (HBM_PEAK_GBS * world),
+                             note="28 B/query algorithmic, but 8 leaf visits per point (the C4 kernel family, "
+                                  "legs.c4.sharded.roofline) bound it: the vector ALUs, not HBM")}
 
 
 def leg_c1(torch, np, Wk, pv, gate, world):
@@ -532,6 +583,10 @@ def main():
         launch_check(args, rank, world)
         return
 
+    # the CPU baseline's threads (OpenMP in the C oracle, and torch's own pool) stay where they start: set before either
+    # runtime is loaded (round 3's unpinned 4-second sample swung 3.6x between runs)
+    os.environ.setdefault("OMP_PROC_BIND", "close")
+    os.environ.setdefault("OMP_PLACES", "cores")
     import numpy as np
     import torch
     import torch.distributed as dist
@@ -605,7 +660,7 @@ def main():
     kgraph = capture_graph(torch, step, kg_n)
     kgraph.replay()
     torch.cuda.synchronize()
-    k_ms = graph_ms_per_launch(torch, kgraph, kg_n)
+    k_ms, k_ms_best = graph_ms_per_launch(torch, kgraph, kg_n, reps=5, stats=True)
     del kgraph
     e_mean, e_med, e_min = time_eager_kernel(torch, np, step, 200)
     # the drop-in call itself -- what a user of the reference writes: val, grad = sdf(points) (sdf.py:535-591), outputs allocated
@@ -616,6 +671,7 @@ def main():
         qps = world * P * args.steps / elapsed
         achieved = BYTES_PER_QUERY * P / (k_ms * 1e-3) / 1e9
         traffic, traffic_source = read_traffic(P)
+        rocprof_us, rocprof_source = read_rocprof_kernel_us(P)
         out = {
             "metric": "SDF (val+grad) queries/sec", "value": qps, "unit": "queries/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
@@ -630,10 +686,15 @@ def main():
                        "backend": (dist.get_backend() if use_pg else None), "gpus_requested": args.gpus},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
-                         "kernel": "pvamd::cached_query_wave", "launch_ms_mean": k_ms,
-                         "timing": f"HIP events on the launch stream around a SEPARATE hipGraph of {kg_n} launches of the "
-                                   f"same call on the same buffers, / {kg_n} (best of 3 replays); NOT the K timed steps, "
-                                   "so it does not change with --steps",
+                         "kernel": "pvamd::cached_query_wave", "launch_ms_mean": k_ms, "launch_ms_best_replay": k_ms_best,
+                         "frac_best_replay": BYTES_PER_QUERY * P / (k_ms_best * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                         "frac_rocprof": None if rocprof_us is None else BYTES_PER_QUERY * P / (rocprof_us * 1e-6) / 1e9 / HBM_PEAK_GBS,
+                         "rocprof_launch_us": rocprof_us, "rocprof_source": rocprof_source,
+                         "timing": f"`frac` / `achieved` / `launch_ms_mean`: HIP events on the launch stream around a SEPARATE "
+                                   f"hipGraph of {kg_n} launches of the same call on the same buffers, / {kg_n}, MEAN of 5 "
+                                   "replays (the best replay is `launch_ms_best_replay`); NOT the K timed steps, so it does "
+                                   "not change with --steps.  `frac_rocprof`: the committed kernel trace's average.  "
+                                   "`frac_of_wall_ms_per_step`: the driver-timed K steps",
                          "eager_launch_ms": {"mean": e_mean, "median": e_med, "min": e_min},
                          "dropin_call": {"call": "val, grad = cached(points)  # CachedSDF.__call__, outputs allocated per call",
                                          "ms_per_call": d_call, "queries_per_s": P / (d_call * 1e-3),

@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define PVAMD_ABI_VERSION 7
+#define PVAMD_ABI_VERSION 8
 
 #define PVAMD_E_NULL      (-1)  /* a required pointer is NULL            */
 #define PVAMD_E_SHAPE     (-2)  /* a size/shape argument is out of range */
@@ -356,6 +356,18 @@ int pvamd_transform_stack(const float* offset_inv, const float* link_world, int3
  * children to read).  link_world_out: device [S*A][4][4], leaf-major, the input of pvamd_transform_stack.          */
 int pvamd_chain_fk(const pvamd_joint_t* joints, int32_t F, const float* q, const float* sin_q, const float* cos_q,
                    int32_t A, int32_t M, float* scratch, float* link_world_out, void* stream);
+
+/* The whole of RobotSDF.set_joint_configuration (model_to_sdf.py:94-113) in ONE launch, from joint values that already sit
+ * on the device: sin / cos, the frame walk of pvamd_chain_fk, and stack_out[s*A+a] = offset_inv[s] @
+ * rigid_inverse(world[leaf s, a]) (the f32-MFMA statement of pvamd_transform_stack) -- the obj->leaf stack that
+ * pvamd_composed_query consumes.  q: device [A][M].  offset_inv: device [S][4][4].  sincos_out: device [A][M][2] (sin, cos
+ * of every revolute joint value, as used: feed them to a CPU restatement to reproduce the stack bit for bit) or NULL.
+ * scratch: device [F][12][A] fp32.  link_world_out: device [S*A][4][4] leaf-major or NULL.  stack_out: device [S*A][4][4].
+ * At most 50 SDF-carrying links (the leaf frames of 64 configurations are staged in LDS).  Graph-capturable: no host
+ * data, no allocation, one kernel.                                                                                   */
+int pvamd_configure_chain(const pvamd_joint_t* joints, int32_t F, const float* q, int32_t A, int32_t M,
+                          const float* offset_inv, int32_t S, float* sincos_out, float* scratch,
+                          float* link_world_out, float* stack_out, void* stream);
 
 #ifdef __cplusplus
 }

@@ -96,30 +96,74 @@ class RobotSDF(sdf.ObjectFrameSDF):
         offset_inv = self._offset_inv_dev(dev)
         with _lib.on_device(dev):
             if hasattr(self.chain, "joint_table"):
-                # on-device FK (pvamd_chain_fk): no per-frame host-driven ops, nothing returns to the host
-                q = joint_config.reshape(1 if joint_config.dim() == 1 else joint_config.shape[0], M).to(
-                    device=dev, dtype=torch.float32).contiguous()
-                A = q.shape[0]
-                joints, F = self._joint_table_dev(dev)
-                sin_q, cos_q = torch.sin(q), torch.cos(q)
-                scratch = torch.empty((F, 12, A), dtype=torch.float32, device=dev)
-                link_world_d = torch.empty((S * A, 4, 4), dtype=torch.float32, device=dev)
-                _lib.check(lib.pvamd_chain_fk(_lib.ptr(joints), F, _lib.ptr(q), _lib.ptr(sin_q), _lib.ptr(cos_q), A, M,
-                                              _lib.ptr(scratch), _lib.ptr(link_world_d), _lib.stream_ptr()),
-                           "pvamd_chain_fk")
+                # ONE launch (pvamd_configure_chain): sin / cos + frame walk + offset^-1 o world^-1 on the f32 MFMA.  Joint values
+                # that already sit on this GPU as float32 (A, M) are used where they are; anything else is one H2D copy.
+                A = 1 if joint_config.dim() == 1 else joint_config.shape[0]
+                if joint_config.is_cuda and joint_config.dtype is torch.float32 and joint_config.device == dev and \
+                        joint_config.is_contiguous():
+                    q = joint_config
+                else:
+                    q = joint_config.reshape(A, M).to(device=dev, dtype=torch.float32).contiguous()
+                stack = self._configure(lib, dev, q, A, M, S, offset_inv)
             else:
                 # a foreign chain object (e.g. pytorch_kinematics.Chain): use its own forward kinematics
                 fk = self.chain.forward_kinematics(joint_config, end_only=False)
                 link_world = torch.cat([tf.as_matrix(fk[name]) for name in self.sdf_to_link_name])  # leaf-major
                 A = link_world.shape[0] // S
                 link_world_d = link_world.to(device=dev, dtype=torch.float32).contiguous()
-            # object_to_link[s*A+a] = offset[s]^-1 @ world_T_link[s,a]^-1 on the matrix cores
-            stack = torch.empty_like(link_world_d)
-            _lib.check(lib.pvamd_transform_stack(_lib.ptr(offset_inv), _lib.ptr(link_world_d), S, A,
-                                                 _lib.ptr(stack), _lib.stream_ptr()), "pvamd_transform_stack")
+                # object_to_link[s*A+a] = offset[s]^-1 @ world_T_link[s,a]^-1 on the matrix cores
+                stack = torch.empty_like(link_world_d)
+                _lib.check(lib.pvamd_transform_stack(_lib.ptr(offset_inv), _lib.ptr(link_world_d), S, A,
+                                                     _lib.ptr(stack), _lib.stream_ptr()), "pvamd_transform_stack")
         self.object_to_link_frames = tf.Transform3d(matrix=stack)
         if self.sdf is not None:
             self.sdf.set_transforms(self.object_to_link_frames, batch_dim=self.configuration_batch, known_rigid=True)
+
+    def _configure(self, lib, dev, q, A, M, S, offset_inv, stack=None, sincos=None):
+        """pvamd_configure_chain on the current stream: q (A, M) float32 on `dev` -> the (S*A, 4, 4) obj->leaf stack.  The
+        frame scratch is kept per batch size (it is private to one call on one stream)."""
+        joints, F = self._joint_table_dev(dev)
+        key = (str(dev), A)
+        hit = self.__dict__.get("_cfg_scratch")
+        if hit is None or hit[0] != key:
+            hit = self._cfg_scratch = (key, torch.empty((F, 12, A), dtype=torch.float32, device=dev))
+        if stack is None:
+            stack = torch.empty((S * A, 4, 4), dtype=torch.float32, device=dev)
+        rc = lib.pvamd_configure_chain(joints.data_ptr(), F, q.data_ptr(), A, M, offset_inv.data_ptr(), S,
+                                       None if sincos is None else sincos.data_ptr(), hit[1].data_ptr(), None,
+                                       stack.data_ptr(), _lib.stream_ptr())
+        if rc != 0:
+            _lib.check(rc, "pvamd_configure_chain")
+        return stack
+
+    def configure_and_query_into(self, joint_config, points, out_val, out_grad):
+        """A planner's inner step without host work between its two launches: joint values (A, M) float32 ALREADY ON THE GPU
+        -> pvamd_configure_chain -> pvamd_composed_query into the caller's (A, P) / (A, P, 3) buffers.  No host data, no
+        allocation after the first call with this batch size: capturable in a hipGraph (model_to_sdf.py:82-125 as two
+        kernels).  Needs a kinematics.Chain (on-device FK) and BOUNDING_BOX CachedSDF leaves; afterwards the object is
+        configured exactly as by set_joint_configuration(joint_config)."""
+        if not hasattr(self.chain, "joint_table"):
+            raise ValueError("configure_and_query_into needs the on-device forward kinematics (pytorch_volumetric_amd.kinematics.Chain)")
+        M, S = len(self.joint_names), len(self.sdf_to_link_name)
+        q = joint_config
+        if not (torch.is_tensor(q) and q.is_cuda and q.dtype is torch.float32 and q.dim() == 2 and q.shape[1] == M and q.is_contiguous()):
+            raise ValueError(f"configure_and_query_into needs contiguous float32 (A, {M}) joint values on the GPU")
+        A = q.shape[0]
+        dev = q.device
+        lib = _lib.load()
+        with _lib.on_device(dev):
+            key = (str(dev), A)
+            hit = self.__dict__.get("_cfg_stack")
+            if hit is None or hit[0] != key:  # the stack this entry point writes is its own, re-used call after call
+                stack = torch.empty((S * A, 4, 4), dtype=torch.float32, device=dev)
+                hit = self._cfg_stack = (key, stack, tf.Transform3d(matrix=stack))
+            self._configure(lib, dev, q, A, M, S, self._offset_inv_dev(dev), stack=hit[1])
+            self.q, self.configuration_batch = q, (A,)
+            self.object_to_link_frames = hit[2]
+            if self.sdf.obj_frame_to_link_frame is not hit[2] or self.sdf.tsf_batch != (A,):
+                self.sdf.set_transforms(hit[2], batch_dim=(A,), known_rigid=True)
+            self.sdf._inverse_frames = None  # surface_bounding_box rebuilds them from the (re-written) stack when asked
+            self.sdf.query_into(points, out_val, out_grad)
 
     def _offset_inv_dev(self, dev):
         if getattr(self, "_offset_inv_cache", None) is None or self._offset_inv_cache.device != dev:

@@ -136,6 +136,93 @@ def test_on_device_fk_matches_oracle_bitwise_and_torch_fk(tmp_path):
     assert torch.allclose(lw.cpu(), ref, atol=2e-6)
 
 
+@pytest.mark.parametrize("A", [1, 20, 77, 200])
+def test_one_launch_configure_matches_the_oracle_given_the_sin_cos_it_used(tmp_path, A):
+    """pvamd_configure_chain = sin / cos + the frame walk + offset^-1 o world^-1 (MFMA) in one kernel.  It emits the sines and
+    cosines it used; the oracle's FK + transform stack fed the same numbers must give the same bits (model_to_sdf.py:94-113)."""
+    import ctypes as C
+    chain = synthetic_arm(str(tmp_path))
+    leaves = [f"link_{i}" for i in range(8)]
+    raw = chain.joint_table(leaves)
+    F = len(raw) // C.sizeof(pv._lib.JointDesc)
+    S, M = 8, 7
+    q = torch.randn(A, M, generator=torch.Generator().manual_seed(A)) * 0.8
+    qd = q.cuda().contiguous()
+    joints = torch.frombuffer(bytearray(raw), dtype=torch.uint8).cuda()
+    off = H.random_rigid(S, seed=5, trans=0.1)
+    off_inv = tf.rigid_inverse(off).cuda().contiguous()
+    sincos = torch.full((A, M, 2), 9.0, device="cuda")
+    scratch = torch.empty((F, 12, A), device="cuda")
+    lw = torch.empty((S * A, 4, 4), device="cuda")
+    stack = torch.empty((S * A, 4, 4), device="cuda")
+    lib = pv._lib.load()
+    pv._lib.check(lib.pvamd_configure_chain(pv._lib.ptr(joints), F, pv._lib.ptr(qd), A, M, pv._lib.ptr(off_inv), S,
+                                            pv._lib.ptr(sincos), pv._lib.ptr(scratch), pv._lib.ptr(lw), pv._lib.ptr(stack),
+                                            pv._lib.stream_ptr()), "pvamd_configure_chain")
+    sc = sincos.cpu().numpy()
+    sn, cn = np.ascontiguousarray(sc[..., 0]), np.ascontiguousarray(sc[..., 1])
+    assert np.allclose(sn, np.sin(q.numpy()), atol=1e-6) and np.allclose(cn, np.cos(q.numpy()), atol=1e-6)
+    joints_o = (oracle.OracleJoint * F).from_buffer_copy(raw)
+    world = np.zeros((F, A, 12), np.float32)
+    olw = np.zeros((S * A, 4, 4), np.float32)
+    qn = q.numpy()
+    oracle.load().oracle_chain_fk(joints_o, C.c_int32(F), C.c_void_p(qn.ctypes.data), C.c_void_p(sn.ctypes.data),
+                                  C.c_void_p(cn.ctypes.data), C.c_int32(A), C.c_int32(M), C.c_void_p(world.ctypes.data),
+                                  C.c_void_p(olw.ctypes.data))
+    assert np.array_equal(lw.cpu().numpy(), olw)
+    assert np.array_equal(stack.cpu().numpy(), oracle.transform_stack(off_inv.cpu().numpy(), olw, S, A))
+    # the two-kernel path of round 3 on the same sines / cosines: the same stack
+    lw2 = torch.empty_like(lw)
+    st2 = torch.empty_like(stack)
+    sin_d, cos_d = sincos[..., 0].contiguous(), sincos[..., 1].contiguous()  # kept alive until the kernels have run
+    pv._lib.check(lib.pvamd_chain_fk(pv._lib.ptr(joints), F, pv._lib.ptr(qd), pv._lib.ptr(sin_d), pv._lib.ptr(cos_d), A, M,
+                                     pv._lib.ptr(scratch), pv._lib.ptr(lw2), pv._lib.stream_ptr()), "pvamd_chain_fk")
+    pv._lib.check(lib.pvamd_transform_stack(pv._lib.ptr(off_inv), pv._lib.ptr(lw2), S, A, pv._lib.ptr(st2), pv._lib.stream_ptr()),
+                  "pvamd_transform_stack")
+    torch.cuda.synchronize()
+    assert torch.equal(lw2, lw) and torch.equal(st2, stack)
+
+
+def test_configure_and_query_into_is_two_launches_and_graph_capturable(tmp_path):
+    """robot.configure_and_query_into(q, pts, val, grad) with q on the GPU == set_joint_configuration(q) + robot(pts), bit for
+    bit, from host tensors or device tensors, eagerly or replayed from a hipGraph with new joint values in place."""
+    robot = pv.RobotSDF(synthetic_arm(str(tmp_path)), path_prefix=str(tmp_path),
+                        link_sdf_cls=pv.cache_link_sdf_factory(resolution=0.02, padding=0.1, device="cuda", cache_path=None))
+    A, P = 24, 5000
+    g = torch.Generator().manual_seed(3)
+    q1, q2 = torch.randn(A, 7, generator=g) * 0.6, torch.randn(A, 7, generator=g) * 0.6
+    pts = H.uniform_points(P, [-0.5, -0.5, -0.1], [0.5, 0.5, 1.2], seed=2).cuda()
+    robot.set_joint_configuration(q1)  # host tensor: one H2D + one launch
+    v_host, g_host = robot(pts)
+    robot.set_joint_configuration(q1.cuda())  # device tensor: one launch
+    v_dev, g_dev = robot(pts)
+    assert torch.equal(v_host, v_dev) and torch.equal(g_host.nan_to_num(7.0), g_dev.nan_to_num(7.0))
+    val = torch.empty((A, P), device="cuda")
+    grad = torch.empty((A, P, 3), device="cuda")
+    qd = q1.cuda().contiguous()
+    robot.configure_and_query_into(qd, pts, val, grad)
+    assert torch.equal(val, v_host) and torch.equal(grad.nan_to_num(7.0), g_host.nan_to_num(7.0))
+    assert robot.configuration_batch == (A,)
+    bb_fused = robot.sdf.surface_bounding_box(padding=0.0).clone()
+    robot.set_joint_configuration(q1)
+    assert torch.equal(bb_fused, robot.sdf.surface_bounding_box(padding=0.0))
+    # captured once, replayed with other joint values written into the same device tensor
+    graph = torch.cuda.CUDAGraph()
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        robot.configure_and_query_into(qd, pts, val, grad)
+        with torch.cuda.graph(graph, stream=side):
+            robot.configure_and_query_into(qd, pts, val, grad)
+    torch.cuda.current_stream().wait_stream(side)
+    qd.copy_(q2)
+    graph.replay()
+    torch.cuda.synchronize()
+    robot.set_joint_configuration(q2)
+    v2, g2 = robot(pts)
+    assert torch.equal(val, v2) and torch.equal(grad.nan_to_num(7.0), g2.nan_to_num(7.0))
+
+
 def test_query_into_and_graph_replay(tmp_path):
     """A planner-style inner loop: set_joint_configuration + query_into captured once in a hipGraph and replayed."""
     chain = synthetic_arm(str(tmp_path))

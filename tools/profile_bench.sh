@@ -22,8 +22,17 @@ for f in glob.glob("$O/kt/**/*kernel_trace.csv", recursive=True):
 total = sum(sum(v) for v in rows.values())
 print("| kernel | grid (threads) x workgroup | calls | total us | avg us | min us | max us | % |")
 print("|---|---|---|---|---|---|---|---|")
-for (name, grid, wg), v in sorted(rows.items(), key=lambda kv: -sum(kv[1]))[:32]:
+for (name, grid, wg), v in sorted(rows.items(), key=lambda kv: -sum(kv[1]))[:40]:
     print("| \`%s\` | %s x %s | %d | %.1f | %.2f | %.2f | %.2f | %.2f |" % (name, grid, wg, len(v), sum(v), sum(v) / len(v), min(v), max(v), 100 * sum(v) / total))
+# machine-readable: the dominant kernel's 1,048,576-point launches (bench.py roofline.frac_rocprof)
+import json
+dom = [(k, v) for k, v in rows.items() if "1,048,576-point launches" in k[0]]
+if dom:
+    (name, grid, wg), v = max(dom, key=lambda kv: len(kv[1]))
+    json.dump({"command": "rocprofv3 --kernel-trace --stats -- python bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline",
+               "dominant": {"kernel": name, "points": 1048576, "calls": len(v), "avg_us": sum(v) / len(v), "min_us": min(v), "max_us": max(v)},
+               "all": [{"kernel": k[0], "grid": k[1], "workgroup": k[2], "calls": len(v), "avg_us": sum(v) / len(v)} for k, v in sorted(rows.items(), key=lambda kv: -sum(kv[1]))[:40]]},
+              open("$O/kernel_stats.json", "w"), indent=1)
 PY
 F=$(find $O/fetch -name "*counter_collection.csv" | head -1); W=$(find $O/write -name "*counter_collection.csv" | head -1)
 [ -z "$ONLY_KT" ] && python tools/pmc_summary.py $F $W cached_query_wave 1048576 > $O/traffic.json

@@ -1,4 +1,4 @@
-"""One BASELINE workload CALLS times, for a rocprofv3 --pmc pass (tools/valu_counts.sh): c1 | c4 | c5."""
+"""One BASELINE workload CALLS times, for a rocprofv3 pass (tools/valu_session.sh): c1 | c3 | c4 | c5."""
 import os, sys
 sys.path.insert(0, os.getcwd())
 import torch
@@ -11,6 +11,12 @@ if which == "c1":  # MeshSDF on the drill, 10k of the 0.002 m grid points (tests
     _, grid_pts = pv.get_coordinates_and_points_in_grid(0.002, drill.bounding_box(0.01))
     pts = grid_pts[torch.randperm(len(grid_pts), generator=torch.Generator().manual_seed(0))[:10_000]].cuda()
     fn = lambda: sdf(pts)
+elif which == "c3":
+    comp = Wk.build_c3(Wk.build_c2_cache())
+    P = 1 << 22
+    pts = Wk.c3_points(P)
+    val = torch.empty((1, P), dtype=torch.float32, device="cuda"); grad = torch.empty((1, P, 3), dtype=torch.float32, device="cuda")
+    fn = lambda: comp.query_into(pts, val, grad)
 elif which == "c4":
     robot = Wk.build_c4(0.02, 0.1)
     A, P = 200, 1 << 18
@@ -23,6 +29,8 @@ else:
     pts = Wk.c5_points(1 << 21)
     W = torch.eye(4).unsqueeze(0).cuda()
     fn = lambda: pv.batch_chamfer_dist(W, pts, obj_factory=mesh, scale=1000.0)
+import time
 for _ in range(calls):
     fn()
-torch.cuda.synchronize()
+    torch.cuda.synchronize()
+    time.sleep(0.01)  # a gap in the kernel trace between calls (tools/valu_session.py groups launches by it)
