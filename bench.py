@@ -248,6 +248,41 @@ def time_calls(torch, np, fn, reps=400):
 VALU_PROFILE = "r04_valu_session.json"  # tools/valu_session.sh: counters, kernel time, opcode mix and issue rates of ONE session
 
 
+def oracle_pin_string(np):
+    """What the oracle is pinned to, read from the booleans tests/golden/make_golden.py wrote into the committed vectors."""
+    try:
+        z = np.load(os.path.join(ROOT, "tests", "golden", "reference_lifted.npz"))
+        pins = {k: bool(z[f"pinned/{k}"]) for k in ("view", "transform", "embree")}
+    except Exception:
+        pins = {"view": False, "transform": False, "embree": False}
+    real = [k for k, v in pins.items() if v]
+    if all(pins.values()):
+        return "oracle/pvamd_oracle.c (in-repo CPU restatement), pinned to vectors generated over the real multidim_indexing / pytorch_kinematics / open3d"
+    return ("oracle/pvamd_oracle.c (in-repo CPU restatement; third-party arithmetic UNPINNED: golden vectors generated over "
+            + ("shims of multidim_indexing's view, pytorch_kinematics' Transform3d and no Embree scene" if not real else
+               f"the real {real} and shims for the rest") + " -- tests/golden/make_golden.py, pinned/* in reference_lifted.npz)")
+
+
+def call_latency(torch, np, fn, calls=100_000, drain_every=256):
+    """Host time of every single call of a loop (perf_counter around the call; the launch is asynchronous), the queue drained
+    every `drain_every` calls outside the timed span: what a planner that issues one query per step sees, incl. the tail."""
+    for _ in range(200):
+        fn()
+    torch.cuda.synchronize()
+    t = np.empty(calls)
+    pc = time.perf_counter
+    for i in range(calls):
+        a = pc()
+        fn()
+        t[i] = pc() - a
+        if i % drain_every == drain_every - 1:
+            torch.cuda.synchronize()
+    torch.cuda.synchronize()
+    us = t * 1e6
+    return {"calls": calls, "p50_us": float(np.percentile(us, 50)), "p99_us": float(np.percentile(us, 99)),
+            "p99_9_us": float(np.percentile(us, 99.9)), "max_us": float(us.max()), "calls_above_1ms": int((us > 1000).sum())}
+
+
 def valu_roofline(kernel_key, ms, launches_per_step=1):
     """Roofline object of a vector-ALU-bound leg, every number from ONE committed rocprofv3 session (profiles/
     r04_valu_session.json, tools/valu_session.sh): SQ_INSTS_VALU per call, the kernels' time in that session, the dynamic
@@ -832,6 +867,29 @@ def main():
                               "frac_of_8TBs": BYTES_PER_QUERY * PL / (m * 1e-3) / 1e9 / HBM_PEAK_GBS}
         del big, bval, bgrad
 
+    if rank == 0 and world == 1 and not args.no_legs and not args.small_legs:
+        # the tail of the drop-in calls (profiles/r04_stall.txt: the 20-40 ms step rounds 2-3 chased is CPython's generation-2
+        # collector walking torch's ~170k objects; pv.warm_up() freezes them out of it and loads every code object up front)
+        try:
+            import gc
+            _, spts = pv.get_coordinates_and_points_in_grid(0.01, np.array([[-1, 0.5], [0.02, 0.02], [-0.2, 0.8]]))
+            spts = spts.cuda()
+            robot20 = build_robot(Wk, robots, 1.0)
+            robot20.set_joint_configuration(Wk.c4_joint_configs(20))
+            cold = {"cached(points)": call_latency(torch, np, lambda: cached(spts), calls=20_000)}
+            t0 = time.perf_counter()
+            pv.warm_up()
+            warm_ms = (time.perf_counter() - t0) * 1e3
+            out["latency"] = {"points": int(spts.shape[0]), "timing": "perf_counter around every call, queue drained every 256 calls "
+                              "outside the timed spans; 100,000 calls each after pv.warm_up() (kernel families launched once, "
+                              "gc.collect() + gc.freeze())", "warm_up_ms": warm_ms,
+                              "cached(points)": call_latency(torch, np, lambda: cached(spts)),
+                              "robot(points) A=20, README-size link grids": call_latency(torch, np, lambda: robot20(spts)),
+                              "before_warm_up_20000_calls": cold,
+                              "gc_frozen_objects": gc.get_freeze_count()}
+        except Exception as exc:
+            out["latency"] = {"error": repr(exc)}
+
     if rank == 0:
         # ---- everything below uses the oracle: only after all GPU timing ----
         from oracle import oracle
@@ -845,7 +903,7 @@ def main():
         out["config"]["oob_fraction"] = float(ooob.mean())
         out["parity"] = {"checked_points": n_chk, "max_abs_val_err_vs_oracle": max_err,
                          "grad_mismatches_vs_oracle": grad_mismatch,
-                         "oracle": "oracle/pvamd_oracle.c (in-repo CPU restatement; third-party arithmetic UNPINNED)"}
+                         "oracle": oracle_pin_string(np)}
         if not args.no_cpu_baseline and world == 1:  # the CPU baseline is timed on rank 0 of the 1-GPU run only
             out["cpu_baseline"] = cpu_baseline(torch, np, cached, pts, args.cpu_seconds)
     if use_pg:

@@ -17,5 +17,6 @@ from pytorch_volumetric_amd.volume import is_inside
 from pytorch_volumetric_amd.transforms import Rotate, Transform3d, Translate
 from pytorch_volumetric_amd.kinematics import Chain, build_chain_from_urdf, build_serial_chain_from_urdf
 from pytorch_volumetric_amd.dist import ShardedSDF, shard_range, sharded_chamfer
+from pytorch_volumetric_amd.warmup import warm_up
 
 __version__ = "0.1.0"

@@ -17,6 +17,11 @@ Two groups of vectors:
      (TorchMultidimView: value-range indexing; pk.Transform3d: 4x4 column-vector transforms).  These pin the
      reference's GLUE (masking, bounding-box fallback, argmin tie-break, output shapes) -- NOT the third-party
      arithmetic, which stays "parity unpinned" (DESIGN.md).
+  C. RE-PINNING IS A RE-RUN: where multidim_indexing / pytorch_kinematics / open3d CAN be imported, group B runs over the
+     real classes instead of the shims, the view's index rule is detected (tools/detect_index_rule.py) and must equal
+     pv.voxel.INDEX_RULE, mesh-query vectors (closest point, distance, gradient, normal) are added, and the booleans
+     `pinned/view`, `pinned/transform`, `pinned/embree` in the .npz say which happened (tests/test_oracle_pinned.py and
+     bench.py's `parity.oracle` read them).
 """
 import ast
 import math
@@ -112,9 +117,95 @@ class _TorchViewShim:
     TorchMultidimView = ShimMultidimView
 
 
+def third_party():
+    """The two third-party classes group B runs over: the REAL ones when their packages can be imported (then the vectors
+    pin that arithmetic and `pinned/*` says so), the shims above otherwise.  Re-pinning is a re-run of this script in an
+    environment that has multidim_indexing / pytorch_kinematics / open3d -- no code to touch."""
+    pinned = {"view": False, "transform": False, "embree": False}
+    view_mod, pk_mod = _TorchViewShim, _PkShim
+    try:
+        from multidim_indexing import torch_view as real_view  # noqa: F401
+        view_mod, pinned["view"] = real_view, True
+    except Exception as exc:
+        print("multidim_indexing not importable -> TorchMultidimView SHIM (index rule stays unpinned):", repr(exc))
+    try:
+        import pytorch_kinematics as real_pk
+        pk_mod, pinned["transform"] = real_pk, True
+    except Exception as exc:
+        print("pytorch_kinematics not importable -> Transform3d SHIM:", repr(exc))
+    try:
+        import open3d  # noqa: F401
+        pinned["embree"] = True
+    except Exception as exc:
+        print("open3d not importable -> no mesh-query (Embree) vectors:", repr(exc))
+    return view_mod, pk_mod, pinned
+
+
+def check_index_rule(view_cls):
+    """With the real view at hand: the rule it implements must be the one this library is set to (pv.voxel.INDEX_RULE), or the
+    vectors below would pin one rule while the kernels restate another.  Fails loudly."""
+    root = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    sys.path.insert(0, root)
+    sys.path.insert(0, os.path.join(root, "tools"))
+    import detect_index_rule
+    from pytorch_volumetric_amd import voxel
+    rule, seen = detect_index_rule.detect(view_cls)
+    if rule != voxel.INDEX_RULE:
+        raise SystemExit(f"the installed TorchMultidimView implements rule {rule} ({detect_index_rule.describe(rule)}; probes: {seen}) "
+                         f"but pv.voxel.INDEX_RULE is {voxel.INDEX_RULE}: set INDEX_RULE = {rule} in pytorch_volumetric_amd/voxel.py, "
+                         "rebuild the caches, then re-run this script")
+    return rule
+
+
+def mesh_query_vectors(out):
+    """Only with open3d: the reference's own ObjectFactory._do_object_frame_closest_point (sdf.py:122-172) on the drill --
+    closest point, distance, gradient, normal for a seeded cloud and for surface-hugging points (|d| < 1e-3 takes the face
+    normal).  The sign test uses the unseeded numpy RNG (sdf.py:149): np.random.seed(0) is set right before the call, and
+    points whose sign flips between two seeds are recorded in `mesh/unstable` so that the tests can skip them."""
+    import open3d as o3d
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    ns = {"torch": torch, "np": np, "math": math, "o3d": o3d, "os": os, "abc": __import__("abc"), "typing": __import__("typing"),
+          "NamedTuple": __import__("typing").NamedTuple, "logger": __import__("logging").getLogger("ref"), "enum": __import__("enum")}
+    try:
+        from arm_pytorch_utilities import tensor_utils
+        ns["tensor_utils"] = tensor_utils
+    except Exception:
+        class _TU:  # the two helpers sdf.py touches: batch flattening for (..., N, 3) inputs and tensor coercion
+            @staticmethod
+            def handle_batch_input(n):
+                return lambda f: f
+
+            @staticmethod
+            def ensure_tensor(device, dtype, *xs):
+                return [torch.as_tensor(x, device=device, dtype=dtype) for x in xs]
+        ns["tensor_utils"] = _TU
+    lift(os.path.join(REF, "sdf.py"), ["SDFQuery", "ObjectFactory", "MeshObjectFactory"], ns)
+    data = np.load(os.path.join(root, "golden", "meshes", "ycb_power_drill.npz"))
+    mesh = o3d.geometry.TriangleMesh(o3d.utility.Vector3dVector(data["vertices"]), o3d.utility.Vector3iVector(data["faces"]))
+    obj = ns["MeshObjectFactory"]("drill", mesh=mesh)
+    g = torch.Generator().manual_seed(0)
+    lo, hi = torch.tensor(data["vertices"].min(0)) - 0.05, torch.tensor(data["vertices"].max(0)) + 0.05
+    pts = (torch.rand(4096, 3, generator=g, dtype=torch.float64) * (hi - lo) + lo).float()
+    res = []
+    for seed in (0, 1):
+        np.random.seed(seed)
+        res.append(obj.object_frame_closest_point(pts, compute_normal=True))
+    a, b = res
+    out["mesh/points"] = pts.numpy()
+    out["mesh/closest"], out["mesh/distance"] = a.closest.numpy(), a.distance.numpy()
+    out["mesh/gradient"], out["mesh/normal"] = a.gradient.numpy(), a.normal.numpy()
+    out["mesh/unstable"] = (torch.sign(a.distance) != torch.sign(b.distance)).numpy()
+
+
 def main():
     out = {}
     torch.manual_seed(0)
+    view_mod, pk_mod, pinned = third_party()
+    Transform3d = pk_mod.Transform3d
+    if pinned["view"]:
+        out["pinned/index_rule"] = np.int64(check_index_rule(view_mod.TorchMultidimView))
+    for k, v in pinned.items():
+        out[f"pinned/{k}"] = np.bool_(v)
 
     # ---------------- group A ----------------
     ns = {"torch": torch, "np": np, "math": math}
@@ -146,7 +237,7 @@ def main():
         def abstractmethod(f):
             return f
     ns2 = {"torch": torch, "np": np, "math": math, "abc": _Abc, "typing": __import__("typing"),
-           "VoxelGrid": object, "torch_view": _TorchViewShim, "pk": _PkShim, "enum": __import__("enum"),
+           "VoxelGrid": object, "torch_view": view_mod, "pk": pk_mod, "enum": __import__("enum"),
            "os": os, "logger": __import__("logging").getLogger("ref"),
            "get_divisible_range_by_resolution": ns["get_divisible_range_by_resolution"],
            "get_coordinates_and_points_in_grid": ns["get_coordinates_and_points_in_grid"]}
@@ -221,20 +312,23 @@ def main():
             M = torch.eye(4).repeat(S * A, 1, 1)
             M[:, 0, 0], M[:, 0, 1], M[:, 1, 0], M[:, 1, 1] = ang.cos(), -ang.sin(), ang.sin(), ang.cos()
             M[:, :3, 3] = torch.rand(S * A, 3) * 0.8 - 0.4
-            comp = ComposedSDF(leaves, ShimTransform3d(matrix=M[:S]))
+            comp = ComposedSDF(leaves, Transform3d(matrix=M[:S]))
             qq = torch.rand(1500, 3) * 2.4 - 1.2
             v1, g1 = comp(qq.reshape(3, 500, 3))
             out["composed/single/tf"], out["composed/points"] = M[:S].numpy(), qq.numpy()
             out["composed/single/val"], out["composed/single/grad"] = v1.numpy(), g1.numpy()  # FLAT (P,) / (P,3)
             out["composed/single/bbox"] = comp.surface_bounding_box(padding=0.02).numpy()     # sdf.py:347-368
-            comp.set_transforms(ShimTransform3d(matrix=M), batch_dim=(A,))
+            comp.set_transforms(Transform3d(matrix=M), batch_dim=(A,))
             v2, g2 = comp(qq.reshape(3, 500, 3))
             out["composed/batched/tf"] = M.numpy()
             out["composed/batched/val"], out["composed/batched/grad"] = v2.numpy(), g2.numpy()  # (4,3,500[,3])
             out["composed/batched/bbox"] = comp.surface_bounding_box(padding=0.02).numpy()
         os.remove(cache_file)
 
+    if pinned["embree"]:
+        mesh_query_vectors(out)
     np.savez_compressed(OUT, **out)
+    print("pinned by the real third-party packages:", pinned)
     print("wrote", OUT, os.path.getsize(OUT), "bytes,", len(out), "arrays")
 
 

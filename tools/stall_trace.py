@@ -10,12 +10,31 @@ from pytorch_volumetric_amd import _lib
 from tests import helpers as H
 
 t_start = time.perf_counter()
+if os.environ.get("PVAMD_STALL_WARMUP"):
+    pv.warm_up()
+    print(f"pv.warm_up(): {(time.perf_counter() - t_start) * 1e3:.1f} ms", flush=True)
 obj = pv.MeshObjectFactory(H.mesh_path("ycb_power_drill.npz"))
 cached = pv.CachedSDF("d", 0.01, obj.bounding_box(padding=0.1), pv.MeshSDF(obj), device="cuda", cache_path=None)
 comp = pv.ComposedSDF([cached] * 8, pv.Transform3d(matrix=H.random_rigid(8, seed=0)))
 mesh = pv.MeshSDF(obj)
+import gc
+_gc_t = [0.0]
+def _on_gc(phase, info):
+    if phase == "start":
+        _gc_t[0] = time.perf_counter()
+    else:
+        d = time.perf_counter() - _gc_t[0]
+        if d > 1e-3:
+            print(f"  garbage collection, generation {info['generation']}: {d * 1e3:.2f} ms, {info.get('collected')} collected, "
+                  f"objects tracked {len(gc.get_objects())}, at split call {launches[0] + 1}", flush=True)
+gc.callbacks.append(_on_gc)
+if os.environ.get("PVAMD_STALL_NOGC"):
+    gc.disable()
+if os.environ.get("PVAMD_STALL_FREEZE"):
+    gc.collect(); gc.freeze()
 slow = []
 launches = [0]
+LIB = _lib.load()
 
 
 def split_call(kind, pts):
@@ -26,7 +45,17 @@ def split_call(kind, pts):
     grad = torch.empty((P, 3), dtype=torch.float32, device="cuda")
     t1 = time.perf_counter()
     if kind == "comp":
-        comp.query_into(pts, val.view(1, P), grad.view(1, P, 3))
+        # ComposedSDF.query_into by hand: the Python prelude and the raw C-ABI call timed apart
+        dev = pts.device
+        grids = comp._leaf_grids(dev)
+        tfd = comp._tf_device(dev)
+        args = (_lib.ptr(grids), 8, _lib.ptr(tfd), 1, _lib.ptr(pts), P, _lib.ptr(val), _lib.ptr(grad), None, comp._query_flags,
+                _lib.stream_ptr())
+        ta = time.perf_counter()
+        rc = LIB.pvamd_composed_query(*args)
+        tb = time.perf_counter()
+        if tb - ta > 2e-3 or ta - t1 > 2e-3:
+            print(f"  comp call {launches[0] + 1}: python prelude {(ta - t1) * 1e3:.2f} ms, raw pvamd_composed_query {(tb - ta) * 1e3:.2f} ms", flush=True)
     else:
         cached.query_into(pts, val, grad)
     t2 = time.perf_counter()
