@@ -449,7 +449,17 @@ def leg_c4(torch, dist, Wk, pv, timer, gate, robots, rank, world, steps, padding
         ref = robot(pts[:65536])  # after timing: the gathered result against the unsharded call, bit for bit
         same = bool(torch.equal(full[0][:, :65536], ref[0]) and torch.equal(full[1][:, :65536], ref[1]))
         recv = getattr(sharded, "bytes_received_per_rank", None)
+        # self-check of the first multi-GPU line: as many ranks as GPUs asked for, the RCCL backend, and a rank receives
+        # (W - 1) / W of the packed output (the 256-point padding of every rank's slice included)
+        padded = -(-(-(-P // world)) // 256) * 256
+        want_recv = (world - 1) * A * padded * 16
+        check = {"ranks": dist.get_world_size(), "ranks_expected": world, "backend": dist.get_backend(),
+                 "bytes_received_per_rank_expected": want_recv, "bytes_match": recv == want_recv,
+                 "kernel_only_ms": t / steps * 1e3, "gathered_ms": tg / gsteps * 1e3}
+        check["ok"] = bool(check["ranks"] == world and same and check["bytes_match"] and
+                           (check["backend"] == "nccl" or world == 1 or getattr(sharded, "last_path", "") != "packed"))
         out["gathered"] = {"gather": True, "value": A * P * gsteps / tg, "ms_per_step": tg / gsteps * 1e3, "steps": gsteps,
+                           "self_check": check,
                            "collective": f"packed (val, grad) records, all_gather_into_tensor x1 ({dist.get_backend()}), "
                                          "unpack kernel writes (A, P) / (A, P, 3)",
                            "bytes_received_per_rank": recv,

@@ -357,6 +357,14 @@ int pvamd_transform_stack(const float* offset_inv, const float* link_world, int3
 int pvamd_chain_fk(const pvamd_joint_t* joints, int32_t F, const float* q, const float* sin_q, const float* cos_q,
                    int32_t A, int32_t M, float* scratch, float* link_world_out, void* stream);
 
+/* PlausibleDiversity's reduction of the (B, P) pairwise chamfer matrix (chamfer.py:185-195) in one pass: per row / per column
+ * the minimum and where it is (first index on ties, a NaN counts as the minimum: torch.min), and means[0] = mean of the row
+ * minima (plausibility), means[1] = mean of the column minima (coverage), summed in float64 in a fixed order.
+ * errors: device [B][P] float32 (is_f64 = 0) or float64.  row_val / col_val: device [B] / [P] of the same dtype.
+ * row_idx / col_idx: device int64.  means: device [2] float64.                                                          */
+int pvamd_pairwise_min_reduce(const void* errors, int32_t is_f64, int32_t B, int32_t P, void* row_val, int64_t* row_idx,
+                              void* col_val, int64_t* col_idx, double* means, void* stream);
+
 /* The whole of RobotSDF.set_joint_configuration (model_to_sdf.py:94-113) in ONE launch, from joint values that already sit
  * on the device: sin / cos, the frame walk of pvamd_chain_fk, and stack_out[s*A+a] = offset_inv[s] @
  * rigid_inverse(world[leaf s, a]) (the f32-MFMA statement of pvamd_transform_stack) -- the obj->leaf stack that

@@ -124,53 +124,75 @@ def pairwise_distance_chamfer(A_link_to_world_tfs, B_world_to_link_tfs=None,
     return errors.view(B, P)
 
 
+class MinOverAxis(NamedTuple):
+    """What torch.min(dim=...) returns: the reference hands these out as most_plausible_per_estimated / most_covered_per_plausible."""
+    values: torch.Tensor
+    indices: torch.Tensor
+
+
 class PlausibleDiversityReturn(NamedTuple):
     plausibility: torch.tensor
     coverage: torch.tensor
-    most_plausible_per_estimated: torch.tensor
-    most_covered_per_plausible: torch.tensor
+    most_plausible_per_estimated: MinOverAxis
+    most_covered_per_plausible: MinOverAxis
+
+
+def reduce_pairwise_errors(errors):
+    """(B, P) chamfer matrix -> PlausibleDiversityReturn (chamfer.py:185-195): plausibility = mean over the B estimated poses
+    of their best match among the P plausible ones, coverage = mean over the P plausible poses of their best match among
+    the estimated ones, with the arg-minima.  A matrix on the GPU is reduced by ONE pass of pvamd_pairwise_min_reduce (row and
+    column minima + indices, then the two means in float64 in a fixed order); a host tensor by the two torch reductions."""
+    if errors.dim() != 2:
+        raise ValueError(f"expected a (B, P) error matrix, got {tuple(errors.shape)}")
+    B, P = errors.shape
+    if not (errors.is_cuda and errors.dtype in (torch.float32, torch.float64) and B > 0 and P > 0):
+        rows, cols = errors.min(dim=1), errors.min(dim=0)
+        return PlausibleDiversityReturn(rows.values.sum() / B, cols.values.sum() / P, MinOverAxis(rows.values, rows.indices),
+                                        MinOverAxis(cols.values, cols.indices))
+    E = errors.detach().contiguous()
+    dev = E.device
+    row_val, col_val = torch.empty((B,), dtype=E.dtype, device=dev), torch.empty((P,), dtype=E.dtype, device=dev)
+    row_idx, col_idx = torch.empty((B,), dtype=torch.int64, device=dev), torch.empty((P,), dtype=torch.int64, device=dev)
+    means = torch.empty((2,), dtype=torch.float64, device=dev)
+    with _lib.on_device(dev):
+        _lib.check(_lib.load().pvamd_pairwise_min_reduce(_lib.ptr(E), 1 if E.dtype == torch.float64 else 0, B, P, _lib.ptr(row_val),
+                                                         _lib.ptr(row_idx), _lib.ptr(col_val), _lib.ptr(col_idx), _lib.ptr(means),
+                                                         _lib.stream_ptr()), "pvamd_pairwise_min_reduce")
+    means = means.to(E.dtype)
+    return PlausibleDiversityReturn(means[0], means[1], MinOverAxis(row_val, row_idx), MinOverAxis(col_val, col_idx))
 
 
 class PlausibleDiversity:
-    """Plausibility / coverage of an estimated pose set against a plausible pose set, in squared distance units
-    (chamfer.py:130-195)."""
+    """Plausibility / coverage of an estimated pose set against a plausible pose set, in squared distance units (chamfer.py:
+    123-195): every (estimated, plausible) pair is scored by the chamfer error of the object's surface points under the
+    relative pose, and the (B, P) matrix is reduced on the device."""
 
     def __init__(self, obj_factory: ObjectFactory, model_points_eval: torch.tensor = None, num_model_points_eval=500,
                  obj_sdf: ObjectFrameSDF = None):
-        self.obj_factory = obj_factory
-        self.obj_sdf = obj_sdf
-        if model_points_eval is None:
-            model_points_eval, _, _ = sample_mesh_points(obj_factory, num_points=num_model_points_eval,
-                                                         name=obj_factory.name)
+        self.obj_factory, self.obj_sdf = obj_factory, obj_sdf
+        if model_points_eval is None:  # the object's own surface samples (chamfer.py:136-138)
+            model_points_eval = sample_mesh_points(obj_factory, num_points=num_model_points_eval, name=obj_factory.name)[0]
         self.model_points_eval = model_points_eval
 
+    def pairwise_errors(self, first_inv, second, scale=1000.):
+        """errors[b, p] = chamfer error of the model points under first_inv[b] @ second[p] (chamfer.py:173-183).  All B * P
+        relative poses go through ONE batch_chamfer_dist call (one spatial order over every transformed point)."""
+        relative = torch.matmul(tf.as_matrix(first_inv).unsqueeze(1), tf.as_matrix(second).unsqueeze(0))  # (B, P, 4, 4)
+        B, P = relative.shape[:2]
+        self.model_points_eval = self.model_points_eval.to(device=relative.device, dtype=relative.dtype)
+        return batch_chamfer_dist(relative.reshape(B * P, 4, 4), self.model_points_eval, self.obj_factory, obj_sdf=self.obj_sdf,
+                                  scale=scale).view(B, P)
+
+    # the reference's names for the two steps
+    compute_tf_pairwise_error_per_batch = pairwise_errors
+    do_evaluate_plausible_diversity_on_pairwise_chamfer_dist = staticmethod(reduce_pairwise_errors)
+
     def __call__(self, T_est_inv, T_p, bidirectional=False, scale=1000.):
-        errors = self.compute_tf_pairwise_error_per_batch(T_est_inv, T_p, scale=scale)
-        ret = self.do_evaluate_plausible_diversity_on_pairwise_chamfer_dist(errors)
-        if bidirectional:
-            errors_rev = self.compute_tf_pairwise_error_per_batch(T_p, T_est_inv, scale=scale)
-            ret2 = self.do_evaluate_plausible_diversity_on_pairwise_chamfer_dist(errors_rev)
-            # plausibility and coverage swap roles when the two sets are swapped
-            ret = PlausibleDiversityReturn(
-                plausibility=(ret.plausibility + ret2.coverage) / 2,
-                coverage=(ret.coverage + ret2.plausibility) / 2,
-                most_plausible_per_estimated=ret.most_plausible_per_estimated,
-                most_covered_per_plausible=ret.most_covered_per_plausible,
-            )
-        return ret
-
-    def compute_tf_pairwise_error_per_batch(self, T_est_inv, T_p, scale=1000.):
-        Iapprox = torch.einsum("bij,pjk->bpik", T_est_inv, T_p)
-        B, P = Iapprox.shape[:2]
-        self.model_points_eval = self.model_points_eval.to(device=Iapprox.device, dtype=Iapprox.dtype)
-        errors = batch_chamfer_dist(Iapprox.reshape(B * P, 4, 4), self.model_points_eval, self.obj_factory,
-                                    obj_sdf=self.obj_sdf, viewing_delay=0, vis=None, scale=scale)
-        return errors.view(B, P)
-
-    @staticmethod
-    def do_evaluate_plausible_diversity_on_pairwise_chamfer_dist(errors_per_batch):
-        B, P = errors_per_batch.shape
-        best_per_sampled = errors_per_batch.min(dim=1)
-        best_per_plausible = errors_per_batch.min(dim=0)
-        return PlausibleDiversityReturn(best_per_sampled.values.sum() / B, best_per_plausible.values.sum() / P,
-                                        best_per_sampled, best_per_plausible)
+        forward = reduce_pairwise_errors(self.pairwise_errors(T_est_inv, T_p, scale=scale))
+        if not bidirectional:
+            return forward
+        # the sets swapped: what was plausibility there is coverage here and vice versa (chamfer.py:160-170); the argmins
+        # reported stay those of the forward direction
+        backward = reduce_pairwise_errors(self.pairwise_errors(T_p, T_est_inv, scale=scale))
+        return PlausibleDiversityReturn((forward.plausibility + backward.coverage) / 2, (forward.coverage + backward.plausibility) / 2,
+                                        forward.most_plausible_per_estimated, forward.most_covered_per_plausible)

@@ -35,6 +35,67 @@ __global__ __launch_bounds__(256) void chamfer_grid_kernel(const pvamd_grid_t g,
     }
 }
 
+// ---- PlausibleDiversity's reduction (chamfer.py:185-195) in one pass over the (B, P) chamfer matrix ----
+// block b < B: the minimum of row b (first index on ties, NaN counts as the minimum -- torch.min);
+// block B + c: the minima of columns 256 c .. 256 c + 255 (thread = column: coalesced across a row).
+template <typename T>
+__global__ __launch_bounds__(256) void pairwise_min_kernel(const T* __restrict__ E, int B, int P, T* __restrict__ row_val,
+                                                          int64_t* __restrict__ row_idx, T* __restrict__ col_val,
+                                                          int64_t* __restrict__ col_idx) {
+    auto better = [](T v, int i, T bv, int bi) {  // (v, i) before (bv, bi): smaller value, NaN smallest, then lower index
+        const bool vn = v != v, bn = bv != bv;
+        if (vn != bn) return vn;
+        if (!vn && v != bv) return v < bv;
+        return i < bi;
+    };
+    if ((int)blockIdx.x < B) {
+        const int b = blockIdx.x;
+        T v = E[(int64_t)b * P + (threadIdx.x < (unsigned)P ? threadIdx.x : 0)];
+        int idx = threadIdx.x < (unsigned)P ? (int)threadIdx.x : 0;
+        for (int j = threadIdx.x + 256; j < P; j += 256) {
+            const T w = E[(int64_t)b * P + j];
+            if (better(w, j, v, idx)) { v = w; idx = j; }
+        }
+        __shared__ T sv[256];
+        __shared__ int si[256];
+        sv[threadIdx.x] = v; si[threadIdx.x] = idx;
+        __syncthreads();
+        for (int off = 128; off > 0; off >>= 1) {
+            if ((int)threadIdx.x < off && better(sv[threadIdx.x + off], si[threadIdx.x + off], sv[threadIdx.x], si[threadIdx.x])) {
+                sv[threadIdx.x] = sv[threadIdx.x + off];
+                si[threadIdx.x] = si[threadIdx.x + off];
+            }
+            __syncthreads();
+        }
+        if (threadIdx.x == 0) { row_val[b] = sv[0]; row_idx[b] = si[0]; }
+    } else {
+        const int c = ((int)blockIdx.x - B) * 256 + threadIdx.x;
+        if (c >= P) return;
+        T v = E[c];
+        int idx = 0;
+        for (int b = 1; b < B; ++b) {
+            const T w = E[(int64_t)b * P + c];
+            if (better(w, b, v, idx)) { v = w; idx = b; }
+        }
+        col_val[c] = v; col_idx[c] = idx;
+    }
+}
+
+// sums[0] = mean of the row minima, sums[1] = mean of the column minima: one wave, fixed order, float64
+template <typename T>
+__global__ __launch_bounds__(64) void pairwise_mean_kernel(const T* __restrict__ row_val, int B, const T* __restrict__ col_val, int P,
+                                                          double* __restrict__ sums) {
+    double a = 0.0, c = 0.0;
+    for (int i = threadIdx.x; i < B; i += 64) a += (double)row_val[i];
+    for (int i = threadIdx.x; i < P; i += 64) c += (double)col_val[i];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        a += __shfl_down(a, off, 64);
+        c += __shfl_down(c, off, 64);
+    }
+    if (threadIdx.x == 0) { sums[0] = a / B; sums[1] = c / P; }
+}
+
 __global__ void zero_f64_kernel2(double* p, int n) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) p[i] = 0.0;
@@ -61,6 +122,24 @@ extern "C" int pvamd_chamfer_grid(const pvamd_grid_t* grid, const float* W, int3
         const unsigned gx = (unsigned)(need < cap ? need : (cap < 1 ? 1 : cap));
         if (grid->index_f64) hipLaunchKernelGGL((chamfer_grid_kernel<true>), dim3(gx, nb), dim3(256), 0, s, *grid, W + 16 * (int64_t)b0, points, N, scale, out_sum + b0);
         else hipLaunchKernelGGL((chamfer_grid_kernel<false>), dim3(gx, nb), dim3(256), 0, s, *grid, W + 16 * (int64_t)b0, points, N, scale, out_sum + b0);
+    }
+    return (int)hipGetLastError();
+}
+
+extern "C" int pvamd_pairwise_min_reduce(const void* errors, int32_t is_f64, int32_t B, int32_t P, void* row_val, int64_t* row_idx,
+                                         void* col_val, int64_t* col_idx, double* means, void* stream) {
+    if (!errors || !row_val || !row_idx || !col_val || !col_idx || !means) return PVAMD_E_NULL;
+    if (B < 1 || P < 1) return PVAMD_E_SHAPE;
+    hipStream_t s = (hipStream_t)stream;
+    const unsigned blocks = (unsigned)B + (unsigned)((P + 255) / 256);
+    if (is_f64) {
+        hipLaunchKernelGGL((pairwise_min_kernel<double>), dim3(blocks), dim3(256), 0, s, (const double*)errors, B, P, (double*)row_val,
+                           row_idx, (double*)col_val, col_idx);
+        hipLaunchKernelGGL((pairwise_mean_kernel<double>), dim3(1), dim3(64), 0, s, (const double*)row_val, B, (const double*)col_val, P, means);
+    } else {
+        hipLaunchKernelGGL((pairwise_min_kernel<float>), dim3(blocks), dim3(256), 0, s, (const float*)errors, B, P, (float*)row_val,
+                           row_idx, (float*)col_val, col_idx);
+        hipLaunchKernelGGL((pairwise_mean_kernel<float>), dim3(1), dim3(64), 0, s, (const float*)row_val, B, (const float*)col_val, P, means);
     }
     return (int)hipGetLastError();
 }

@@ -54,6 +54,11 @@ def test_two_ranks_share_the_gpu_and_every_leg_reports():
     assert legs["c4"]["gathered"]["bytes_received_per_rank"] == 8 * 8192 * 16 and legs["c4"]["gathered"]["xgmi_lower_bound_ms"] > 0
     assert legs["c4"]["gathered_by_configs"]["equals_unsharded_call"] is True
     assert legs["c5"]["rel_err_vs_analytic"] < 1e-3
+    # the self-check the first real multi-GPU line will carry: rank count, received bytes = (W - 1) / W of the packed output,
+    # kernel-only against gathered time (gloo here, so `ok` only asks for the backend when the ranks own their GPUs)
+    chk = legs["c4"]["gathered"]["self_check"]
+    assert chk["ranks"] == chk["ranks_expected"] == 2 and chk["bytes_match"] is True and chk["backend"] == "gloo"
+    assert chk["bytes_received_per_rank_expected"] == 8 * 8192 * 16 and chk["gathered_ms"] > 0 and chk["kernel_only_ms"] > 0
 
 
 @pytest.mark.gpu
@@ -106,9 +111,15 @@ def test_single_rank_line_has_the_contract_fields():
     assert roof["bound"] == "hbm" and roof["unit"] == "GB/s" and abs(roof["frac"] - roof["achieved"] / roof["peak"]) < 1e-9
     assert "SEPARATE" in roof["timing"] and "traffic_source" in roof
     assert roof["dropin_call"]["ms_per_call"] > 0 and roof["dropin_call"]["queries_per_s"] > 1e9
-    assert "torch_opforop" in line["cpu_baseline"] and "FUSED" in line["cpu_baseline"]["what"]
+    assert "launch_ms_best_replay" in roof and roof["launch_ms_best_replay"] <= roof["launch_ms_mean"] and "frac_rocprof" in roof
+    assert roof["frac"] <= 1.0 and roof["frac_best_replay"] <= 1.0
+    cpu = line["cpu_baseline"]
+    # the op-for-op restatement of what the reference runs on CPU is the headline CPU figure; the fused C port is nested
+    assert cpu["kind"] == "op-for-op restatement" and cpu["cores"] >= 1 and cpu["spread"]["samples"] >= 3
+    assert cpu["fused_port"]["kind"] == "port" and cpu["fused_port"]["value"] > cpu["value"]
+    assert cpu["spread"]["min"] <= cpu["value"] <= cpu["spread"]["max"] and cpu["thread_pinning"]["OMP_PROC_BIND"] == "close"
     assert line["steps"] == 20 and line["warmup"] == 5 and line["n_gpus"] == 1
-    assert line["cpu_baseline"]["kind"] == "port" and line["cpu_baseline"]["cores"] >= 1
+    assert "UNPINNED" in line["parity"]["oracle"]
 
 
 @pytest.mark.gpu

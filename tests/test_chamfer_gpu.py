@@ -105,6 +105,35 @@ def test_plausible_diversity_properties(mesh):
     assert torch.allclose(r.coverage, r_other.plausibility, rtol=0.15)
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float64])
+def test_device_reduction_of_the_pairwise_matrix_equals_the_reference_reducer(dtype):
+    """pvamd_pairwise_min_reduce (row / column minima, first index on ties, NaN as the minimum, the two means) against the
+    vectors the reference's own do_evaluate_plausible_diversity_on_pairwise_chamfer_dist produced (pd/*) and against torch's
+    reductions on matrices with ties, NaNs and more columns than a block holds."""
+    import os
+    G = np.load(os.path.join(H.GOLDEN, "reference_lifted.npz"))
+    E = torch.from_numpy(G["pd/errors"]).to(dtype)
+    r = pv.PlausibleDiversity.do_evaluate_plausible_diversity_on_pairwise_chamfer_dist(E.cuda())
+    assert r.plausibility.is_cuda and r.plausibility.dtype == dtype
+    assert np.allclose(r.plausibility.cpu().numpy(), G["pd/plausibility"], rtol=1e-6)
+    assert np.allclose(r.coverage.cpu().numpy(), G["pd/coverage"], rtol=1e-6)
+    assert np.array_equal(r.most_plausible_per_estimated.indices.cpu().numpy(), G["pd/argmin_rows"])
+    assert np.array_equal(r.most_covered_per_plausible.indices.cpu().numpy(), G["pd/argmin_cols"])
+    g = torch.Generator().manual_seed(4)
+    for B, P in ((1, 1), (3, 700), (257, 5), (120, 300)):
+        M = torch.rand(B, P, generator=g, dtype=torch.float64).mul(8).round().div(8).to(dtype)  # many exact ties
+        if B * P > 100:
+            M[B // 2, P // 3] = float("nan")
+        dev = pv.chamfer.reduce_pairwise_errors(M.cuda())
+        rows, cols = M.min(dim=1), M.min(dim=0)  # host torch: first index on ties, NaN propagates
+        assert torch.equal(dev.most_plausible_per_estimated.values.cpu().nan_to_num(-1.0), rows.values.nan_to_num(-1.0))
+        assert torch.equal(dev.most_covered_per_plausible.values.cpu().nan_to_num(-1.0), cols.values.nan_to_num(-1.0))
+        assert torch.equal(dev.most_plausible_per_estimated.indices.cpu(), rows.indices)
+        assert torch.equal(dev.most_covered_per_plausible.indices.cpu(), cols.indices)
+        assert torch.allclose(dev.plausibility.cpu(), rows.values.sum() / B, rtol=1e-5, equal_nan=True)
+        assert torch.allclose(dev.coverage.cpu(), cols.values.sum() / P, rtol=1e-5, equal_nan=True)
+
+
 def test_pairwise_distance_chamfer_shape_and_diagonal():
     obj = pv.MeshObjectFactory(H.mesh_path("probe.obj"))
     T = perturbations(torch.eye(4).unsqueeze(0), 6, seed=2)
