@@ -813,6 +813,11 @@ __global__ __launch_bounds__(256) void compose_merge_kernel(const float* __restr
 #define PVAMD_UNPERMUTE_TILES 1
 #endif
 constexpr int kUnpermuteTiles = PVAMD_UNPERMUTE_TILES;
+// waves per workgroup of the un-permute pass: its own knob (the query kernel's 4 are tuned for its register budget)
+#ifndef PVAMD_UNPERMUTE_WAVES
+#define PVAMD_UNPERMUTE_WAVES 4
+#endif
+constexpr int kUnpermuteWaves = PVAMD_UNPERMUTE_WAVES;
 // ---- bucketed path: un-permute ----
 // The kernel above ran on spatially sorted points and left one packed record per (configuration, sorted position);
 // this pass brings them back to the caller's point order: out[a][j] = packed[a][inv[j]].  One wave = 256 consecutive
@@ -821,12 +826,12 @@ constexpr int kUnpermuteTiles = PVAMD_UNPERMUTE_TILES;
 // 1 KB stores like everywhere else.  Blocks of one configuration are kept on one XCD (block b runs on XCD b % 8) so that
 // the window is pulled into ONE L2 instead of eight (README-size C4, whole bucketed call: 1.67 ms pinned, 2.06 ms with
 // configuration-major blocks, 2.30 ms with configuration-fastest blocks).
-__global__ __launch_bounds__(kWavesPerBlock * 64) void composed_unpermute_kernel(const f32x4* __restrict__ packed,
+__global__ __launch_bounds__(kUnpermuteWaves * 64) void composed_unpermute_kernel(const f32x4* __restrict__ packed,
                                                                                  const int* __restrict__ inv, int64_t P,
                                                                                  int64_t Pp, int A, int64_t tile_blocks,
                                                                                  float* __restrict__ val,
                                                                                  float* __restrict__ grad) {
-    __shared__ __attribute__((aligned(16))) float lds[kWavesPerBlock][1024];
+    __shared__ __attribute__((aligned(16))) float lds[kUnpermuteWaves][1024];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     float* spf = lds[wave];
     f32x4_alias* sp = reinterpret_cast<f32x4_alias*>(spf);
@@ -840,7 +845,7 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void composed_unpermute_kernel
     const f32x4* src = packed + (int64_t)a * Pp;
     // kUnpermuteTiles tiles per wave: all their gathers are issued before the first result is used
     f32x4 r[kUnpermuteTiles][4];
-    const int64_t tile0 = ((within / 8) * kWavesPerBlock + wave) * kUnpermuteTiles;
+    const int64_t tile0 = ((within / 8) * kUnpermuteWaves + wave) * kUnpermuteTiles;
 #pragma unroll
     for (int t = 0; t < kUnpermuteTiles; ++t) {
 #pragma unroll
@@ -921,12 +926,12 @@ extern "C" int pvamd_unpack_records(const float* rec, const int32_t* index, int6
     if (!rec || !index || !out_val || !out_grad) return PVAMD_E_NULL;
     if (!aligned_to(rec, 16) || !aligned_to(index, 4) || !aligned_to(out_val, 4) || !aligned_to(out_grad, 4)) return PVAMD_E_ALIGN;
     const int64_t ntiles = (P + kTilePoints - 1) / kTilePoints;
-    const int64_t tile_blocks = (ntiles + kWavesPerBlock - 1) / kWavesPerBlock;
+    const int64_t tile_blocks = (ntiles + kUnpermuteWaves - 1) / kUnpermuteWaves;
     const int64_t groups = ((int64_t)A + 7) / 8;
     const int64_t ublocks = (tile_blocks + kUnpermuteTiles - 1) / kUnpermuteTiles;
     const int64_t blocks = groups * 8 * ublocks;
     if (blocks > 0x7fffffffLL) return PVAMD_E_SHAPE;
-    hipLaunchKernelGGL(composed_unpermute_kernel, dim3((unsigned)blocks), dim3(kWavesPerBlock * 64), 0, (hipStream_t)stream,
+    hipLaunchKernelGGL(composed_unpermute_kernel, dim3((unsigned)blocks), dim3(kUnpermuteWaves * 64), 0, (hipStream_t)stream,
                        reinterpret_cast<const f32x4*>(rec), index, P, stride, A, ublocks, out_val, out_grad);
     return (int)hipGetLastError();
 }
