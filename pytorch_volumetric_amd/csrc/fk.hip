@@ -99,11 +99,27 @@ __global__ __launch_bounds__(64) void configure_chain_kernel(const pvamd_joint_t
     // the joint table through LDS: one coalesced read instead of a chain of F dependent scalar-cache misses (the walk is
     // serial: at A = 20 the kernel IS its latency)
     pvamd_joint_t* sj = reinterpret_cast<pvamd_joint_t*>(leafm + (size_t)S * 12 * 64);
+    float* ssc = reinterpret_cast<float*>(sj + F);  // [64][M][2]: sin, cos of this block's joint values
     {
         const uint32_t* src = reinterpret_cast<const uint32_t*>(joints);
         uint32_t* dst = reinterpret_cast<uint32_t*>(sj);
         const int words = F * (int)(sizeof(pvamd_joint_t) / 4);
         for (int w = lane; w < words; w += 64) dst[w] = src[w];
+    }
+    // phase 0: every sine / cosine of the block, lanes = (configuration, joint) pairs -- ~100 instructions each that would
+    // otherwise sit in every lane's serial frame walk (with A = 20 only 20 lanes walk; all 64 work here)
+    {
+        const int nA0 = A - a0 < 64 ? A - a0 : 64;
+        for (int idx = lane; idx < nA0 * M; idx += 64) {
+            const float qv = q[(int64_t)a0 * M + idx];
+            const float sv = sinf(qv), cv = cosf(qv);  // (joint values are a few radians: the small-argument path of both)
+            ssc[2 * idx] = sv;
+            ssc[2 * idx + 1] = cv;
+            if (sincos) {
+                sincos[((int64_t)a0 * M + idx) * 2] = sv;
+                sincos[((int64_t)a0 * M + idx) * 2 + 1] = cv;
+            }
+        }
     }
     __syncthreads();
     float m[12];
@@ -122,12 +138,7 @@ __global__ __launch_bounds__(64) void configure_chain_kernel(const pvamd_joint_t
         }
         compose_affine(P, J.origin, m);
         if (J.jtype == 1) {  // revolute / continuous: Rodrigues rotation about the joint axis
-            const float qv = q[(int64_t)ar * M + J.jcol];
-            const float s = sinf(qv), c = cosf(qv);  // (joint values are a few radians: the small-argument path of both)
-            if (sincos && live) {
-                sincos[((int64_t)a * M + J.jcol) * 2] = s;
-                sincos[((int64_t)a * M + J.jcol) * 2 + 1] = c;
-            }
+            const float s = ssc[2 * ((ar - a0) * M + J.jcol)], c = ssc[2 * ((ar - a0) * M + J.jcol) + 1];
             const float x = J.axis[0], y = J.axis[1], z = J.axis[2];
             const float t = sub_rn(1.f, c);
             const float tx = mul_rn(t, x), ty = mul_rn(t, y), tz = mul_rn(t, z);
@@ -210,7 +221,7 @@ extern "C" int pvamd_configure_chain(const pvamd_joint_t* joints, int32_t F, con
     if (F < 1 || A < 1 || M < 0 || S < 1) return PVAMD_E_SHAPE;
     if (!joints || !offset_inv || !scratch || !stack_out) return PVAMD_E_NULL;
     if (M > 0 && !q) return PVAMD_E_NULL;
-    const size_t lds = (size_t)S * 12 * 64 * sizeof(float) + (size_t)F * sizeof(pvamd_joint_t);
+    const size_t lds = (size_t)S * 12 * 64 * sizeof(float) + (size_t)F * sizeof(pvamd_joint_t) + (size_t)64 * M * 2 * sizeof(float);
     if (lds > 150 * 1024) return PVAMD_E_SHAPE;  // ~50 SDF-carrying links: use pvamd_chain_fk + pvamd_transform_stack
     hipLaunchKernelGGL(configure_chain_kernel, dim3((A + 63) / 64), dim3(64), lds, (hipStream_t)stream, joints, F, q, A, M,
                        offset_inv, S, sincos_out, scratch, link_world_out, stack_out);
