@@ -1,0 +1,16 @@
+#!/bin/bash
+export TMPDIR=/tmp
+O=gpurun_out/r4b15; mkdir -p $O
+rm -rf /tmp/kt; rocprofv3 --kernel-trace --output-format csv -d /tmp/kt -o c -- python tools/run_composed.py c4 0 12 > /tmp/kt.log 2>&1
+python - <<PY
+import csv, glob, collections
+d = collections.defaultdict(list)
+for f in glob.glob("/tmp/kt/**/*kernel_trace.csv", recursive=True):
+    for r in csv.DictReader(open(f)):
+        if "composed" in r["Kernel_Name"]:
+            d[r["Kernel_Name"][:70]].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
+for k, v in d.items():
+    v = v[2:]
+    print(k, "n=%d mean %.1f us min %.1f" % (len(v), sum(v) / len(v), min(v)))
+PY
+timeout 600 python tools/composed_ab.py c4 2>&1 | grep "^C4" | tee $O/composed_ab.txt
