@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define PVAMD_ABI_VERSION 9
+#define PVAMD_ABI_VERSION 8
 
 #define PVAMD_E_NULL      (-1)  /* a required pointer is NULL            */
 #define PVAMD_E_SHAPE     (-2)  /* a size/shape argument is out of range */
@@ -211,21 +211,9 @@ int pvamd_voxel_scatter_u8(const pvamd_grid_t* grid, uint8_t* storage, const flo
 #define PVAMD_COMPOSED_FORCE_WAVE_TILE 4  /* testing / tuning: take the wave-tile kernel whatever the size                 */
 #define PVAMD_COMPOSED_POINTS_FASTEST 8   /* tuning: per-lane kernel with blocks ordered points-fastest (default: configuration-fastest) */
 #define PVAMD_COMPOSED_LEGACY_LEAF_LOOP 16 /* testing / tuning: wave-tile kernel with the round-3 leaf loop (lookups and exact roots inside the leaf loop) */
-#define PVAMD_COMPOSED_ONE_LAUNCH 32      /* testing / tuning: pvamd_composed_query_scratch ignores its scratch */
 int pvamd_composed_query(const pvamd_grid_t* grids, int32_t S, const float* tf, int32_t A,
                          const float* points, int64_t P,
                          float* out_val, float* out_grad, int32_t* out_leaf, int32_t flags, void* stream);
-
-/* The same query with caller scratch (round 4).  With scratch_bytes >= 4 * A * P, at most 24 leaves and a query the
- * wave-tile kernel takes (L2-resident grids), the call is TWO launches: the first answers every (configuration, point)
- * pair from the out-of-range (bounding-box) candidates alone and leaves one 32-bit record per pair in the scratch (which
- * leaves the point is in range of, which leaf holds the out-of-range minimum); the second walks the records of the whole
- * launch, 64 pairs with an in-range leaf to a wave, looks those leaves up and overwrites the answer where one of them wins
- * by (value, leaf) -- sdf.py:421, the same bits as pvamd_composed_query.  Otherwise (scratch NULL or too small, more
- * leaves, large grids, few pairs) it IS pvamd_composed_query.  scratch: device, 4-byte aligned, contents undefined after.  */
-int pvamd_composed_query_scratch(const pvamd_grid_t* grids, int32_t S, const float* tf, int32_t A,
-                                 const float* points, int64_t P, float* out_val, float* out_grad, int32_t* out_leaf,
-                                 void* scratch, int64_t scratch_bytes, int32_t flags, void* stream);
 
 /* The same query for FLOAT64 points with a float64 transform stack (sdf.py:392-433 when the chain / the Transform3d is
  * float64: the transform, every leaf's index arithmetic, range test and bounding-box branch -- sdf.py:545-547 -- and the

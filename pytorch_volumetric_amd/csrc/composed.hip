@@ -389,16 +389,10 @@ struct BestIn {
     int leaf, flat;
 };
 
-// DEFERRED (two launches, pvamd_composed_query_scratch): the leaf loop does NOT look the in-range leaves up; it records
-// them -- bit s of a 24-bit mask per (configuration, point), beside the out-of-range winner's leaf -- and writes the
-// out-of-range answer; composed_inrange_kernel then walks the records of the whole launch, compacted 64 to a wave.
-constexpr int kDeferredMaxLeaves = 24;   // mask bits of a record
-constexpr uint32_t kRecNoLeaf = 255u;    // "no out-of-range candidate": loses every (value, leaf) tie
-template <int PPP, bool PACKED, bool MASKED, bool DEFERRED = false>
+template <int PPP, bool PACKED, bool MASKED>
 PVAMD_DEV void tile_passes_split(const pvamd_grid_t* __restrict__ grids, int S, const float* __restrict__ tf, int A, int a,
                                  int64_t first, int64_t P, float* __restrict__ val, int* __restrict__ leaf, float* spf,
-                                 int lane, uint64_t todo, float lower, uint32_t* __restrict__ rec = nullptr) {
-    static_assert(!(DEFERRED && PACKED), "the packed (sorted / sharded) paths keep the one-launch loop");
+                                 int lane, uint64_t todo, float lower) {
     float* svf = spf + 768;
     const int first_leaf = todo ? __builtin_ctzll(todo) : 0;
     const bool refine = MASKED && S <= 64 && todo != ((S >= 64) ? ~0ull : ((1ull << S) - 1ull));
@@ -409,7 +403,6 @@ PVAMD_DEV void tile_passes_split(const pvamd_grid_t* __restrict__ grids, int S, 
         BestOut best[PPP];
         BestIn bin[PPP];
         uint64_t unsure[PPP];
-        uint32_t bits[PPP];  // DEFERRED: the leaves this point is in range of
 #pragma unroll
         for (int k = 0; k < PPP; ++k) {
             const int p = lane + 64 * (h + k);
@@ -419,7 +412,6 @@ PVAMD_DEV void tile_passes_split(const pvamd_grid_t* __restrict__ grids, int S, 
             best[k] = BestOut{__builtin_inff(), __builtin_nanf(""), __builtin_nanf(""), __builtin_nanf(""), kNoLeaf};
             bin[k] = BestIn{__builtin_inff(), kNoLeaf, 0};
             unsure[k] = 0;
-            bits[k] = 0;
         }
         uint64_t rem = todo;
         for (int s = 0; s < S; ++s) {
@@ -435,10 +427,7 @@ PVAMD_DEV void tile_passes_split(const pvamd_grid_t* __restrict__ grids, int S, 
 #if defined(PVAMD_ABLATE) && (PVAMD_ABLATE & 1)  // timing experiment only (tools/r4_ablate.sh): no in-range look-ups
                 vm = 0;
 #endif
-                if (DEFERRED && vm != 0) {
-                    if (__builtin_amdgcn_inverse_ballot_w64(vm)) bits[k] |= 1u << s;
-                    if (vm == everyone) continue;
-                } else if (vm != 0) {
+                if (vm != 0) {
                     // the lanes in range look their value up (index estimate; shaky ones are redone exactly below)
                     const bool valid = __builtin_amdgcn_inverse_ballot_w64(vm);
                     bool shaky = false;
@@ -499,11 +488,7 @@ PVAMD_DEV void tile_passes_split(const pvamd_grid_t* __restrict__ grids, int S, 
             fin[k].gy = best[k].ty;
             fin[k].gz = best[k].tz;
             fin[k].tag = (best[k].leaf == kNoLeaf ? first_leaf : best[k].leaf) | kUnnormalised;
-            const bool has = !DEFERRED && bin[k].leaf != kNoLeaf;
-            if (DEFERRED) {  // one coalesced 4-byte store per point: the mask and who holds the out-of-range minimum
-                const uint32_t who = best[k].leaf == kNoLeaf ? kRecNoLeaf : (uint32_t)best[k].leaf;
-                rec[(int64_t)a * P + first + lane + 64 * (h + k)] = bits[k] | (who << 24);
-            }
+            const bool has = bin[k].leaf != kNoLeaf;
             if (wave_any(has)) {
                 const int li = has ? bin[k].leaf : 0;
                 float4 r = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -549,172 +534,6 @@ PVAMD_DEV void tile_passes_split(const pvamd_grid_t* __restrict__ grids, int S, 
             if (leaf) leaf[(int64_t)a * P + first + p] = s_win;
         }
     }
-}
-
-// ---- second launch of the two-launch query: the in-range look-ups of the WHOLE launch, 64 to a wave ----
-// One row per leaf for the block's configuration, what a per-lane look-up needs, in 16-byte groups for ds_read_b128:
-//   [0..11] 3x4 obj->leaf matrix   [12..14] fmin  [15] shape[1]   [16..18] inv32  [19] shape[2]   [20..22] err32
-//   [23] nx*ny*nz - 1              [24,25] vox pointer            [26,27] unused
-constexpr int kLeafRow = 28;
-#ifndef PVAMD_INRANGE_WAVES
-#define PVAMD_INRANGE_WAVES 16
-#endif
-constexpr int kInrangeWaves = PVAMD_INRANGE_WAVES;  // one leaf table per workgroup: 16 waves share it
-constexpr int kInrangePointsPerBlock = 1024 * kInrangeWaves;
-constexpr int kInrangeQueue = 128;  // (point, record) entries per wave; drained 64 at a time
-
-PVAMD_DEV void build_leaf_table(const pvamd_grid_t* __restrict__ grids, int S, const float* __restrict__ tf, int A, int a,
-                                float* table) {
-    for (int s = threadIdx.x; s < S; s += blockDim.x) {
-        const pvamd_grid_t& g = grids[s];
-        const float* M = tf + 16 * ((int64_t)s * A + a);
-        float* row = table + kLeafRow * s;
-#pragma unroll
-        for (int j = 0; j < 12; ++j) row[j] = M[j];
-#pragma unroll
-        for (int d = 0; d < 3; ++d) {
-            row[12 + d] = g.fmin[d];
-            row[16 + d] = g.inv32[d];
-            row[20 + d] = g.err32[d];
-        }
-        row[15] = __int_as_float(g.shape[1]);
-        row[19] = __int_as_float(g.shape[2]);
-        row[23] = __int_as_float(g.shape[0] * g.shape[1] * g.shape[2] - 1);
-        const uint64_t vox = (uint64_t)(uintptr_t)g.vox;
-        row[24] = __uint_as_float((uint32_t)vox);
-        row[25] = __uint_as_float((uint32_t)(vox >> 32));
-        row[26] = row[27] = 0.f;
-    }
-}
-
-// The records rec[a][i] = mask | who << 24 that the first launch left: a wave streams through its share of one
-// configuration's records (coalesced 4-byte loads), appends the non-zero ones to a queue in LDS, and whenever 64 wait, lane e
-// takes entry e: it walks the set bits of ITS mask in ascending leaf order (index estimate with the exact statements behind
-// a rare branch, 16-byte gather of the record; "strictly smaller, or the first" = first minimum, NaN counts as minimum), then
-// compares that minimum with the out-of-range answer already in the outputs by (value, leaf) -- sdf.py:421 over all leaves --
-// and overwrites it where the in-range leaf wins.  On scattered points 10 % of the pairs have a record and a drain works
-// with all 64 lanes, where the in-loop look-ups of the one-launch kernel ran for 1.3.
-__global__ __launch_bounds__(kInrangeWaves * 64) void composed_inrange_kernel(const pvamd_grid_t* __restrict__ grids, int S,
-                                                                              const float* __restrict__ tf, int A,
-                                                                              const float* __restrict__ pts, int64_t P,
-                                                                              const uint32_t* __restrict__ rec,
-                                                                              float* __restrict__ val, float* __restrict__ grad,
-                                                                              int* __restrict__ leaf_out, int a0) {
-    extern __shared__ __attribute__((aligned(16))) float leaf_table[];  // S rows of kLeafRow floats
-    __shared__ uint64_t queues[kInrangeWaves][kInrangeQueue];
-    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int a = a0 + blockIdx.x;
-    build_leaf_table(grids, S, tf, A, a, leaf_table);
-    __syncthreads();
-    uint64_t* queue = queues[wave];
-    const uint32_t* my_rec = rec + (int64_t)a * P;
-    const int64_t begin = (int64_t)blockIdx.y * kInrangePointsPerBlock + (int64_t)wave * (kInrangePointsPerBlock / kInrangeWaves);
-    const int64_t end_ = begin + kInrangePointsPerBlock / kInrangeWaves < P ? begin + kInrangePointsPerBlock / kInrangeWaves : P;
-    int count = 0;  // wave-uniform
-    auto drain = [&](int n) {  // the last n (<= 64) entries
-        PVAMD_WAVE_SYNC();
-        const bool active = lane < n;
-        const uint64_t e = active ? queue[count - n + lane] : 0;
-        count -= n;
-        const int64_t i = (int64_t)(e >> 32);
-        uint32_t mask = (uint32_t)e & 0xFFFFFFu;
-        const uint32_t who = ((uint32_t)e >> 24) & 0xFFu;
-        float px = 0.f, py = 0.f, pz = 0.f, vo = 0.f;
-        if (active) {  // the point and the answer it may replace: one round trip for both
-            px = pts[3 * i];
-            py = pts[3 * i + 1];
-            pz = pts[3 * i + 2];
-            vo = val[(int64_t)a * P + i];
-        }
-        Best in{__builtin_inff(), 0.f, 0.f, 0.f, kNoLeaf};
-        while (wave_any(mask != 0)) {
-            const bool live = mask != 0;
-            const int s = live ? __builtin_ctz(mask) : 0;
-            mask &= mask - 1;
-            const f32x4_alias* row = reinterpret_cast<const f32x4_alias*>(leaf_table + kLeafRow * s);
-            const f32x4 m0 = row[0], m1 = row[1], m2 = row[2], c0 = row[3], c1 = row[4], c2 = row[5], c3 = row[6];
-            const float x = affine_row(m0.x, m0.y, m0.z, m0.w, px, py, pz);  // the leaf loop's statement on the same numbers
-            const float y = affine_row(m1.x, m1.y, m1.z, m1.w, px, py, pz);
-            const float z = affine_row(m2.x, m2.y, m2.z, m2.w, px, py, pz);
-            const float q[3] = {x, y, z};
-            const float fmin[3] = {c0.x, c0.y, c0.z}, inv32[3] = {c1.x, c1.y, c1.z}, err32[3] = {c2.x, c2.y, c2.z};
-            int kk[3];
-            bool shaky = false;
-#pragma unroll
-            for (int d = 0; d < 3; ++d) {  // voxel_flat_estimate's statements on the row's numbers
-                const float t = mul_rn(sub_rn(q[d], fmin[d]), inv32[d]);
-                const float kc = __builtin_rintf(t);
-                shaky |= !(sub_rn(0.5f, fabsf(sub_rn(t, kc))) > err32[d]);
-                kk[d] = (int)kc;
-            }
-            if (__builtin_expect(wave_any(shaky & live), 0)) {
-                if (shaky & live) {  // the reference's own statements (IEEE division in the leaf's index dtype), per-lane reads
-                    const pvamd_grid_t& g = grids[s];
-#pragma unroll 1
-                    for (int d = 0; d < 3; ++d) {
-                        long long kd;
-                        if (g.index_f64) voxel_index_1d<true>(g, d, q[d], kd);
-                        else voxel_index_1d<false>(g, d, q[d], kd);
-                        kk[d] = (int)kd;
-                    }
-                }
-            }
-            const int ny = __float_as_int(c0.w), nz = __float_as_int(c1.w);
-            const unsigned last = __float_as_uint(c2.w);
-            const unsigned flat_u = (unsigned)((kk[0] * ny + kk[1]) * nz + kk[2]);
-            const int flat = (int)(flat_u < last ? flat_u : last);
-            float4 r = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (live) {
-                const uint64_t vox = (uint64_t)__float_as_uint(c3.x) | ((uint64_t)__float_as_uint(c3.y) << 32);
-                r = load_record(reinterpret_cast<const float*>((uintptr_t)vox), flat);
-            }
-            const bool take = live & ((in.tag == kNoLeaf) | (!(r.x >= in.v) & (in.v == in.v)));
-            in.v = take ? r.x : in.v;
-            in.gx = take ? r.y : in.gx;
-            in.gy = take ? r.z : in.gy;
-            in.gz = take ? r.w : in.gz;
-            in.tag = take ? s : in.tag;
-        }
-        if (active) {
-            const int64_t o = (int64_t)a * P + i;
-            const float vi = in.v;
-            const int lo = who == kRecNoLeaf ? kNoLeaf : (int)who;
-            const bool vi_nan = vi != vi, vo_nan = vo != vo;
-            const bool less = (vi_nan & !vo_nan) | (vi < vo);
-            const bool same = (vi == vo) | (vi_nan & vo_nan);
-            if (less | (same & (in.tag < lo))) {
-                const float* M = leaf_table + kLeafRow * in.tag;  // g_obj = R^T g_leaf (rotate_back's statement)
-                val[o] = vi;
-                grad[3 * o] = fmaf(M[8], in.gz, fmaf(M[4], in.gy, mul_rn(M[0], in.gx)));
-                grad[3 * o + 1] = fmaf(M[9], in.gz, fmaf(M[5], in.gy, mul_rn(M[1], in.gx)));
-                grad[3 * o + 2] = fmaf(M[10], in.gz, fmaf(M[6], in.gy, mul_rn(M[2], in.gx)));
-                if (leaf_out) leaf_out[o] = in.tag;
-            }
-        }
-    };
-    // the wave's records first, all loads in flight together (a load -> ballot -> next load loop is one memory round trip per
-    // 64 records: 16 of them in a row per wave)
-    constexpr int kRounds = kInrangePointsPerBlock / kInrangeWaves / 64;
-    uint32_t mine[kRounds];
-#pragma unroll
-    for (int j = 0; j < kRounds; ++j) {
-        const int64_t i = begin + 64 * j + lane;
-        mine[j] = i < end_ ? my_rec[i] : 0u;
-    }
-#pragma unroll
-    for (int j = 0; j < kRounds; ++j) {
-        const int64_t i = begin + 64 * j + lane;
-        const uint32_t r = mine[j];
-        const bool nz = (r & 0xFFFFFFu) != 0;
-        const uint64_t m = __builtin_amdgcn_ballot_w64(nz);
-        if (m != 0) {
-            const int rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0));
-            if (nz) queue[count + rank] = ((uint64_t)i << 32) | r;
-            count += __builtin_popcountll(m);
-            if (count >= 64) drain(64);
-        }
-    }
-    if (count > 0) drain(count);
 }
 
 // The same two minima for ONE point per lane (composed_query_scalar): all leaves, the exact index statements inline.
@@ -786,8 +605,7 @@ __global__ __launch_bounds__(kWavesPerBlock * 64, MODE == kEstimate ? PVAMD_COMP
                                                                            int64_t ntiles, int64_t P,
                                                                            float* __restrict__ val,
                                                                            float* __restrict__ grad,
-                                                                           int* __restrict__ leaf, int a0,
-                                                                           uint32_t* __restrict__ rec = nullptr) {
+                                                                           int* __restrict__ leaf, int a0) {
     __shared__ __attribute__((aligned(16))) float lds[kWavesPerBlock][1024];
     __shared__ float cull[kMaxCullLeaves][8];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -846,10 +664,7 @@ __global__ __launch_bounds__(kWavesPerBlock * 64, MODE == kEstimate ? PVAMD_COMP
         // two copies of the leaf loop only where instructions are what binds (kEstimate: grids that live in L2); the
         // gather-bound kInlineExact build loses more to the larger body than the simpler loop gives (README-size robot,
         // sorted points: 1.00 -> 1.10 ms with both copies)
-        if constexpr (SPLIT == 2) {
-            if (masked) tile_passes_split<PPP, PACKED, true, true>(grids, S, tf, A, a, first, P, val, leaf, spf, lane, todo, lower, rec);
-            else tile_passes_split<PPP, PACKED, false, true>(grids, S, tf, A, a, first, P, val, leaf, spf, lane, todo, lower, rec);
-        } else if constexpr (SPLIT != 0) {
+        if constexpr (SPLIT != 0) {
             if (masked) tile_passes_split<PPP, PACKED, true>(grids, S, tf, A, a, first, P, val, leaf, spf, lane, todo, lower);
             else tile_passes_split<PPP, PACKED, false>(grids, S, tf, A, a, first, P, val, leaf, spf, lane, todo, lower);
         } else {
@@ -1135,27 +950,9 @@ extern "C" int pvamd_composed_query_bucketed(const pvamd_grid_t* grids, int32_t 
     return pvamd_unpack_records(scratch, inv, P, Pp, A, out_val, out_grad, stream);
 }
 
-static int composed_query_impl(const pvamd_grid_t* grids, int32_t S, const float* tf, int32_t A, const float* points, int64_t P,
-                               float* out_val, float* out_grad, int32_t* out_leaf, void* scratch, int64_t scratch_bytes,
-                               int32_t flags, void* stream);
-
 extern "C" int pvamd_composed_query(const pvamd_grid_t* grids, int32_t S, const float* tf, int32_t A,
                                     const float* points, int64_t P, float* out_val, float* out_grad,
                                     int32_t* out_leaf, int32_t flags, void* stream) {
-    return composed_query_impl(grids, S, tf, A, points, P, out_val, out_grad, out_leaf, nullptr, 0, flags, stream);
-}
-
-extern "C" int pvamd_composed_query_scratch(const pvamd_grid_t* grids, int32_t S, const float* tf, int32_t A,
-                                            const float* points, int64_t P, float* out_val, float* out_grad,
-                                            int32_t* out_leaf, void* scratch, int64_t scratch_bytes, int32_t flags,
-                                            void* stream) {
-    if (scratch && !aligned_to(scratch, 4)) return PVAMD_E_ALIGN;
-    return composed_query_impl(grids, S, tf, A, points, P, out_val, out_grad, out_leaf, scratch, scratch_bytes, flags, stream);
-}
-
-static int composed_query_impl(const pvamd_grid_t* grids, int32_t S, const float* tf, int32_t A, const float* points, int64_t P,
-                               float* out_val, float* out_grad, int32_t* out_leaf, void* scratch, int64_t scratch_bytes,
-                               int32_t flags, void* stream) {
     if (S < 1 || A < 1 || P < 0 || S >= kUnnormalised) return PVAMD_E_SHAPE;
     if (P == 0) return 0;
     if (!grids || !tf || !out_val || !out_grad || !points) return PVAMD_E_NULL;
@@ -1184,11 +981,6 @@ static int composed_query_impl(const pvamd_grid_t* grids, int32_t S, const float
     // The configuration is a grid dimension: blockIdx.x (any count) in the wave-tile kernel and in the per-lane kernel's
     // default order; blockIdx.y (<= 65535) in the per-lane kernel's points-fastest order, whose larger batches go out in
     // slabs (the kernels take the slab's first configuration and index transforms / outputs with the global one)
-    // two launches (pvamd_composed_query_scratch): scattered points leave ~10 % of the (configuration, point) pairs with an
-    // in-range leaf; looked up inside the leaf loop they cost 0.21 of C4's 0.69 ms at 1.3 live lanes per visit
-    const bool two_launches = wave_tiles && scratch && scratch_bytes >= (int64_t)A * P * 4 && S <= kDeferredMaxLeaves &&
-                              !(flags & (PVAMD_COMPOSED_INLINE_EXACT | PVAMD_COMPOSED_LEGACY_LEAF_LOOP | PVAMD_COMPOSED_ONE_LAUNCH)) &&
-                              (P + kInrangePointsPerBlock - 1) / kInrangePointsPerBlock <= 65535;
     const bool a_is_y = !wave_tiles && (flags & 8);  // only this order carries the configuration in gridDim.y (<= 65535)
     const int slab = a_is_y ? kConfigSlab : (kConfigSlab < 65535 ? kConfigSlab : A);
     for (int a0 = 0; a0 < A; a0 += slab) {
@@ -1204,15 +996,7 @@ static int composed_query_impl(const pvamd_grid_t* grids, int32_t S, const float
             else if (legacy_leaf_loop(flags, S))
                 hipLaunchKernelGGL((composed_query_wave<PVAMD_COMPOSED_PPP, kEstimate, false, 0>), dim3(An, gy), dim3(kWavesPerBlock * 64), 0, s,
                                    grids, S, tf, A, points, ntiles, P, out_val, out_grad, out_leaf, a0);
-            else if (two_launches) {
-                // first launch: out-of-range answers + one record per (configuration, point); second: the in-range look-ups
-                uint32_t* rec = static_cast<uint32_t*>(scratch);
-                hipLaunchKernelGGL((composed_query_wave<PVAMD_COMPOSED_PPP, kEstimate, false, 2>), dim3(An, gy), dim3(kWavesPerBlock * 64),
-                                   0, s, grids, S, tf, A, points, ntiles, P, out_val, out_grad, out_leaf, a0, rec);
-                const unsigned chunks = (unsigned)((P + kInrangePointsPerBlock - 1) / kInrangePointsPerBlock);
-                hipLaunchKernelGGL(composed_inrange_kernel, dim3(An, chunks), dim3(kInrangeWaves * 64), (size_t)S * kLeafRow * sizeof(float),
-                                   s, grids, S, tf, A, points, P, rec, out_val, out_grad, out_leaf, a0);
-            } else
+            else
                 hipLaunchKernelGGL((composed_query_wave<PVAMD_COMPOSED_PPP, kEstimate, false, 1>), dim3(An, gy), dim3(kWavesPerBlock * 64),
                                    0, s, grids, S, tf, A, points, ntiles, P, out_val, out_grad, out_leaf, a0);
         } else {

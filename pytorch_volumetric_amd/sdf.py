@@ -746,22 +746,6 @@ class ComposedSDF(ObjectFrameSDF):
             self._query_flags = _lib.COMPOSED_INLINE_EXACT if grid_bytes > (4 << 20) else 0
         return self._grids_dev
 
-    two_launches = True  # False: never hand the fused kernel scratch (pvamd_composed_query_scratch degrades to one launch)
-
-    def _scratch_for(self, A, P, dev):
-        """(pointer, bytes) of the per-(configuration, point) record buffer of the two-launch query, or (None, 0) when the call
-        would not use it (include/pvamd.h pvamd_composed_query_scratch: a configuration batch large enough for the wave-tile
-        kernel, L2-resident grids, at most 24 leaves).  The buffer is kept and grows only: query_into stays allocation-free
-        after the first call of a shape."""
-        if not self.two_launches or A < 2 or len(self.sdfs) > 24 or (self._query_flags & _lib.COMPOSED_INLINE_EXACT) or \
-                P < 256 or -(-P // 256) * A < 32768:
-            return None, 0
-        need = A * P
-        buf = self.__dict__.get("_records")
-        if buf is None or buf.numel() < need or buf.device != dev:
-            buf = self._records = torch.empty((need,), dtype=torch.int32, device=dev)
-        return buf.data_ptr(), need * 4
-
     def _tf_device(self, dev):
         if self._tf_dev is None or self._tf_dev.device != dev:
             self._tf_dev = tf.as_matrix(self.obj_frame_to_link_frame).to(device=dev, dtype=torch.float32).contiguous()
@@ -785,7 +769,7 @@ class ComposedSDF(ObjectFrameSDF):
                 with _lib.on_device(dev):
                     grids = self._leaf_grids(dev)
                 if _lib.same_gpu(sdfs[0].device, dev):
-                    plan = (dev, dev.index, grids.data_ptr(), len(sdfs), _lib.load().pvamd_composed_query_scratch, grids)
+                    plan = (dev, dev.index, grids.data_ptr(), len(sdfs), _lib.load().pvamd_composed_query, grids)
         self._plan = (key, plan)
         return plan
 
@@ -816,11 +800,10 @@ class ComposedSDF(ObjectFrameSDF):
                 else:
                     val = torch.empty((P,), dtype=torch.float32, device=dev)
                     grad = torch.empty((P, 3), dtype=torch.float32, device=dev)
-                sptr, sbytes = self._scratch_for(A, P, dev)
                 rc = plan[4](plan[2], plan[3], tfd.data_ptr(), A, p.data_ptr(), P, val.data_ptr(), grad.data_ptr(), None,
-                             sptr, sbytes, flags, _lib.current_raw_stream(plan[1]))
+                             flags, _lib.current_raw_stream(plan[1]))
                 if rc != 0:
-                    _lib.check(rc, "pvamd_composed_query_scratch")
+                    _lib.check(rc, "pvamd_composed_query")
                 return val, grad
         S = len(self.sdfs)
         A = math.prod(self.tsf_batch) if self.tsf_batch is not None else 1
@@ -854,11 +837,9 @@ class ComposedSDF(ObjectFrameSDF):
                                                                  _lib.ptr(val), _lib.ptr(grad), self._query_flags,
                                                                  _lib.stream_ptr()), "pvamd_composed_query_bucketed")
                 else:
-                    sptr, sbytes = self._scratch_for(A, P, dev)
-                    _lib.check(lib.pvamd_composed_query_scratch(_lib.ptr(grids), S, _lib.ptr(self._tf_device(dev)),
-                                                                A, _lib.ptr(flat), P, _lib.ptr(val), _lib.ptr(grad), None,
-                                                                sptr, sbytes, self._query_flags, _lib.stream_ptr()),
-                               "pvamd_composed_query_scratch")
+                    _lib.check(lib.pvamd_composed_query(_lib.ptr(grids), S, _lib.ptr(self._tf_device(dev)),
+                                                        A, _lib.ptr(flat), P, _lib.ptr(val), _lib.ptr(grad), None,
+                                                        self._query_flags, _lib.stream_ptr()), "pvamd_composed_query")
         else:
             val, grad = self._generic(flat, S, A)
         if self.tsf_batch is not None:
@@ -946,17 +927,15 @@ class ComposedSDF(ObjectFrameSDF):
         grad = torch.empty((count, P, 3), dtype=torch.float32, device=dev)
         with _lib.on_device(dev):
             grids = self._leaf_grids(dev)
-            sptr, sbytes = self._scratch_for(count, P, dev)
-            _lib.check(_lib.load().pvamd_composed_query_scratch(_lib.ptr(grids), S, _lib.ptr(sub), count, _lib.ptr(flat), P,
-                                                                _lib.ptr(val), _lib.ptr(grad), None, sptr, sbytes,
-                                                                self._query_flags, _lib.stream_ptr()), "pvamd_composed_query_scratch")
+            _lib.check(_lib.load().pvamd_composed_query(_lib.ptr(grids), S, _lib.ptr(sub), count, _lib.ptr(flat), P,
+                                                        _lib.ptr(val), _lib.ptr(grad), None, self._query_flags,
+                                                        _lib.stream_ptr()), "pvamd_composed_query")
         return val, grad
 
     def query_into(self, points, out_val, out_grad):
         """Allocation-free fused query for inner loops / graph capture: contiguous fp32 (P,3) GPU points, results into
         the caller's fp32 (A,P) / (A,P,3) buffers (A = number of configurations, 1 without a transform batch).  Needs
-        every leaf to be a BOUNDING_BOX CachedSDF.  One C-ABI call, one or two kernel launches on the current stream (a batch
-        large enough for the two-launch scheme keeps its record buffer on this object: allocated at the first call of a shape)."""
+        every leaf to be a BOUNDING_BOX CachedSDF.  One C-ABI call, one kernel launch on the current stream."""
         if not self._fusable():
             raise ValueError("query_into needs every leaf to be a CachedSDF with the BOUNDING_BOX strategy")
         A = math.prod(self.tsf_batch) if self.tsf_batch is not None else 1
@@ -972,12 +951,11 @@ class ComposedSDF(ObjectFrameSDF):
                                   f"{dev} / {out_val.device} / {out_grad.device}")
         with _lib.on_device(dev):
             grids = self._leaf_grids(dev)
-            sptr, sbytes = self._scratch_for(A, P, dev)  # kept between calls: no allocation after the first of a shape
-            _lib.check(_lib.load().pvamd_composed_query_scratch(_lib.ptr(grids), len(self.sdfs),
-                                                                _lib.ptr(self._tf_device(dev)), A, _lib.ptr(points), P,
-                                                                _lib.ptr(out_val), _lib.ptr(out_grad), None, sptr, sbytes,
-                                                                self._query_flags, _lib.stream_ptr()),
-                       "pvamd_composed_query_scratch")
+            _lib.check(_lib.load().pvamd_composed_query(_lib.ptr(grids), len(self.sdfs),
+                                                        _lib.ptr(self._tf_device(dev)), A, _lib.ptr(points), P,
+                                                        _lib.ptr(out_val), _lib.ptr(out_grad), None, self._query_flags,
+                                                        _lib.stream_ptr()),
+                       "pvamd_composed_query")
 
     def _generic(self, flat, S, A):
         """Leaves that are not cached grids (MeshSDF -- the reference's own tests/test_sdf.py:61-80 -- SphereSDF, nested

@@ -14,7 +14,6 @@ from tests import helpers as H
 pytestmark = pytest.mark.gpu
 
 WAVE, LEGACY, PER_LANE, PER_LANE_LEGACY = 4, 4 | 16, 2, 2 | 16
-TWO_LAUNCH = 1 << 20  # test-side marker: call pvamd_composed_query_scratch with a record buffer (wave-tile kernel forced)
 
 
 def make_leaf(f64=True, res=0.01, padding=0.1, flip=False):
@@ -37,14 +36,8 @@ def query_with_leaf_ids(comp, pts, flags):
     val = torch.empty((A, P), dtype=torch.float32, device=dev)
     grad = torch.empty((A, P, 3), dtype=torch.float32, device=dev)
     leaf = torch.full((A, P), -5, dtype=torch.int32, device=dev)
-    if flags & TWO_LAUNCH:  # the scratch entry: out-of-range answers + records, then the in-range look-ups of the whole launch
-        scratch = torch.full((A * P,), 0x5A5A5A5A, dtype=torch.int32, device=dev)
-        _lib.check(_lib.load().pvamd_composed_query_scratch(_lib.ptr(grids), S, _lib.ptr(tfd), A, _lib.ptr(p), P, _lib.ptr(val),
-                                                            _lib.ptr(grad), _lib.ptr(leaf), _lib.ptr(scratch), A * P * 4,
-                                                            flags & ~TWO_LAUNCH, _lib.stream_ptr()), "pvamd_composed_query_scratch")
-    else:
-        _lib.check(_lib.load().pvamd_composed_query(_lib.ptr(grids), S, _lib.ptr(tfd), A, _lib.ptr(p), P, _lib.ptr(val),
-                                                    _lib.ptr(grad), _lib.ptr(leaf), flags, _lib.stream_ptr()), "pvamd_composed_query")
+    _lib.check(_lib.load().pvamd_composed_query(_lib.ptr(grids), S, _lib.ptr(tfd), A, _lib.ptr(p), P, _lib.ptr(val),
+                                                _lib.ptr(grad), _lib.ptr(leaf), flags, _lib.stream_ptr()), "pvamd_composed_query")
     torch.cuda.synchronize()
     return val.cpu().numpy(), grad.cpu().numpy(), leaf.cpu().numpy()
 
@@ -53,10 +46,8 @@ def check_all_kernels(leaves, tfm, A, pts):
     comp = pv.ComposedSDF(leaves, None)
     comp.set_transforms(pv.Transform3d(matrix=tfm), batch_dim=(A,) if A > 1 else None)
     oval, ograd, oleaf = oracle.composed_query([H.oracle_grid_from_cached(l) for l in leaves], tfm.numpy(), A, pts.numpy())
-    for flags in (WAVE, WAVE | TWO_LAUNCH, LEGACY, PER_LANE, PER_LANE_LEGACY):
+    for flags in (WAVE, LEGACY, PER_LANE, PER_LANE_LEGACY):
         if not (flags & 2) and pts.shape[0] < 256:
-            continue
-        if (flags & TWO_LAUNCH) and len(leaves) > 24:
             continue
         val, grad, leaf = query_with_leaf_ids(comp, pts, flags)
         assert np.array_equal(val, oval, equal_nan=True), flags

@@ -106,18 +106,6 @@ def test_composed_query_fuzz(seed):
         val, grad = comp(torch.from_numpy(pts).cuda())
         assert np.array_equal(val.cpu().numpy().reshape(A, -1), oval, equal_nan=True), (flags, bucket)
         assert np.array_equal(grad.cpu().numpy().reshape(A, -1, 3), ograd, equal_nan=True), (flags, bucket)
-    if n >= 256 and S <= 24:  # the two-launch scheme through the scratch entry (wave-tile kernel forced)
-        dev = torch.device("cuda", torch.cuda.current_device())
-        p = torch.from_numpy(pts).cuda()
-        val = torch.empty((A, n), dtype=torch.float32, device=dev)
-        grad = torch.empty((A, n, 3), dtype=torch.float32, device=dev)
-        scratch = torch.empty((A * n,), dtype=torch.int32, device=dev)
-        lib = pv._lib.load()
-        pv._lib.check(lib.pvamd_composed_query_scratch(pv._lib.ptr(comp._leaf_grids(dev)), S, pv._lib.ptr(comp._tf_device(dev)), A,
-                                                       pv._lib.ptr(p), n, pv._lib.ptr(val), pv._lib.ptr(grad), None, pv._lib.ptr(scratch),
-                                                       A * n * 4, 4, pv._lib.stream_ptr()), "pvamd_composed_query_scratch")
-        assert np.array_equal(val.cpu().numpy(), oval, equal_nan=True), "two launches"
-        assert np.array_equal(grad.cpu().numpy(), ograd, equal_nan=True), "two launches"
 
 
 def random_mesh(rng):

@@ -10,7 +10,7 @@ import pytorch_volumetric_amd as pv
 from pytorch_volumetric_amd import _lib
 from bench_configs import gpu_time
 
-VARIANTS = ((0, "auto"), (4, "wave-tile two launches"), (4 | 32, "wave-tile one launch"), (4 | 16, "wave-tile round-3 loop"), (2, "per-lane split-minima"), (2 | 16, "per-lane round-3 loop"))
+VARIANTS = ((0, "auto"), (4, "wave-tile split-minima"), (4 | 16, "wave-tile round-3 loop"), (2, "per-lane split-minima"), (2 | 16, "per-lane round-3 loop"))
 
 
 def run(name, sdf, pts, A, variants=VARIANTS):
