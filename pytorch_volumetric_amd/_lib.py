@@ -11,7 +11,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("PVAMD_LIB") or os.path.join(_HERE, "csrc", "libpvamd.so")  # PVAMD_LIB: A/B builds (tools/)
 
-ABI_VERSION = 8
+ABI_VERSION = 9
 OOB_LOOKUP_GT_SDF = 0
 OOB_BOUNDING_BOX = 1
 COMPOSED_INLINE_EXACT = 1
@@ -37,9 +37,15 @@ def tiles_floats(F):
 MESH_SCRATCH_GROUPS = 2048
 
 
+def mesh_scratch_slots(P):
+    """PVAMD_MESH_SCRATCH_SLOTS(P)"""
+    groups = (P + 63) // 64
+    return groups if groups < MESH_SCRATCH_GROUPS else max(groups // 8, MESH_SCRATCH_GROUPS)
+
+
 def mesh_scratch_bytes(P):
     """PVAMD_MESH_SCRATCH_BYTES(P)"""
-    return 64 + min((P + 63) // 64, MESH_SCRATCH_GROUPS) * (64 * 28 + 8)
+    return 64 + mesh_scratch_slots(P) * (64 * 28 + 8)
 
 
 _c_float_p = ctypes.POINTER(ctypes.c_float)
@@ -302,10 +308,10 @@ def morton_order_scratch_words(P):
 
 
 def morton_order(points, min_points=2048, want_inverse=False, want_sorted=False):
-    """int32 permutation that walks fp32 [P,3] device points along a Z-order curve (None below `min_points`, where
+    """int32 permutation that walks fp32 [P,3] device points along a Hilbert curve (None below `min_points`, where
     ordering costs more than it saves).  Spatially coherent waves are what lets the mesh kernels skip far tiles and the
-    bucketed composed kernel skip far leaves.  One C-ABI call (pvamd_morton_order: a seven-launch counting sort on Morton
-    cells); nothing comes back to the host.  With want_inverse / want_sorted: (order, inverse, sorted points)."""
+    bucketed composed kernel skip far leaves.  One C-ABI call (pvamd_morton_order -- the name is older than the curve: a
+    seven-launch counting sort on the cells of the curve); nothing comes back to the host.  With want_inverse / want_sorted: (order, inverse, sorted points)."""
     P = points.shape[0]
     if P < min_points or P == 0:
         return (None, None, None) if (want_inverse or want_sorted) else None

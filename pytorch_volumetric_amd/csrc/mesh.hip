@@ -228,15 +228,22 @@ PVAMD_DEV bool rect_may_improve(const LaneState& s, V3 w, float dist2, V3 fu, fl
 }
 
 #ifdef PVAMD_MESH_STATS
-__device__ unsigned long long g_stats[16];
+__device__ unsigned long long g_stats[32];
+__device__ long long g_nested;  // unused
 #define STAT(i, v) do { if ((threadIdx.x & 63) == 0) atomicAdd(&g_stats[i], (unsigned long long)(v)); } while (0)
 extern "C" int pvamd_debug_stats(unsigned long long* out, int reset) {
     (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_stats), sizeof(g_stats));
-    if (reset) { unsigned long long z[16] = {}; (void)hipMemcpyToSymbol(HIP_SYMBOL(g_stats), z, sizeof(z)); }
+    if (reset) { unsigned long long z[32] = {}; (void)hipMemcpyToSymbol(HIP_SYMBOL(g_stats), z, sizeof(z)); }
     return 0;
 }
+#define TIC(t) const long long t = __builtin_readcyclecounter()
+#define TOC(i, t) STAT(i, __builtin_readcyclecounter() - t)
+#define TOC_NET(i, t, inner) STAT(i, __builtin_readcyclecounter() - t - (inner))
 #else
 #define STAT(i, v)
+#define TIC(t)
+#define TOC(i, t)
+#define TOC_NET(i, t, inner)
 #endif
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -402,6 +409,7 @@ template <bool WITH_RAY>
 PVAMD_DEV void drain_closest(const MeshArgs& m, GroupShared<WITH_RAY>& g, WaveLocal<WITH_RAY>& wl, Wave<WITH_RAY>& wv, bool everything) {
     if (wv.nc == 0) return;
     const int lane = threadIdx.x & 63;
+    TIC(t_drain);
     drain(wl.qc, wv.nc, everything, [&](int count, const unsigned* q) {
         const unsigned e = lane < count ? q[lane] : 0u;
         const int owner = e & 63;
@@ -415,6 +423,7 @@ PVAMD_DEV void drain_closest(const MeshArgs& m, GroupShared<WITH_RAY>& g, WaveLo
         }
     });
     pull_reach(g, wv);
+    TOC(16, t_drain);
 }
 
 template <bool WITH_RAY>
@@ -442,6 +451,7 @@ PVAMD_DEV void visit_tile(const MeshArgs& m, GroupShared<WITH_RAY>& g, WaveLocal
     const int ntiles = (m.F + kTile - 1) / kTile;
     const int n = min(kTile, m.F - ti * kTile);
     STAT(1, 1);
+    TIC(t_visit);
     unsigned gm = 0u;
     {
         // lanes = groups: the 16 group spheres at (c, Q) ...
@@ -498,6 +508,7 @@ PVAMD_DEV void visit_tile(const MeshArgs& m, GroupShared<WITH_RAY>& g, WaveLocal
         wl.m0[lane] = am0;
         PVAMD_WAVE_SYNC();
         const int j0 = ti * kTile + pass * 64;
+        TIC(t_surv);
         while (todo != 0ull) {
             const int b = __builtin_ctzll(todo);
             todo &= todo - 1ull;
@@ -529,7 +540,9 @@ PVAMD_DEV void visit_tile(const MeshArgs& m, GroupShared<WITH_RAY>& g, WaveLocal
                 }
             }
         }
+        TOC(18, t_surv);
     }
+    TOC(17, t_visit);
 }
 
 // Upper bound on every live lane's distance to the mesh from the tile spheres (each contains whole triangles):
@@ -568,7 +581,7 @@ PVAMD_DEV int scan_seed(const MeshArgs& m, Wave<WITH_RAY>& wv, int part, int npa
 // with the smallest |p - ctr| + r (each sphere contains whole triangles, so each is an upper bound of the lane's distance
 // to the mesh).  The first visit then queues pairs against a bound a few millimetres wide instead of a tile radius.
 template <bool WITH_RAY>
-PVAMD_DEV void greedy_reach(const MeshArgs& m, Wave<WITH_RAY>& wv, int ti) {
+PVAMD_DEV void greedy_reach(const MeshArgs& m, GroupShared<WITH_RAY>& g, Wave<WITH_RAY>& wv, int ti) {
     const int ntiles = (m.F + kTile - 1) / kTile;
     const f32x4* spheres = reinterpret_cast<const f32x4*>(m.tiles);
     const V3 p = wv.s.p;
@@ -584,12 +597,29 @@ PVAMD_DEV void greedy_reach(const MeshArgs& m, Wave<WITH_RAY>& wv, int ti) {
         if (b < bound) { bound = b; gi = k; }
     }
     const int j0 = ti * kTile + gi * kGroup;  // per lane
+    float nearest = INFINITY;
+    int jn = -1;
     for (int k = 0; k < kGroup; ++k) {
-        if (j0 + k < m.F) bound = fminf(bound, reach_of(record_plane(m.rec, j0 + k, kPlaneSphere)));
+        if (j0 + k < m.F) {
+            const float b = reach_of(record_plane(m.rec, j0 + k, kPlaneSphere));
+            if (b < nearest) { nearest = b; jn = j0 + k; }
+        }
     }
-    bound *= 1.00001f;
+#ifndef PVAMD_MESH_NO_GREEDY_EXACT
+    // ... and the exact distance to that record's triangle, all 64 lanes at once (what a drain does for 64 queued pairs):
+    // the bound drops from "the far side of the nearest record's sphere" to a real distance before anything is queued
+    // against it, and the pair is a candidate like any other (same operations as in the drain: same bits).
+    if (jn >= 0 && wv.live) {
+        const f32x4 A = record_plane(m.rec, jn, kPlaneA), B = record_plane(m.rec, jn, kPlaneB), C = record_plane(m.rec, jn, kPlaneC);
+        const V3 qp = sub(closest_point_triangle(p, xyz(A), xyz(B), xyz(C)), p);
+        const float d2 = dot(qp, qp);
+        atomicMin(&g.best[threadIdx.x & 63], ((unsigned long long)(unsigned)__float_as_int(d2) << 32) | (unsigned)__float_as_int(A.w));
+        STAT(4, 1);
+    }
+#endif
+    bound = fminf(bound, nearest) * 1.00001f;
     if (bound < wv.s.reach) set_reach(wv.s, bound);  // a NaN point: never
-    refresh_bound(wv);
+    pull_reach(g, wv);
 }
 
 // the tiles ti with ti % nparts == part, `skip` excepted (it was visited before), flagged 64 at a time
@@ -700,23 +730,24 @@ static __host__ __device__ inline HandOver hand_over(void* scratch, int cap) {
     h.cap = scratch ? cap : 0;
     return h;
 }
-#ifndef PVAMD_MESH_HEAVY_EIGHTHS
-#define PVAMD_MESH_HEAVY_EIGHTHS 3
+#ifndef PVAMD_MESH_HEAVY_32NDS
+#define PVAMD_MESH_HEAVY_32NDS 6
 #endif
 #ifndef PVAMD_MESH_HEAVY_PARTS
 #define PVAMD_MESH_HEAVY_PARTS 32
 #endif
-// heavy = still flags this many eighths of the tiles (of at least kHeavyMinTiles) once its reaches are about final.  C5
-// (389 tiles, 32,768 groups), groups listed / ms with 4 waves per group in the main launch: 2/8 1671 / 3.91, 3/8 703 / 3.71,
-// 4/8 384 / 3.80, 5/8 238 / 3.99 (64 instead of 32 parts: +0.04); with 8 waves per group 5.2-5.5 whatever the threshold;
-// nothing handed over: 5.9 (8 waves)
-constexpr int kHeavyEighths = PVAMD_MESH_HEAVY_EIGHTHS;
+// heavy = still flags this many 32nds of the tiles (of at least kHeavyMinTiles) once its reaches are about final.  C5
+// (389 tiles, 32,768 groups), round 4 (triangles in patches, points along the Hilbert curve, exact greedy bound), whole
+// call / groups listed with 2 waves per group in the main launch: 4/32 3.24 ms / 1782, 5/32 3.20 / 1000, 6/32 3.17 / 745,
+// 7/32 3.18 / 569, 8/32 3.47 / 470, 10/32 3.47 / 301; with 4 waves per group 8/32 3.55, 12/32 3.77, 16/32 3.96 (64 instead
+// of 32 parts: -0.05 with 4 waves, +0.1 with 2); nothing handed over: 5.15 (8 waves).  (Round 3, Z-order: 12/32 and 4
+// waves, 3.71.)
+constexpr int kHeavy32nds = PVAMD_MESH_HEAVY_32NDS;
 #ifndef PVAMD_MESH_HEAVY_MIN_TILES
 #define PVAMD_MESH_HEAVY_MIN_TILES 128
 #endif
 constexpr int kHeavyMinTiles = PVAMD_MESH_HEAVY_MIN_TILES;
 constexpr int kHeavyParts = PVAMD_MESH_HEAVY_PARTS;
-constexpr int kHandOverCap = PVAMD_MESH_SCRATCH_GROUPS;
 
 // tiles some lane may still need, counted with lanes = tiles at (c, Q)
 template <bool WITH_RAY>
@@ -744,12 +775,15 @@ PVAMD_DEV bool scan_mesh(const MeshArgs& m, MeshShared<SLICES, WITH_RAY>& sh, Wa
                          int64_t jitter_index, const HandOver& ho, int group, int transform) {
     const int lane = threadIdx.x & 63;
     bool handed = false;
+    TIC(t_all);
     if (scan_begin(m, sh.g, wv, wave, seed, jitter_index, nullptr) && m.F > 0) {
+        TIC(t_seed);
         const int first = scan_seed(m, wv, wave, SLICES);
         if (first >= 0) {
 #ifndef PVAMD_MESH_NO_GREEDY
-            greedy_reach(m, wv, first);
+            greedy_reach(m, sh.g, wv, first);
 #endif
+            TOC(20, t_seed);
             visit_tile<WITH_RAY>(m, sh.g, sh.w[wave], wv, first);
             drain_closest(m, sh.g, sh.w[wave], wv, true);  // publish what the nearest tile gave before looking further
         }
@@ -758,7 +792,7 @@ PVAMD_DEV bool scan_mesh(const MeshArgs& m, MeshShared<SLICES, WITH_RAY>& sh, Wa
             if (wave == 0) {
                 pull_reach(sh.g, wv);
                 int slot = -1;
-                if (flagged_tiles(m, wv) * 8 >= ((m.F + kTile - 1) / kTile) * kHeavyEighths) {
+                if (flagged_tiles(m, wv) * 32 >= ((m.F + kTile - 1) / kTile) * kHeavy32nds) {
                     if (lane == 0) slot = atomicAdd(ho.count, 1);
                     slot = __builtin_amdgcn_readfirstlane(slot);
                     if (slot >= ho.cap) slot = -1;  // list full: this block does the work itself
@@ -785,6 +819,7 @@ PVAMD_DEV bool scan_mesh(const MeshArgs& m, MeshShared<SLICES, WITH_RAY>& sh, Wa
             scan_finish(m, sh.g, sh.w[wave], wv);
         }
     }
+    TOC(19, t_all);
     __syncthreads();
     return handed;
 }
@@ -923,7 +958,6 @@ __global__ __launch_bounds__(128) void hand_over_all_kernel(MeshArgs m, const in
     const int64_t slot = (int64_t)g * 64 + lane;
     const int64_t i = point_index(order, slot, P);
     if (threadIdx.x < 64) {
-        ho.best[slot] = kBestInit;
         ho.hits[slot] = 0;
         const V3 dir = jitter_dir(m.ray_dir, seed, index_base + i);
         float* o = ho.dir + slot * 3;
@@ -939,6 +973,7 @@ __global__ __launch_bounds__(128) void hand_over_all_kernel(MeshArgs m, const in
     // |p - ctr| + r (every sphere contains whole triangles).  The blocks of the parts launch cannot hand each other their
     // finds, so each would otherwise start from the tile-sphere bound (a tile radius too wide) and queue 3x the pairs.
     float bound = INFINITY;
+    unsigned long long found = kBestInit;
     if (m.F > 0) {
         const V3 p = v3(pts[3 * i], pts[3 * i + 1], pts[3 * i + 2]);
         const int ntiles = (m.F + kTile - 1) / kTile;
@@ -960,11 +995,28 @@ __global__ __launch_bounds__(128) void hand_over_all_kernel(MeshArgs m, const in
             if (b < bound) { bound = b; gi = k; }
         }
         const int j0 = ti * kTile + gi * kGroup;
+        float nearest = INFINITY;
+        int jn = -1;
         for (int k = 0; k < kGroup; ++k) {
             if (j0 + k >= m.F) break;
-            bound = fminf(bound, reach_of(record_plane(m.rec, j0 + k, kPlaneSphere)));
+            const float b = reach_of(record_plane(m.rec, j0 + k, kPlaneSphere));
+            if (b < nearest) { nearest = b; jn = j0 + k; }
         }
+        bound = fminf(bound, nearest);
+#ifndef PVAMD_MESH_NO_GREEDY_EXACT
+        // the exact distance to that record's triangle: a candidate like any other (the slots start from it), and a bound
+        // that is a real distance instead of the far side of a sphere
+        if (jn >= 0 && fabsf(p.x) < INFINITY && fabsf(p.y) < INFINITY && fabsf(p.z) < INFINITY) {
+            const f32x4 A = record_plane(m.rec, jn, kPlaneA), B = record_plane(m.rec, jn, kPlaneB), C = record_plane(m.rec, jn, kPlaneC);
+            const V3 qp = sub(closest_point_triangle(p, xyz(A), xyz(B), xyz(C)), p);
+            const float d2 = dot(qp, qp);
+            found = ((unsigned long long)(unsigned)__float_as_int(d2) << 32) | (unsigned)__float_as_int(A.w);
+            if (!(found < kBestInit)) found = kBestInit;  // a NaN d2
+            else bound = fminf(bound, fast_sqrt(d2) * 1.00001f + 1.1e-19f);
+        }
+#endif
     }
+    ho.best[slot] = found;
     ho.reach[slot] = bound * 1.00001f;  // a NaN / inf point: never a finite bound
 }
 __global__ void hand_over_none_kernel(HandOver ho) { *ho.count = 0; }
@@ -983,6 +1035,7 @@ PVAMD_DEV void parts_of_group(const MeshArgs& m, MeshShared<kTile / 64, WITH_RAY
     Wave<WITH_RAY> wv;
     wv.s.p = M ? chamfer_point(M, pts, i) : v3(pts[3 * i], pts[3 * i + 1], pts[3 * i + 2]);
     const unsigned long long start = ho.best[(int64_t)slot * 64 + lane];
+    TIC(t_parts);
     if (scan_begin(m, sh.g, wv, wave, seed, index_base + i, &start, WITH_RAY ? ho.dir + (int64_t)slot * 192 : nullptr)) {
         scan_seed(m, wv, 0, 1);  // the bound from the tile spheres (the slot's own finds are pulled in scan_tiles) ...
         const float known = ho.reach[(int64_t)slot * 64 + lane];  // ... and the one worked out when the group was listed
@@ -991,6 +1044,7 @@ PVAMD_DEV void parts_of_group(const MeshArgs& m, MeshShared<kTile / 64, WITH_RAY
         scan_tiles<WITH_RAY>(m, sh.g, sh.w[wave], wv, -1, (int)blockIdx.y, (int)gridDim.y, wave, wave + 1);
         scan_finish(m, sh.g, sh.w[wave], wv);
     }
+    TOC(21, t_parts);
     __syncthreads();
     if (wave == 0) {
         if (sh.g.best[lane] < start) atomicMin(&ho.best[(int64_t)slot * 64 + lane], sh.g.best[lane]);
@@ -1150,12 +1204,13 @@ constexpr int kMinParts = PVAMD_MESH_MIN_PARTS;     // below this the single lau
 //                            4, 0.79 with 2);
 //   many tiles            -> the work per group is heavy-tailed (a point near the medial axis is equidistant to much of
 //                            the surface and needs most tiles) and the slowest groups set the kernel time: 8 when nothing
-//                            can be handed over (C5, 389 tiles: 5.9 ms with 8, 7.5 with 4, 11 with 2), 4 when the heavy
-//                            groups go to a launch of their own (5.2 ms with 8, 4.0 with 4, 4.7 with 2).
+//                            can be handed over (C5, 389 tiles: 5.2 ms with 8, 11.5 with 2); when the heavy groups go
+//                            to a launch of their own the tail is gone and the count of groups decides as above (C5:
+//                            3.17 ms with 2, 3.55 with 4).
 static int pick_slices(int64_t groups, int mesh_tiles, bool hand_over) {
     int s = 2;
     while (s < 8 && (int64_t)s * groups < 16384) s <<= 1;
-    if (mesh_tiles > 128) s = hand_over ? 4 : 8;
+    if (mesh_tiles > 128 && !hand_over) s = 8;
     if (s > PVAMD_MESH_MAX_SLICES) s = PVAMD_MESH_MAX_SLICES;
     while (s > 1 && s > mesh_tiles) s >>= 1;
     return s;
@@ -1224,7 +1279,7 @@ extern "C" int pvamd_mesh_query(const pvamd_mesh_t* mesh, const float* points, c
     const QueryOut out{out_closest, out_dist, out_grad, out_face, out_normal};
     const int ntiles = (mesh->F + kTile - 1) / kTile;
     
-    const int cap = (int)(groups < kHandOverCap ? groups : kHandOverCap);  // what PVAMD_MESH_SCRATCH_BYTES(P) holds
+    const int cap = (int)PVAMD_MESH_SCRATCH_SLOTS(P);  // what PVAMD_MESH_SCRATCH_BYTES(P) holds
     const HandOver ho = hand_over(scratch, cap);
     const int slices = pick_slices(groups, ntiles, ho.cap > 0 && ntiles >= kHeavyMinTiles);
     // few point groups, many tiles: spread each group's tiles over `parts` blocks of four waves, one per 64-record pass
@@ -1278,7 +1333,7 @@ static int launch_chamfer_mesh(const pvamd_mesh_t* mesh, const float* W, int32_t
     const int64_t groups = (N + 63) / 64;
     if (groups > 0x7fffffff) return PVAMD_E_SHAPE;
     const int ntiles = (mesh->F + kTile - 1) / kTile;
-    const int cap = (int)(groups < kHandOverCap ? groups : kHandOverCap);
+    const int cap = (int)PVAMD_MESH_SCRATCH_SLOTS(N);
     const HandOver ho = hand_over(ntiles >= kHeavyMinTiles ? scratch : nullptr, cap);
     const int32_t ny = W ? B : 1;
     const int slices = pick_slices(groups * (int64_t)ny, ntiles, ho.cap > 0);

@@ -12,6 +12,12 @@
 #include "common.h"
 #include "morton.h"
 
+#ifdef PVAMD_ORDER_MORTON
+#define PVAMD_ORDER_KEY(x, y, z, lo, hi, b) morton_key30(x, y, z, lo, hi)
+#else
+#define PVAMD_ORDER_KEY(x, y, z, lo, hi, b) hilbert_key30(x, y, z, lo, hi, b)
+#endif
+
 namespace pvamd {
 
 // scratch layout (uint32 words): [0..5] bounds codes, [8 .. 8 + cells) cell counters / offsets, then P keys, then
@@ -70,7 +76,7 @@ __global__ __launch_bounds__(256) void order_count_kernel(const float* __restric
         lo[d] = order_decode(scratch[d]);
         hi[d] = order_decode(scratch[3 + d]);
     }
-    const unsigned key = morton_key30(pts[3 * i], pts[3 * i + 1], pts[3 * i + 2], lo, hi);
+    const unsigned key = PVAMD_ORDER_KEY(pts[3 * i], pts[3 * i + 1], pts[3 * i + 2], lo, hi, (30 - shift) / 3);
     const unsigned cells = 1u << (30 - shift);
     scratch[kBoxWords + cells + i] = key;
     atomicAdd(scratch + kBoxWords + (key >> shift), 1u);
@@ -191,7 +197,7 @@ __global__ __launch_bounds__(1024) void order_small_kernel(const float* __restri
     __syncthreads();
     const float blo[3] = {box[0], box[1], box[2]}, bhi[3] = {box[3], box[4], box[5]};
     for (int i = t; i < P; i += 1024)
-        atomicAdd(&hist[morton_key30(pts[3 * i], pts[3 * i + 1], pts[3 * i + 2], blo, bhi) >> kSmallShift], 1u);
+        atomicAdd(&hist[PVAMD_ORDER_KEY(pts[3 * i], pts[3 * i + 1], pts[3 * i + 2], blo, bhi, (30 - kSmallShift) / 3) >> kSmallShift], 1u);
     __syncthreads();
     unsigned c4[4], sum = 0;
 #pragma unroll
@@ -210,7 +216,7 @@ __global__ __launch_bounds__(1024) void order_small_kernel(const float* __restri
     __syncthreads();
     for (int i = t; i < P; i += 1024) {
         const float x = pts[3 * i], y = pts[3 * i + 1], z = pts[3 * i + 2];
-        const unsigned slot = atomicAdd(&hist[morton_key30(x, y, z, blo, bhi) >> kSmallShift], 1u);
+        const unsigned slot = atomicAdd(&hist[PVAMD_ORDER_KEY(x, y, z, blo, bhi, (30 - kSmallShift) / 3) >> kSmallShift], 1u);
         order[slot] = i;
         if (inv) inv[i] = (int)slot;
         if (sorted_pts) {

@@ -117,13 +117,13 @@ class ObjectFactory(abc.ABC):
 
     # ---- device state ----
     def _mesh_desc(self):
-        """Upload + prepare the mesh once per device: triangles in Morton order of their centroids (what makes the
-        kernels' tile spheres tight), per-triangle records, tile spheres, face-id map."""
+        """Upload + prepare the mesh once per device: triangles in compact patches of 16 / 256 (mesh_io.patch_order: what makes
+        the kernels' group and tile spheres tight), per-triangle records, tile spheres, face-id map."""
         dev = _lib.require_gpu()
         if self._tri_dev is None or self._tri_dev.device != dev:
             lib = _lib.load()
             soup = self._mesh.triangle_soup().astype(np.float32)  # the scene stores float32 vertices
-            order = mesh_io.morton_order(soup.mean(axis=1))
+            order = mesh_io.patch_order(soup.mean(axis=1))
             F = soup.shape[0]
             self._tri_dev = torch.from_numpy(np.ascontiguousarray(soup[order])).to(dev)
             face_id = torch.from_numpy(order.astype(np.int32)).to(dev)

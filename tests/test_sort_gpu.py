@@ -11,35 +11,67 @@ from tests import helpers as H
 pytestmark = pytest.mark.gpu
 
 
-def coarse_cells(pts, bits):
-    """Host restatement of the cell a point falls in: the leading `bits` bits of the 30-bit Morton key over the bounds of
-    the finite coordinates (csrc/morton.h)."""
+def curve_cells(pts, bits):
+    """Host restatement of the cell a point falls in and of its position along the Hilbert curve (csrc/morton.h
+    hilbert_key30: 2^(bits/3) cells per axis over the bounds of the finite coordinates, Skilling's transform)."""
+    b = bits // 3
     p = pts.astype(np.float32)
     fin = np.where(np.isfinite(p), p, np.nan)
     lo, hi = np.nanmin(fin, axis=0).astype(np.float32), np.nanmax(fin, axis=0).astype(np.float32)
     span = np.maximum((hi - lo).astype(np.float32), np.float32(1e-30))
+    top = np.float32((1 << b) - 1)
     with np.errstate(invalid="ignore"):
-        t = ((p - lo) / span * np.float32(1023.0)).astype(np.float32)
-    t = np.where(np.isnan(t), 0.0, np.clip(t, 0.0, 1023.0))
-    c = t.astype(np.uint32)
-    key = np.zeros(len(p), dtype=np.uint64)
-    for b in range(10):
+        t = (((p - lo) / span).astype(np.float32) * np.float32(top + np.float32(0.999))).astype(np.float32)
+    t = np.where(np.isnan(t), 0.0, np.clip(t, 0.0, top))
+    X = [t[:, d].astype(np.int64) for d in range(3)]
+    Q = 1 << (b - 1)
+    while Q > 1:
+        P = Q - 1
         for d in range(3):
-            key |= ((c[:, d].astype(np.uint64) >> b) & 1) << (3 * b + d)
-    return key >> (30 - bits)
+            hit = (X[d] & Q) != 0
+            t_ = np.where(hit, 0, (X[0] ^ X[d]) & P)
+            X[0] = np.where(hit, X[0] ^ P, X[0] ^ t_)
+            if d:
+                X[d] = X[d] ^ t_
+        Q >>= 1
+    X[1] ^= X[0]
+    X[2] ^= X[1]
+    g = np.zeros_like(X[0])
+    Q = 1 << (b - 1)
+    while Q > 1:
+        g = np.where((X[2] & Q) != 0, g ^ (Q - 1), g)
+        Q >>= 1
+    key = np.zeros(len(p), dtype=np.int64)
+    for k in range(b):
+        for d in range(3):
+            key |= (((X[d] ^ g) >> k) & 1) << (3 * k + (2 - d))
+    return key
 
 
 @pytest.mark.parametrize("P", [1, 5, 300, 10_000, 16_384, 16_385, 65_535, 65_536, 262_144, (1 << 20) + 77])
-def test_order_is_a_permutation_that_walks_the_cells_in_z_order(P):
+def test_order_is_a_permutation_that_walks_the_cells_along_the_hilbert_curve(P):
     pts = H.uniform_points(P, [-0.7, -0.7, -0.2], [0.7, 0.7, 1.5], seed=P).cuda()
     order, inv, spts = _lib.morton_order(pts, min_points=0, want_inverse=True, want_sorted=True)
     o = order.cpu().numpy()
     assert np.array_equal(np.sort(o), np.arange(P))
     assert np.array_equal(inv.cpu().numpy()[o], np.arange(P))
     assert torch.equal(spts, pts[order.long()])
-    cells = coarse_cells(pts.cpu().numpy(), 21 if P >= (1 << 20) else (18 if P >= (1 << 16) else (15 if P > 16384 else 12)))
+    cells = curve_cells(pts.cpu().numpy(), 21 if P >= (1 << 20) else (18 if P >= (1 << 16) else (15 if P > 16384 else 12)))
     walked = cells[o]
-    assert (np.diff(walked.astype(np.int64)) >= 0).all()  # cells in Z order; inside a cell any order
+    assert (np.diff(walked) >= 0).all()  # cells in curve order; inside a cell any order
+
+
+def test_a_full_grid_is_walked_cell_to_face_neighbour():
+    """One point per cell of a 32^3 grid: consecutive points of the order are face neighbours (the property the Z curve
+    lacks and the 64-point groups of the mesh kernels are tighter for)."""
+    n = 32
+    idx = torch.stack(torch.meshgrid(*[torch.arange(n)] * 3, indexing="ij"), dim=-1).reshape(-1, 3).float()
+    pts = ((idx + 0.5) / n)
+    pts = torch.cat((pts, torch.tensor([[0.0, 0.0, 0.0], [1.0, 1.0, 1.0]])))  # pin the bounds to the grid's box
+    order = _lib.morton_order(pts.cuda(), min_points=0).cpu().numpy()
+    walked = order[order < n ** 3]
+    steps = np.abs(np.diff(idx.numpy()[walked], axis=0)).sum(axis=1)
+    assert (steps == 1).all()
 
 
 def test_non_finite_points_are_placed_somewhere_and_nothing_else_moves():
@@ -58,7 +90,7 @@ def test_degenerate_clouds():
     line[:, 0] = torch.linspace(0, 1, 4096)
     o = _lib.morton_order(line.cuda(), min_points=0).cpu().numpy()
     assert np.array_equal(np.sort(o), np.arange(4096))
-    assert (np.diff(line[o, 0].numpy()) >= -1.0 / 15).all()  # monotone up to the cell size (16 cells per axis here)
+    assert np.abs(np.diff(line[o, 0].numpy())).mean() < 2.0 / 15  # neighbours stay neighbours (16 cells per axis here)
 
 
 def test_mesh_query_bits_do_not_depend_on_the_processing_order():

@@ -14,7 +14,7 @@ lib = _lib.load()
 
 
 def stats():
-    buf = (ctypes.c_ulonglong * 16)()
+    buf = (ctypes.c_ulonglong * 32)()
     torch.cuda.synchronize()
     lib.pvamd_debug_stats(buf, 1)
     return list(buf)

@@ -12,11 +12,13 @@ import workloads as H
 lib = _lib.load()
 NAMES = ["tile_passes (64 tile spheres each)", "tiles_visited", "record_passes (64 records at (c,Q))",
          "survivors (tested per point)", "closest_pairs", "ray_pairs", "drains", "survivors_any_near (rect per point)",
-         "enqueues"]
+         "enqueues", "group tests per point", "-", "-", "-", "-", "-", "-", "cycles in drain_closest", "cycles in visit_tile (all)",
+         "cycles in survivor loops (incl. their drains)", "cycles in scan_mesh (main launch)", "cycles in seed + greedy",
+         "cycles in parts_of_group"]
 
 
 def stats(reset=True):
-    buf = (ctypes.c_ulonglong * 16)()
+    buf = (ctypes.c_ulonglong * 32)()
     torch.cuda.synchronize()
     lib.pvamd_debug_stats(buf, 1 if reset else 0)
     return list(buf)
