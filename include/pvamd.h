@@ -305,12 +305,12 @@ int pvamd_morton_order(const float* points, int64_t P, int32_t* order_out, int32
  * are spread over several workgroups where one group's serial walk would set the time -- every group of a query of few
  * points, and the heavy groups of a large one (points about equidistant to much of a mesh of >= 128 tiles) -- in three
  * launches that meet in scratch; results are the same bits either way.  Contents on return are unspecified.      */
-#define PVAMD_MESH_SCRATCH_GROUPS 2048  /* point groups (of 64) a scratch buffer has slots for: every group up to this many, ... */
-/* ... then 2048 or an eighth of the groups, whichever is more (C5: 2.3 % of the groups are handed over; one that finds the
+#define PVAMD_MESH_SCRATCH_GROUPS 8192  /* point groups (of 64) a scratch buffer has slots for: every group up to this many, ... */
+/* ... then 8192 or an eighth of the groups, whichever is more (C5: 2.3 % of the groups are handed over; one that finds the
  * list full walks the mesh on its own two waves, 4x slower than the rest put together when that happens to thousands) */
 #define PVAMD_MESH_SCRATCH_SLOTS(P) ((((P) + 63) / 64) < PVAMD_MESH_SCRATCH_GROUPS ? (((P) + 63) / 64) : \
                                      ((((P) + 63) / 64) / 8 > PVAMD_MESH_SCRATCH_GROUPS ? (((P) + 63) / 64) / 8 : PVAMD_MESH_SCRATCH_GROUPS))
-#define PVAMD_MESH_SCRATCH_BYTES(P) (64 + PVAMD_MESH_SCRATCH_SLOTS(P) * (int64_t)(64 * 28 + 8))
+#define PVAMD_MESH_SCRATCH_BYTES(P) (64 + PVAMD_MESH_SCRATCH_SLOTS(P) * (int64_t)(64 * 40 + 8 + 64))
 int pvamd_mesh_query(const pvamd_mesh_t* mesh, const float* points, const int32_t* order, int64_t P,
                      uint64_t jitter_seed, int64_t index_base, float* out_closest, float* out_dist, float* out_grad, int32_t* out_face,
                      float* out_normal, void* scratch, void* stream);

@@ -34,7 +34,7 @@ def tiles_floats(F):
     return ((F + TRI_TILE - 1) // TRI_TILE) * (4 + 4 * (TRI_TILE // TRI_GROUP))
 
 
-MESH_SCRATCH_GROUPS = 2048
+MESH_SCRATCH_GROUPS = 8192
 
 
 def mesh_scratch_slots(P):
@@ -45,7 +45,7 @@ def mesh_scratch_slots(P):
 
 def mesh_scratch_bytes(P):
     """PVAMD_MESH_SCRATCH_BYTES(P)"""
-    return 64 + mesh_scratch_slots(P) * (64 * 28 + 8)
+    return 64 + mesh_scratch_slots(P) * (64 * 40 + 8 + 64)
 
 
 _c_float_p = ctypes.POINTER(ctypes.c_float)

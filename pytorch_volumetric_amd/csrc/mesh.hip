@@ -16,6 +16,7 @@
 //     tests (the oracle's operation sequences) run densely over the queue.  Bit-identical to the plain double loop of
 //     oracle/pvamd_oracle.c; with spatially sorted triangles and points this is a flat three-level BVH.
 //   * ties in d^2 resolve to the lowest ORIGINAL face id (lexicographic min), independent of processing order.
+#include <cstdlib>
 #include "common.h"
 #include "mesh_math.h"
 #include "morton.h"
@@ -674,7 +675,8 @@ PVAMD_DEV void scan_finish(const MeshArgs& m, GroupShared<WITH_RAY>& g, WaveLoca
 // False when no lane has a finite point (uniform over the block: every wave holds the same points).
 template <bool WITH_RAY>
 PVAMD_DEV bool scan_begin(const MeshArgs& m, GroupShared<WITH_RAY>& g, Wave<WITH_RAY>& wv, int wave, uint64_t seed,
-                          int64_t jitter_index, const unsigned long long* start, const float* __restrict__ drawn = nullptr) {
+                          int64_t jitter_index, const unsigned long long* start, const float* __restrict__ drawn = nullptr,
+                          const float* __restrict__ bound = nullptr) {
     const int lane = threadIdx.x & 63;
     if (wave == 0) {
         g.best[lane] = start ? *start : kBestInit;
@@ -694,7 +696,7 @@ PVAMD_DEV bool scan_begin(const MeshArgs& m, GroupShared<WITH_RAY>& g, Wave<WITH
         wv.dir = v3(g.dir[3 * lane], g.dir[3 * lane + 1], g.dir[3 * lane + 2]);
         wv.dn = v3(g.dn[3 * lane], g.dn[3 * lane + 1], g.dn[3 * lane + 2]);
     }
-    return wave_setup(m, wv);
+    return bound ? load_bound(bound, wv) : wave_setup(m, wv);
 }
 
 // ---- point groups that are handed over -----------------------------------------------------------------------
@@ -707,7 +709,9 @@ PVAMD_DEV bool scan_begin(const MeshArgs& m, GroupShared<WITH_RAY>& g, Wave<WITH
 // outputs.  The few-points path (below) is the same three launches with EVERY group listed up front.
 // scratch: int count | int entries[cap][2] (point group, transform) | u64 best[cap][64] | int hits[cap][64] |
 //          float dir[cap][64][3] (the jittered ray of each point, drawn once) | float reach[cap][64] (an upper bound
-//          of each point's distance to the mesh to start from, +inf when none was worked out)
+//          of each point's distance to the mesh to start from, +inf when none was worked out) | float bound[cap][16]
+//          (the group's wave bound: every block of the parts launch would otherwise redo its eight wave reductions) |
+//          float pts[cap][64][3] (the group's points)
 struct HandOver {
     int* count;
     int* entries;
@@ -715,8 +719,12 @@ struct HandOver {
     int* hits;
     float* dir;
     float* reach;
+    float* pts;    // [cap][64][3]: the group's points (for the chamfer calls: transformed), so that the blocks of the parts launch
+                   // read them with one coalesced load instead of the order -> point chain
+    float* bound;  // [cap][16]: the group's wave bound (c, rho, ray axis, k, rho_k, any lane live), worked out once when it is listed
     int cap;  // 0: nothing is handed over
 };
+constexpr int kBoundFloats = 16;
 constexpr int kHandOverHeader = 64;  // bytes
 static __host__ __device__ inline HandOver hand_over(void* scratch, int cap) {
     HandOver h;
@@ -727,6 +735,8 @@ static __host__ __device__ inline HandOver hand_over(void* scratch, int cap) {
     h.hits = reinterpret_cast<int*>(base + kHandOverHeader + (size_t)cap * 8 + (size_t)cap * 64 * 8);
     h.dir = reinterpret_cast<float*>(base + kHandOverHeader + (size_t)cap * 8 + (size_t)cap * 64 * 12);
     h.reach = reinterpret_cast<float*>(base + kHandOverHeader + (size_t)cap * 8 + (size_t)cap * 64 * 24);
+    h.bound = reinterpret_cast<float*>(base + kHandOverHeader + (size_t)cap * 8 + (size_t)cap * 64 * 28);
+    h.pts = reinterpret_cast<float*>(base + kHandOverHeader + (size_t)cap * 8 + (size_t)cap * 64 * 28 + (size_t)cap * 64);
     h.cap = scratch ? cap : 0;
     return h;
 }
@@ -748,6 +758,56 @@ constexpr int kHeavy32nds = PVAMD_MESH_HEAVY_32NDS;
 #endif
 constexpr int kHeavyMinTiles = PVAMD_MESH_HEAVY_MIN_TILES;
 constexpr int kHeavyParts = PVAMD_MESH_HEAVY_PARTS;
+
+PVAMD_DEV void store_bound(float* __restrict__ b, const WaveBound& wb, bool any_live) {
+    if ((threadIdx.x & 63) != 0) return;
+    b[0] = wb.q.p.x; b[1] = wb.q.p.y; b[2] = wb.q.p.z; b[3] = wb.rho;
+    b[4] = wb.dn0.x; b[5] = wb.dn0.y; b[6] = wb.dn0.z; b[7] = wb.k;
+    b[8] = wb.rho_k; b[9] = any_live ? 1.f : 0.f;
+    b[10] = wb.q.reach;  // Q when the group was listed (+inf: unknown)
+}
+// Does the block of part `part` of `nparts` have anything to do for the listed group whose bound is `b`?  The wave-level
+// test of scan_tiles at the group's (c, Q) on the block's own tiles, before anything else is loaded: about half the blocks
+// of a few-points query own no tile that any lane can need, and go straight to their tick.
+template <bool WITH_RAY>
+PVAMD_DEV bool part_has_work(const MeshArgs& m, const float* __restrict__ b, int part, int nparts) {
+    if (uniform(b[9]) == 0.f) return false;
+    WaveBound wb;
+    wb.q.p = v3(uniform(b[0]), uniform(b[1]), uniform(b[2]));
+    wb.rho = uniform(b[3]);
+    wb.dn0 = v3(uniform(b[4]), uniform(b[5]), uniform(b[6]));
+    wb.k = uniform(b[7]);
+    wb.rho_k = uniform(b[8]);
+    set_reach(wb.q, uniform(b[10]));
+    const int lane = threadIdx.x & 63;
+    const int ntiles = (m.F + kTile - 1) / kTile;
+    const f32x4* tiles4 = reinterpret_cast<const f32x4*>(m.tiles);
+    for (int base = part; base < ntiles; base += 64 * nparts) {
+        const int ti = base + lane * nparts;
+        const f32x4 ts = tiles4[ti < ntiles ? ti : 0];
+        const V3 w = v3(ts.x - wb.q.p.x, ts.y - wb.q.p.y, ts.z - wb.q.p.z);
+        const float dist2 = dot(w, w);
+        bool need = sphere_may_improve(wb.q, dist2, ts.w);
+        if (WITH_RAY) need = need || axis_may_hit(wb, w, dist2, ts.w);
+        if (__any(need && ti < ntiles)) return true;
+    }
+    return false;
+}
+// the per-wave setup of a listed group: the lanes' own state + the stored bound.  False: no lane has a finite point.
+template <bool WITH_RAY>
+PVAMD_DEV bool load_bound(const float* __restrict__ b, Wave<WITH_RAY>& wv) {
+    const V3 p = wv.s.p;
+    wv.live = fabsf(p.x) < INFINITY && fabsf(p.y) < INFINITY && fabsf(p.z) < INFINITY;
+    wv.nc = wv.nr = 0;
+    set_reach(wv.s, INFINITY);
+    wv.wb.q.p = v3(uniform(b[0]), uniform(b[1]), uniform(b[2]));
+    wv.wb.rho = uniform(b[3]);
+    wv.wb.dn0 = v3(uniform(b[4]), uniform(b[5]), uniform(b[6]));
+    wv.wb.k = uniform(b[7]);
+    wv.wb.rho_k = uniform(b[8]);
+    set_reach(wv.wb.q, INFINITY);
+    return uniform(b[9]) != 0.f;
+}
 
 // tiles some lane may still need, counted with lanes = tiles at (c, Q)
 template <bool WITH_RAY>
@@ -804,6 +864,11 @@ PVAMD_DEV bool scan_mesh(const MeshArgs& m, MeshShared<SLICES, WITH_RAY>& sh, Wa
                     }
                     ho.best[(int64_t)slot * 64 + lane] = sh.g.best[lane];  // a bound to start from; the hits are counted afresh
                     ho.reach[(int64_t)slot * 64 + lane] = INFINITY;
+                    store_bound(ho.bound + (int64_t)slot * kBoundFloats, wv.wb, true);
+                    {
+                        float* q = ho.pts + ((int64_t)slot * 64 + lane) * 3;
+                        q[0] = wv.s.p.x; q[1] = wv.s.p.y; q[2] = wv.s.p.z;
+                    }
                     if (WITH_RAY) {
                         ho.hits[(int64_t)slot * 64 + lane] = 0;
                         for (int d = 0; d < 3; ++d) ho.dir[((int64_t)slot * 64 + lane) * 3 + d] = sh.g.dir[3 * lane + d];
@@ -954,6 +1019,7 @@ __global__ __launch_bounds__(64 * SLICES) void chamfer_mesh_kernel(MeshArgs m, c
 // independent serial chains: 5 + 8 us one after the other, 8 side by side)
 __global__ __launch_bounds__(128) void hand_over_all_kernel(MeshArgs m, const int* __restrict__ order, const float* __restrict__ pts,
                                                             int64_t P, uint64_t seed, int64_t index_base, HandOver ho, int groups) {
+    __shared__ float reach_of_lane[64];
     const int g = blockIdx.x, lane = threadIdx.x & 63;
     const int64_t slot = (int64_t)g * 64 + lane;
     const int64_t i = point_index(order, slot, P);
@@ -962,10 +1028,26 @@ __global__ __launch_bounds__(128) void hand_over_all_kernel(MeshArgs m, const in
         const V3 dir = jitter_dir(m.ray_dir, seed, index_base + i);
         float* o = ho.dir + slot * 3;
         o[0] = dir.x; o[1] = dir.y; o[2] = dir.z;
-        if (lane == 0) {
-            ho.entries[2 * g] = g;
-            ho.entries[2 * g + 1] = 0;
-            if (g == 0) *ho.count = groups;
+        {   // the group's wave bound, once for all the blocks of the parts launch (same operations as scan_begin + wave_setup)
+            Wave<true> wv{};
+            wv.s.p = v3(pts[3 * i], pts[3 * i + 1], pts[3 * i + 2]);
+            const float inv_len = 1.f / sqrt_rn(dot(dir, dir));
+            wv.dir = dir;
+            wv.dn = v3(dir.x * inv_len, dir.y * inv_len, dir.z * inv_len);
+            const bool any_live = wave_setup(m, wv);
+            float* q = ho.pts + slot * 3;
+            q[0] = wv.s.p.x; q[1] = wv.s.p.y; q[2] = wv.s.p.z;
+            if (lane == 0) {
+                ho.entries[2 * g] = g;
+                ho.entries[2 * g + 1] = 0;
+                if (g == 0) *ho.count = groups;
+            }
+            __syncthreads();  // the other wave's bounds
+            if (any_live) {
+                set_reach(wv.s, reach_of_lane[lane]);
+                refresh_bound(wv);  // Q: what a block of the parts launch will start from
+            }
+            store_bound(ho.bound + (int64_t)g * kBoundFloats, wv.wb, any_live);
         }
         return;
     }
@@ -1018,6 +1100,8 @@ __global__ __launch_bounds__(128) void hand_over_all_kernel(MeshArgs m, const in
     }
     ho.best[slot] = found;
     ho.reach[slot] = bound * 1.00001f;  // a NaN / inf point: never a finite bound
+    reach_of_lane[lane] = bound * 1.00001f;
+    __syncthreads();
 }
 __global__ void hand_over_none_kernel(HandOver ho) { *ho.count = 0; }
 
@@ -1026,38 +1110,70 @@ __global__ void hand_over_none_kernel(HandOver ho) { *ho.count = 0; }
                                   // 30k points 0.201 / 0.190 / 0.207 ms at 6 / 7 / 8)
 #endif
 // one listed group in one block: wave w takes the w-th 64-record pass of the tiles ti % gridDim.y == blockIdx.y
-template <bool WITH_RAY>
-PVAMD_DEV void parts_of_group(const MeshArgs& m, MeshShared<kTile / 64, WITH_RAY>& sh, const int* __restrict__ order,
+template <bool WITH_RAY, bool WAIT = false, int WAVES = kTile / 64>
+PVAMD_DEV void parts_of_group(const MeshArgs& m, MeshShared<WAVES, WITH_RAY>& sh, const int* __restrict__ order,
                               const float* __restrict__ M, const float* __restrict__ pts, int64_t P, uint64_t seed,
                               int64_t index_base, const HandOver& ho, int slot, int group) {
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int64_t i = point_index(order, (int64_t)group * 64 + lane, P);
+    if (!part_has_work<WITH_RAY>(m, ho.bound + (int64_t)slot * kBoundFloats, (int)blockIdx.y, (int)gridDim.y)) return;  // the whole block
     Wave<WITH_RAY> wv;
-    wv.s.p = M ? chamfer_point(M, pts, i) : v3(pts[3 * i], pts[3 * i + 1], pts[3 * i + 2]);
+    // everything a block needs to start comes from the slot, in one batch of independent loads
+    const float* q = ho.pts + ((int64_t)slot * 64 + lane) * 3;
+    wv.s.p = v3(q[0], q[1], q[2]);
     const unsigned long long start = ho.best[(int64_t)slot * 64 + lane];
+    const float known = ho.reach[(int64_t)slot * 64 + lane];
     TIC(t_parts);
-    if (scan_begin(m, sh.g, wv, wave, seed, index_base + i, &start, WITH_RAY ? ho.dir + (int64_t)slot * 192 : nullptr)) {
-        scan_seed(m, wv, 0, 1);  // the bound from the tile spheres (the slot's own finds are pulled in scan_tiles) ...
-        const float known = ho.reach[(int64_t)slot * 64 + lane];  // ... and the one worked out when the group was listed
+    if (scan_begin(m, sh.g, wv, wave, seed, 0, &start, WITH_RAY ? ho.dir + (int64_t)slot * 192 : nullptr,
+                   ho.bound + (int64_t)slot * kBoundFloats)) {
+        // the bound worked out when the group was listed, or what it had found by then (pulled from the slots in scan_tiles);
+        // the bound from the tile spheres only for a lane that has neither
+        if (__any(wv.live && !(known < INFINITY) && (unsigned)(start >> 32) >= 0x7F800000u)) scan_seed(m, wv, 0, 1);
         if (known < wv.s.reach) set_reach(wv.s, known);
         refresh_bound(wv);
-        scan_tiles<WITH_RAY>(m, sh.g, sh.w[wave], wv, -1, (int)blockIdx.y, (int)gridDim.y, wave, wave + 1);
+        constexpr int kPasses = (kTile / 64) / WAVES;  // 64-record passes of a tile per wave
+        scan_tiles<WITH_RAY>(m, sh.g, sh.w[wave], wv, -1, (int)blockIdx.y, (int)gridDim.y, wave * kPasses, (wave + 1) * kPasses);
         scan_finish(m, sh.g, sh.w[wave], wv);
     }
     TOC(21, t_parts);
     __syncthreads();
     if (wave == 0) {
-        if (sh.g.best[lane] < start) atomicMin(&ho.best[(int64_t)slot * 64 + lane], sh.g.best[lane]);
-        if (WITH_RAY && sh.g.hits[lane] != 0) atomicAdd(&ho.hits[(int64_t)slot * 64 + lane], sh.g.hits[lane]);
+        if (WAIT) {  // returning atomics: when the old values are back, the updates have been performed
+            unsigned long long was = 0ull;
+            int had = 0;
+            if (sh.g.best[lane] < start) was = atomicMin(&ho.best[(int64_t)slot * 64 + lane], sh.g.best[lane]);
+            if (WITH_RAY && sh.g.hits[lane] != 0) had = atomicAdd(&ho.hits[(int64_t)slot * 64 + lane], sh.g.hits[lane]);
+            asm volatile("" ::"v"(was), "v"(had) : "memory");
+        } else {
+            if (sh.g.best[lane] < start) atomicMin(&ho.best[(int64_t)slot * 64 + lane], sh.g.best[lane]);
+            if (WITH_RAY && sh.g.hits[lane] != 0) atomicAdd(&ho.hits[(int64_t)slot * 64 + lane], sh.g.hits[lane]);
+        }
     }
 }
 
-// few points: grid x = point groups (slot g = group g), y = part
-__global__ __launch_bounds__(64 * (kTile / 64), PVAMD_MESH_PARTS_WAVES) void mesh_parts_all_kernel(MeshArgs m, const int* __restrict__ order,
+// few points: grid x = point groups (slot g = group g), y = part.  The block that folds a group's LAST part in writes the
+// group's outputs (entries[2g + 1], zeroed by the list launch, counts the parts that are done): no finish launch.
+// kAllWaves waves per block, each (kTile / 64) / kAllWaves of the passes of a tile
+template <int kAllWaves>
+__global__ __launch_bounds__(64 * kAllWaves, PVAMD_MESH_PARTS_WAVES) void mesh_parts_all_kernel(MeshArgs m, const int* __restrict__ order,
                                                                           const float* __restrict__ pts, int64_t P,
-                                                                          uint64_t seed, int64_t index_base, HandOver ho) {
-    __shared__ __attribute__((aligned(16))) MeshShared<kTile / 64, true> sh;
-    parts_of_group<true>(m, sh, order, nullptr, pts, P, seed, index_base, ho, (int)blockIdx.x, (int)blockIdx.x);
+                                                                          uint64_t seed, int64_t index_base, HandOver ho, QueryOut out) {
+    __shared__ __attribute__((aligned(16))) MeshShared<kAllWaves, true> sh;
+    const int g = (int)blockIdx.x;
+    parts_of_group<true, true, kAllWaves>(m, sh, order, nullptr, pts, P, seed, index_base, ho, g, g);
+    if (threadIdx.x >= 64) return;
+    // No fences: the slots are only ever touched by device-scope read-modify-write atomics inside this launch, this block's
+    // have been performed (their old values are back) before its tick, and the block whose tick is the last reads the slots
+    // with atomics as well.  (A __threadfence() per block -- an L2 write-back -- took the launch from 65 to 180 us.)
+    const int lane = threadIdx.x;
+    int done = 0;
+    if (lane == 0) done = atomicAdd(&ho.entries[2 * g + 1], 1);
+    if (__builtin_amdgcn_readfirstlane(done) != (int)gridDim.y - 1) return;
+    const int64_t k = (int64_t)g * 64 + lane;
+    if (k >= P) return;
+    const int64_t i = order ? (int64_t)order[k] : k;
+    const unsigned long long found = atomicMin(&ho.best[k], ~0ull);
+    const int hits = atomicOr(&ho.hits[k], 0);
+    write_query(m, out, i, v3(pts[3 * i], pts[3 * i + 1], pts[3 * i + 2]), found, hits);
 }
 
 // the listed groups: grid x = slots (strided over the list), y = part
@@ -1188,7 +1304,7 @@ constexpr int kMaxFaces = 1 << 26;  // queue entries are record << 6 | lane
 #endif
 constexpr int kFillWaves = PVAMD_MESH_FILL_WAVES;  // 4 x (256 CUs x 4 SIMDs x 8 waves): short waves, several rounds
 #ifndef PVAMD_MESH_MIN_PARTS
-#define PVAMD_MESH_MIN_PARTS 6
+#define PVAMD_MESH_MIN_PARTS 4
 #endif
 #ifndef PVAMD_MESH_MAX_PARTS
 #define PVAMD_MESH_MAX_PARTS 32
@@ -1282,21 +1398,32 @@ extern "C" int pvamd_mesh_query(const pvamd_mesh_t* mesh, const float* points, c
     const int cap = (int)PVAMD_MESH_SCRATCH_SLOTS(P);  // what PVAMD_MESH_SCRATCH_BYTES(P) holds
     const HandOver ho = hand_over(scratch, cap);
     const int slices = pick_slices(groups, ntiles, ho.cap > 0 && ntiles >= kHeavyMinTiles);
-    // few point groups, many tiles: spread each group's tiles over `parts` blocks of four waves, one per 64-record pass
-    // (see mesh_parts_kernel)
-    int parts = (int)((int64_t)kFillWaves / (groups * (kTile / 64)));
-    if (parts > ntiles) parts = ntiles;
-    {   // cap, but never below what fills the chip twice over (1000 points: 0.061 ms with 62 parts, 0.080 with 32)
-        const int64_t fill = 16384 / (groups * (kTile / 64));
-        const int most = fill > kMaxParts ? (int)fill : kMaxParts;
-        if (parts > most) parts = most;
+    // few point groups, many tiles: spread each group's tiles over `parts` blocks of `aw` waves (see mesh_parts_kernel)
+    // Sweep over 1k .. 520k points x parts x waves on the 62-tile drill and the 389-tile sphere (profiles/r04_mesh_variants.txt,
+    // section 7): tiles per block by the number of point groups whatever the size of the mesh -- one for up to 64 groups, two
+    // up to 256, three up to ~2000, then a five-hundredth of the groups --, two waves per block instead of four once the
+    // launch is beyond ~100k waves.
+    const int per_block = groups <= 64 ? 1 : (groups <= 256 ? 2 : (groups < 2048 ? 3 : (int)(groups / 512)));
+    int parts = (ntiles + per_block - 1) / per_block;
+    int aw = (int64_t)groups * parts * 4 > 100000 ? 2 : 4;
+    bool few = parts >= kMinParts;
+#ifdef PVAMD_MESH_TUNE
+    if (getenv("PVAMD_TUNE_PARTS")) {  // parts = 0: the single launch
+        parts = atoi(getenv("PVAMD_TUNE_PARTS"));
+        aw = getenv("PVAMD_TUNE_WAVES") ? atoi(getenv("PVAMD_TUNE_WAVES")) : 4;
+        few = parts > 0;
+        if (parts > ntiles) parts = ntiles;
     }
-    if (ho.cap > 0 && groups <= ho.cap && parts >= kMinParts) {
+#endif
+    if (ho.cap > 0 && groups <= ho.cap && few) {
         hipLaunchKernelGGL(hand_over_all_kernel, dim3((unsigned)groups), dim3(128), 0, s, m, order, points, P, jitter_seed, index_base,
                            ho, (int)groups);
-        hipLaunchKernelGGL(mesh_parts_all_kernel, dim3((unsigned)groups, (unsigned)parts), dim3(kTile), 0, s, m, order, points, P,
-                           jitter_seed, index_base, ho);
-        hipLaunchKernelGGL(mesh_query_finish_kernel, dim3((unsigned)groups), dim3(64), 0, s, m, order, points, P, ho, (int)groups, out);
+        const dim3 grid((unsigned)groups, (unsigned)parts);
+        switch (aw) {
+            case 1: hipLaunchKernelGGL((mesh_parts_all_kernel<1>), grid, dim3(64), 0, s, m, order, points, P, jitter_seed, index_base, ho, out); break;
+            case 2: hipLaunchKernelGGL((mesh_parts_all_kernel<2>), grid, dim3(128), 0, s, m, order, points, P, jitter_seed, index_base, ho, out); break;
+            default: hipLaunchKernelGGL((mesh_parts_all_kernel<4>), grid, dim3(256), 0, s, m, order, points, P, jitter_seed, index_base, ho, out); break;
+        }
         return (int)hipGetLastError();
     }
     const bool heavy = ho.cap > 0 && ntiles >= kHeavyMinTiles;

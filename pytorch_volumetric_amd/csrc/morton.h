@@ -35,7 +35,8 @@ PVAMD_DEV unsigned hilbert_key30(float x, float y, float z, const float lo[3], c
     const float top = (float)((1 << b) - 1);
 #pragma unroll
     for (int d = 0; d < 3; ++d) {
-        float t = (p[d] - lo[d]) / fmaxf(hi[d] - lo[d], 1e-30f) * (top + 0.999f);
+        // (the scale is loop-invariant in the callers: one division per axis and thread, not per point)
+        float t = (p[d] - lo[d]) * ((top + 0.999f) / fmaxf(hi[d] - lo[d], 1e-30f));
         t = fminf(fmaxf(t, 0.f), top);  // NaN -> 0
         X[d] = (unsigned)t;
     }

@@ -156,23 +156,30 @@ __global__ __launch_bounds__(256) void order_scatter_kernel(const float* __restr
 
 // ---- up to 16384 points: the whole thing in ONE workgroup (bounds, 16^3-cell histogram in LDS, scan, scatter) ----
 // The seven launches above cost ~4.5 us each whatever their size; for the 10k-point query of BASELINE C1 that was a
-// quarter of the call.
-constexpr int kSmallCells = 4096, kSmallShift = 18;
+// quarter of the call.  Every thread keeps its (up to 16) points and their cells in registers: the points are read once,
+// the curve position is worked out once, and the scan of the 4096 cell counters is a wave scan + 16 wave totals (five
+// barriers in all; the first version read the points three times and scanned with twenty barriers: 25 us for 10k points).
+constexpr int kSmallCells = 4096, kSmallShift = 18, kSmallPer = 16;
 __global__ __launch_bounds__(1024) void order_small_kernel(const float* __restrict__ pts, int P, int* __restrict__ order,
                                                            int* __restrict__ inv, float* __restrict__ sorted_pts) {
     __shared__ unsigned hist[kSmallCells];
-    __shared__ unsigned partial[1024];
+    __shared__ unsigned wsum[16];
     __shared__ float part[16][6];
     __shared__ float box[6];
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    float x[kSmallPer], y[kSmallPer], z[kSmallPer];
     float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
-    for (int i = t; i < P; i += 1024) {
+#pragma unroll
+    for (int k = 0; k < kSmallPer; ++k) {
+        const int i = t + 1024 * k;
+        x[k] = y[k] = z[k] = NAN;
+        if (i < P) { x[k] = pts[3 * i]; y[k] = pts[3 * i + 1]; z[k] = pts[3 * i + 2]; }
+        const float v[3] = {x[k], y[k], z[k]};
 #pragma unroll
         for (int d = 0; d < 3; ++d) {
-            const float v = pts[3 * i + d];
-            if (fabsf(v) < INFINITY) {
-                lo[d] = fminf(lo[d], v);
-                hi[d] = fmaxf(hi[d], v);
+            if (fabsf(v[d]) < INFINITY) {  // false for NaN and +-inf
+                lo[d] = fminf(lo[d], v[d]);
+                hi[d] = fmaxf(hi[d], v[d]);
             }
         }
     }
@@ -187,7 +194,8 @@ __global__ __launch_bounds__(1024) void order_small_kernel(const float* __restri
 #pragma unroll
         for (int d = 0; d < 3; ++d) { part[wave][d] = lo[d]; part[wave][3 + d] = hi[d]; }
     }
-    for (int c = t; c < kSmallCells; c += 1024) hist[c] = 0u;
+#pragma unroll
+    for (int k = 0; k < kSmallCells / 1024; ++k) hist[t + 1024 * k] = 0u;
     __syncthreads();
     if (t < 6) {
         float v = part[0][t];
@@ -196,33 +204,45 @@ __global__ __launch_bounds__(1024) void order_small_kernel(const float* __restri
     }
     __syncthreads();
     const float blo[3] = {box[0], box[1], box[2]}, bhi[3] = {box[3], box[4], box[5]};
-    for (int i = t; i < P; i += 1024)
-        atomicAdd(&hist[PVAMD_ORDER_KEY(pts[3 * i], pts[3 * i + 1], pts[3 * i + 2], blo, bhi, (30 - kSmallShift) / 3) >> kSmallShift], 1u);
+    unsigned cell[kSmallPer];
+#pragma unroll
+    for (int k = 0; k < kSmallPer; ++k) {
+        cell[k] = 0u;
+        if (1024 * k < P) {  // uniform over the block: the one workgroup is bound by its vector ALUs
+            cell[k] = PVAMD_ORDER_KEY(x[k], y[k], z[k], blo, bhi, (30 - kSmallShift) / 3) >> kSmallShift;
+            if (t + 1024 * k < P) atomicAdd(&hist[cell[k]], 1u);
+        }
+    }
     __syncthreads();
+    // exclusive scan of the 4096 counters: thread t owns cells 4t .. 4t+3
     unsigned c4[4], sum = 0;
 #pragma unroll
     for (int k = 0; k < 4; ++k) { c4[k] = hist[4 * t + k]; sum += c4[k]; }
-    partial[t] = sum;
-    __syncthreads();
-    for (int off = 1; off < 1024; off <<= 1) {
-        const unsigned add = t >= off ? partial[t - off] : 0u;
-        __syncthreads();
-        partial[t] += add;
-        __syncthreads();
+    unsigned incl = sum;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const unsigned up = __shfl_up(incl, off, 64);
+        if (lane >= off) incl += up;
     }
-    unsigned run = partial[t] - sum;
+    if (lane == 63) wsum[wave] = incl;
+    __syncthreads();
+    unsigned run = incl - sum;
+    for (int w = 0; w < wave; ++w) run += wsum[w];
 #pragma unroll
     for (int k = 0; k < 4; ++k) { hist[4 * t + k] = run; run += c4[k]; }
     __syncthreads();
-    for (int i = t; i < P; i += 1024) {
-        const float x = pts[3 * i], y = pts[3 * i + 1], z = pts[3 * i + 2];
-        const unsigned slot = atomicAdd(&hist[PVAMD_ORDER_KEY(x, y, z, blo, bhi, (30 - kSmallShift) / 3) >> kSmallShift], 1u);
-        order[slot] = i;
-        if (inv) inv[i] = (int)slot;
-        if (sorted_pts) {
-            sorted_pts[3 * slot] = x;
-            sorted_pts[3 * slot + 1] = y;
-            sorted_pts[3 * slot + 2] = z;
+#pragma unroll
+    for (int k = 0; k < kSmallPer; ++k) {
+        const int i = t + 1024 * k;
+        if (i < P) {
+            const unsigned slot = atomicAdd(&hist[cell[k]], 1u);
+            order[slot] = i;
+            if (inv) inv[i] = (int)slot;
+            if (sorted_pts) {
+                sorted_pts[3 * slot] = x[k];
+                sorted_pts[3 * slot + 1] = y[k];
+                sorted_pts[3 * slot + 2] = z[k];
+            }
         }
     }
 }

@@ -219,15 +219,15 @@ def test_heavy_point_groups_are_handed_over_with_the_same_bits():
     listed = int(scratch.view(torch.int32)[0].item())
     assert 0 < listed < 2 * (pts.shape[0] // 64), listed
     assert torch.allclose(sums[0], sums[1], rtol=1e-12, atol=0)
-    # more heavy groups than the list has slots for (2048): the ones that find it full walk the mesh themselves
-    many = ((torch.rand(2200 * 64, 3, generator=g) - 0.5) * 0.02).float().cuda().contiguous()
+    # more heavy groups than the list has slots for (8192): the ones that find it full walk the mesh themselves
+    many = ((torch.rand(9000 * 64, 3, generator=g) - 0.5) * 0.02).float().cuda().contiguous()
     order = _lib.morton_order(many)
-    scratch.zero_()
+    scratch = torch.zeros((_lib.mesh_scratch_bytes(many.shape[0]) // 8,), dtype=torch.int64, device="cuda")
     one = torch.empty((2, 1), dtype=torch.float64, device="cuda")
     for k, sc in enumerate((None, scratch)):
         _lib.check(lib.pvamd_chamfer_mesh(ctypes.byref(desc), _lib.ptr(W), 1, _lib.ptr(many), _lib.ptr(order), many.shape[0],
                                           1000.0, _lib.ptr(one[k]), _lib.ptr(sc), _lib.stream_ptr()), "pvamd_chamfer_mesh")
-    assert int(scratch.view(torch.int32)[0].item()) > _lib.MESH_SCRATCH_GROUPS
+    assert int(scratch.view(torch.int32)[0].item()) > _lib.mesh_scratch_slots(many.shape[0]) == _lib.MESH_SCRATCH_GROUPS
     assert torch.allclose(one[0], one[1], rtol=1e-12, atol=0)
     obj.tile_split = True
     a_ = obj.object_frame_closest_point(many[:140_000]).distance.clone()

@@ -21,7 +21,7 @@ def curve_cells(pts, bits):
     span = np.maximum((hi - lo).astype(np.float32), np.float32(1e-30))
     top = np.float32((1 << b) - 1)
     with np.errstate(invalid="ignore"):
-        t = (((p - lo) / span).astype(np.float32) * np.float32(top + np.float32(0.999))).astype(np.float32)
+        t = ((p - lo).astype(np.float32) * (np.float32(top + np.float32(0.999)) / span).astype(np.float32)).astype(np.float32)
     t = np.where(np.isnan(t), 0.0, np.clip(t, 0.0, top))
     X = [t[:, d].astype(np.int64) for d in range(3)]
     Q = 1 << (b - 1)
