@@ -1065,9 +1065,19 @@ __global__ __launch_bounds__(128) void hand_over_all_kernel(MeshArgs m, const in
             return fast_sqrt(dot(w, w)) * 1.00001f + (sp.w + 1.1e-19f);  // slack: 1 ulp + the flushed denormals
         };
         int ti = 0;
-        for (int t = 0; t < ntiles; ++t) {  // wave-uniform t: scalar loads
-            const float b = reach_of(spheres[t]);
-            if (b < bound) { bound = b; ti = t; }
+        // every lane against every tile sphere: 64 spheres per vector load, handed round with v_readlane (a scalar load per
+        // tile is a memory round trip per tile: 62 of them in a row were half of this launch)
+        for (int base = 0; base < ntiles; base += 64) {
+            const f32x4 mine = spheres[base + lane < ntiles ? base + lane : base];
+            const int n = min(64, ntiles - base);
+            for (int t = 0; t < n; ++t) {
+                const f32x4 sp = {__int_as_float(__builtin_amdgcn_readlane(__float_as_int(mine.x), t)),
+                                  __int_as_float(__builtin_amdgcn_readlane(__float_as_int(mine.y), t)),
+                                  __int_as_float(__builtin_amdgcn_readlane(__float_as_int(mine.z), t)),
+                                  __int_as_float(__builtin_amdgcn_readlane(__float_as_int(mine.w), t))};
+                const float b = reach_of(sp);
+                if (b < bound) { bound = b; ti = base + t; }
+            }
         }
         int gi = 0;
         const int ngroups = (min(kTile, m.F - ti * kTile) + kGroup - 1) / kGroup;
@@ -1177,15 +1187,15 @@ __global__ __launch_bounds__(64 * kAllWaves, PVAMD_MESH_PARTS_WAVES) void mesh_p
 }
 
 // the listed groups: grid x = slots (strided over the list), y = part
-template <bool WITH_RAY>
-__global__ __launch_bounds__(64 * (kTile / 64), PVAMD_MESH_PARTS_WAVES) void mesh_parts_kernel(MeshArgs m, const int* __restrict__ order,
+template <bool WITH_RAY, int WAVES>
+__global__ __launch_bounds__(64 * WAVES, PVAMD_MESH_PARTS_WAVES) void mesh_parts_kernel(MeshArgs m, const int* __restrict__ order,
                                                                       const float* __restrict__ W,
                                                                       const float* __restrict__ pts, int64_t P,
                                                                       uint64_t seed, int64_t index_base, HandOver ho) {
-    __shared__ __attribute__((aligned(16))) MeshShared<kTile / 64, WITH_RAY> sh;
+    __shared__ __attribute__((aligned(16))) MeshShared<WAVES, WITH_RAY> sh;
     const int listed = min(*ho.count, ho.cap);
     for (int slot = blockIdx.x; slot < listed; slot += gridDim.x) {
-        parts_of_group<WITH_RAY>(m, sh, order, W ? W + 16 * (int64_t)ho.entries[2 * slot + 1] : nullptr, pts, P, seed, index_base,
+        parts_of_group<WITH_RAY, false, WAVES>(m, sh, order, W ? W + 16 * (int64_t)ho.entries[2 * slot + 1] : nullptr, pts, P, seed, index_base,
                                  ho, slot, ho.entries[2 * slot]);
         __syncthreads();  // the slots in LDS are reused by the next listed group
     }
@@ -1378,6 +1388,24 @@ extern "C" int pvamd_mesh_prepare(const float* tri, const int32_t* face_id, int3
 // grid.x of the launches that walk the list of handed-over groups
 static unsigned list_blocks(int cap) { return (unsigned)(cap < 512 ? (cap < 1 ? 1 : cap) : 512); }
 
+// the parts launch over the listed (heavy) groups: x = slots (a block strides over the list), y = parts
+template <bool WITH_RAY>
+static void launch_heavy_parts(const MeshArgs& m, const int* order, const float* W, const float* points, int64_t P, uint64_t seed,
+                               int64_t index_base, const HandOver& ho, int ntiles, hipStream_t s) {
+    int parts = kHeavyParts, waves = 4;
+    unsigned xb = list_blocks(ho.cap);
+#ifdef PVAMD_MESH_TUNE
+    if (getenv("PVAMD_TUNE_HPARTS")) parts = atoi(getenv("PVAMD_TUNE_HPARTS"));
+    if (getenv("PVAMD_TUNE_HWAVES")) waves = atoi(getenv("PVAMD_TUNE_HWAVES"));
+    if (getenv("PVAMD_TUNE_HBLOCKS")) xb = (unsigned)atoi(getenv("PVAMD_TUNE_HBLOCKS"));
+    if (xb > (unsigned)ho.cap) xb = (unsigned)ho.cap;
+#endif
+    if (parts > ntiles) parts = ntiles;
+    const dim3 grid(xb, (unsigned)parts);
+    if (waves == 2) hipLaunchKernelGGL((mesh_parts_kernel<WITH_RAY, 2>), grid, dim3(128), 0, s, m, order, W, points, P, seed, index_base, ho);
+    else hipLaunchKernelGGL((mesh_parts_kernel<WITH_RAY, 4>), grid, dim3(256), 0, s, m, order, W, points, P, seed, index_base, ho);
+}
+
 extern "C" int pvamd_mesh_query(const pvamd_mesh_t* mesh, const float* points, const int32_t* order, int64_t P,
                                 uint64_t jitter_seed, int64_t index_base, float* out_closest, float* out_dist, float* out_grad,
                                 int32_t* out_face, float* out_normal, void* scratch, void* stream) {
@@ -1436,8 +1464,7 @@ extern "C" int pvamd_mesh_query(const pvamd_mesh_t* mesh, const float* points, c
         default: hipLaunchKernelGGL((mesh_query_kernel<1>), dim3((unsigned)groups), dim3(64), 0, s, m, order, points, P, jitter_seed, index_base, out, heavy ? ho : none); break;
     }
     if (heavy) {
-        hipLaunchKernelGGL((mesh_parts_kernel<true>), dim3(list_blocks(ho.cap), kHeavyParts), dim3(kTile), 0, s, m, order,
-                           (const float*)nullptr, points, P, jitter_seed, index_base, ho);
+        launch_heavy_parts<true>(m, order, nullptr, points, P, jitter_seed, index_base, ho, ntiles, s);
         hipLaunchKernelGGL(mesh_query_finish_kernel, dim3(list_blocks(ho.cap)), dim3(64), 0, s, m, order, points, P, ho, -1, out);
     }
     return (int)hipGetLastError();
@@ -1477,8 +1504,7 @@ static int launch_chamfer_mesh(const pvamd_mesh_t* mesh, const float* W, int32_t
         }
     }
     if (ho.cap > 0) {
-        hipLaunchKernelGGL((mesh_parts_kernel<false>), dim3(list_blocks(ho.cap), kHeavyParts), dim3(kTile), 0, s, m, order, W, points,
-                           N, (uint64_t)0, (int64_t)0, ho);
+        launch_heavy_parts<false>(m, order, W, points, N, 0, 0, ho, ntiles, s);
         hipLaunchKernelGGL(chamfer_finish_kernel, dim3(list_blocks(ho.cap)), dim3(64), 0, s, m, order, W, points, N, scale, ho, out_sum, per);
     }
     return (int)hipGetLastError();

@@ -69,6 +69,48 @@ PVAMD_DEV unsigned hilbert_key30(float x, float y, float z, const float lo[3], c
     return key << (30 - 3 * b);
 }
 
+// The same curve position for a 16^3 grid as a table look-up: kHilbert16.v[x << 8 | y << 4 | z] (8 KB, filled at compile
+// time by the transform above restated for the host compiler).  The one-workgroup sort of up to 16k points is bound by
+// its vector ALUs, and the transform was 100 of the ~176 instructions it spent per point.
+struct Hilbert16Table {
+    uint16_t v[4096];
+    constexpr Hilbert16Table() : v() {
+        for (unsigned cell = 0; cell < 4096u; ++cell) {
+            unsigned X[3] = {(cell >> 8) & 15u, (cell >> 4) & 15u, cell & 15u};
+            for (unsigned Q = 8u; Q > 1u; Q >>= 1) {
+                const unsigned P = Q - 1u;
+                for (int d = 0; d < 3; ++d) {
+                    if (X[d] & Q) {
+                        X[0] ^= P;
+                    } else {
+                        const unsigned t = (X[0] ^ X[d]) & P;
+                        X[0] ^= t;
+                        X[d] ^= t;
+                    }
+                }
+            }
+            X[1] ^= X[0];
+            X[2] ^= X[1];
+            unsigned t = 0u;
+            for (unsigned Q = 8u; Q > 1u; Q >>= 1)
+                if (X[2] & Q) t ^= Q - 1u;
+            unsigned key = 0u;
+            for (int b = 0; b < 4; ++b)
+                for (int d = 0; d < 3; ++d) key |= (((X[d] ^ t) >> b) & 1u) << (3 * b + (2 - d));
+            v[cell] = (uint16_t)key;
+        }
+    }
+};
+__device__ const Hilbert16Table kHilbert16 = Hilbert16Table();
+
+PVAMD_DEV unsigned hilbert_cell16(float x, float y, float z, const float lo[3], const float scale[3]) {
+    const float p[3] = {x, y, z};
+    unsigned c[3];
+#pragma unroll
+    for (int d = 0; d < 3; ++d) c[d] = (unsigned)fminf(fmaxf((p[d] - lo[d]) * scale[d], 0.f), 15.f);  // NaN -> 0
+    return kHilbert16.v[(c[0] << 8) | (c[1] << 4) | c[2]];
+}
+
 // Floats folded through an order-preserving map to uint32 so that atomicMin / atomicMax give float bounds.
 PVAMD_DEV unsigned order_code(float f) {
     const unsigned b = (unsigned)__float_as_int(f);

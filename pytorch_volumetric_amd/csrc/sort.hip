@@ -204,12 +204,19 @@ __global__ __launch_bounds__(1024) void order_small_kernel(const float* __restri
     }
     __syncthreads();
     const float blo[3] = {box[0], box[1], box[2]}, bhi[3] = {box[3], box[4], box[5]};
+    float scale[3];  // as hilbert_key30 with b = 4
+#pragma unroll
+    for (int d = 0; d < 3; ++d) scale[d] = (15.f + 0.999f) / fmaxf(bhi[d] - blo[d], 1e-30f);
     unsigned cell[kSmallPer];
 #pragma unroll
     for (int k = 0; k < kSmallPer; ++k) {
         cell[k] = 0u;
         if (1024 * k < P) {  // uniform over the block: the one workgroup is bound by its vector ALUs
-            cell[k] = PVAMD_ORDER_KEY(x[k], y[k], z[k], blo, bhi, (30 - kSmallShift) / 3) >> kSmallShift;
+#ifdef PVAMD_ORDER_MORTON
+            cell[k] = morton_key30(x[k], y[k], z[k], blo, bhi) >> kSmallShift;
+#else
+            cell[k] = hilbert_cell16(x[k], y[k], z[k], blo, scale);
+#endif
             if (t + 1024 * k < P) atomicAdd(&hist[cell[k]], 1u);
         }
     }
@@ -263,7 +270,11 @@ extern "C" int pvamd_morton_order(const float* points, int64_t P, int32_t* order
         return (int)hipGetLastError();
     }
     unsigned* w = reinterpret_cast<unsigned*>(scratch);
+#ifdef PVAMD_ORDER_BITS_OVERRIDE
+    const int bits = PVAMD_ORDER_BITS_OVERRIDE < PVAMD_MORTON_ORDER_BITS(P) ? PVAMD_ORDER_BITS_OVERRIDE : PVAMD_MORTON_ORDER_BITS(P), shift = 30 - bits, cells = 1 << bits;
+#else
     const int bits = PVAMD_MORTON_ORDER_BITS(P), shift = 30 - bits, cells = 1 << bits;
+#endif
     hipLaunchKernelGGL(order_init_kernel, dim3((cells + 255) / 256), dim3(256), 0, s, w, cells);
     const int64_t want = (P + 255) / 256;
     hipLaunchKernelGGL(order_bounds_kernel, dim3(want < 512 ? (unsigned)want : 512u), dim3(256), 0, s, points, P, w);

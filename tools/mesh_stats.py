@@ -35,7 +35,7 @@ def report(tag, P, F):
 
 m = mesh_io.uv_sphere_mesh(0.1, 250, 200)
 sphere = pv.MeshObjectFactory(mesh=m)
-n = 1 << 19
+n = 1 << (int(sys.argv[1]) if len(sys.argv) > 1 else 19)
 src = H.uniform_points(n, [-0.15] * 3, [0.15] * 3, seed=2).cuda()
 W = torch.eye(4).unsqueeze(0).cuda()
 pv.batch_chamfer_dist(W, src, sphere, scale=1000.0)
