@@ -264,8 +264,9 @@ int pvamd_unpack_records(const float* rec, const int32_t* index, int64_t P, int6
  * triangle's in-plane bounding rectangle: centre, two unit axes, half extents) plus one bounding sphere per run of
  * PVAMD_TRI_GROUP and of PVAMD_TRI_TILE records.  The bounds only ever SKIP work that provably cannot change a result
  * (computed in float64 for the rounded values stored, inflated by abs_margin and a relative 1e-5), so query results
- * are bit-identical to the untiled brute force whatever order the triangles are given in; spatially sorted input
- * (e.g. Morton order of centroids) is what makes the skipping effective.
+ * are bit-identical to the untiled brute force whatever order the triangles are given in; input in compact runs of
+ * PVAMD_TRI_GROUP / PVAMD_TRI_TILE triangles (the Python host: median-split patches of the centroids, mesh_io.patch_order;
+ * half the radii of Z-order runs on a surface) is what makes the skipping effective.
  * tri: device [F][3][3] fp32 soup in the order to process.  face_id: device [F] int32 original ids, or NULL for 0..F-1.
  * abs_margin: absolute slack, >= 1e-6 * (largest |vertex coordinate| + bounding-box diagonal).
  * rec_out: device float[PVAMD_REC_FLOATS(F)] (16-byte aligned).  tiles_out: device float[PVAMD_TILES_FLOATS(F)]
@@ -283,10 +284,12 @@ int pvamd_points_aabb(const float* points, int64_t P, float* box_out, void* stre
  * keys_out: device [P] int32.                                                                                  */
 int pvamd_morton_keys(const float* points, int64_t P, const float* box, int32_t* keys_out, void* stream);
 
-/* A spatial processing order for a point set, in one call (bounds, Morton cell counts, scan, scatter: seven small
- * launches instead of a general-purpose device sort): order_out[k] = index of the k-th point along a Z-order curve of
- * 16^3 cells over the points' bounding box up to 16 k points (one launch), 32^3 / 64^3 / 128^3 beyond 16 k / 64 k / 1 M.  Points of one cell come out in an arbitrary,
- * run-dependent order -- the kernels that take an `order` return the same bits for any order.
+/* A spatial processing order for a point set, in one call (bounds, cell counts, scan, scatter: seven small launches
+ * instead of a general-purpose device sort): order_out[k] = index of the k-th point along a HILBERT curve (since ABI 9; a
+ * Z-order curve before -- the name stayed) of 16^3 cells over the points' bounding box up to 16 k points (one launch),
+ * 32^3 / 64^3 / 128^3 beyond 16 k / 64 k / 1 M: consecutive cells are face neighbours at every level, so the 64 points of
+ * a wave are 25 % closer together than along the Z curve.  Points of one cell come out in an arbitrary, run-dependent
+ * order -- the kernels that take an `order` return the same bits for any order.
  * order_out: device [P] int32.  inv_out: device [P] int32 or NULL, inv[order[k]] = k.  sorted_points_out: device [P][3] or
  * NULL, the points in that order.  scratch: device, PVAMD_MORTON_ORDER_SCRATCH_BYTES(P) bytes, 4-byte aligned.          */
 #define PVAMD_MORTON_ORDER_BITS(P) ((P) >= (1 << 20) ? 21 : ((P) >= (1 << 16) ? 18 : 15))
@@ -302,9 +305,11 @@ int pvamd_morton_order(const float* points, int64_t P, int32_t* order_out, int32
  * draws the jitter an unsharded one would.  out_closest: device [P][3] or NULL.  out_dist: device [P].  out_grad: device
  * [P][3].  out_face: device [P] int32 or NULL.  out_normal: device [P][3] or NULL (compute_normal=True).
  * scratch: device, PVAMD_MESH_SCRATCH_BYTES(P) bytes, 8-byte aligned, or NULL.  With it, the tiles of a 64-point group
- * are spread over several workgroups where one group's serial walk would set the time -- every group of a query of few
- * points, and the heavy groups of a large one (points about equidistant to much of a mesh of >= 128 tiles) -- in three
- * launches that meet in scratch; results are the same bits either way.  Contents on return are unspecified.      */
+ * are spread over several workgroups where one group's serial walk would set the time -- every group of a query of up to
+ * PVAMD_MESH_SCRATCH_GROUPS groups (two launches: list, then parts + outputs), and the heavy groups of a larger one
+ * (points about equidistant to much of a mesh of >= 128 tiles; three launches) -- meeting in scratch (per slot: the
+ * group's points, rays, bounds, best (d^2, face) and hit counts); results are the same bits either way.  Contents on
+ * return are unspecified.                                                                                          */
 #define PVAMD_MESH_SCRATCH_GROUPS 8192  /* point groups (of 64) a scratch buffer has slots for: every group up to this many, ... */
 /* ... then 8192 or an eighth of the groups, whichever is more (C5: 2.3 % of the groups are handed over; one that finds the
  * list full walks the mesh on its own two waves, 4x slower than the rest put together when that happens to thousands) */
