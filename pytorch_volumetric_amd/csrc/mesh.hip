@@ -1428,11 +1428,12 @@ extern "C" int pvamd_mesh_query(const pvamd_mesh_t* mesh, const float* points, c
     const int slices = pick_slices(groups, ntiles, ho.cap > 0 && ntiles >= kHeavyMinTiles);
     // few point groups, many tiles: spread each group's tiles over `parts` blocks of `aw` waves (see mesh_parts_kernel)
     // Sweep over 1k .. 520k points x parts x waves on the 62-tile drill and the 389-tile sphere (profiles/r04_mesh_variants.txt,
-    // section 7): tiles per block by the number of point groups whatever the size of the mesh -- one for up to 64 groups, two
-    // up to 256, three up to ~2000, then a five-hundredth of the groups --, two waves per block instead of four once the
+    // section 7): tiles per block by the number of point groups whatever the size of the mesh -- one for up to 64 groups, one
+    // and a half up to 256, three up to ~2000, then a five-hundredth of the groups --, two waves per block instead of four once the
     // launch is beyond ~100k waves.
-    const int per_block = groups <= 64 ? 1 : (groups <= 256 ? 2 : (groups < 2048 ? 3 : (int)(groups / 512)));
-    int parts = (ntiles + per_block - 1) / per_block;
+    // (in halves of a tile)
+    const int half_tiles = groups <= 64 ? 2 : (groups <= 256 ? 3 : (groups < 2048 ? 6 : (int)(groups / 256)));
+    int parts = (2 * ntiles + half_tiles - 1) / half_tiles;
     int aw = (int64_t)groups * parts * 4 > 100000 ? 2 : 4;
     bool few = parts >= kMinParts;
 #ifdef PVAMD_MESH_TUNE
