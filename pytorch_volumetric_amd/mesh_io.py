@@ -239,11 +239,33 @@ def _parse_ply(data):
     return verts, np.array(faces, dtype=np.int64).reshape(-1, 3)
 
 
-SUPPORTED_MESH_EXTENSIONS = (".obj", ".stl", ".ply", ".npz")
+SUPPORTED_MESH_EXTENSIONS = (".obj", ".stl", ".ply", ".off", ".npz")
+
+
+def _parse_off(text):
+    """Object File Format: "OFF", then `nv nf ne` (on the same or the next line), nv vertex lines, nf face lines
+    `k i0 .. ik-1 [colour]` (polygons fanned); `#` comments and blank lines anywhere."""
+    lines = [l.split("#", 1)[0].split() for l in text.splitlines()]
+    lines = [l for l in lines if l]
+    if not lines or not lines[0][0].upper().endswith("OFF"):
+        raise ValueError("not an OFF file")
+    if len(lines[0]) >= 3:
+        counts, first = lines[0][1:], 1
+    else:
+        counts, first = lines[1], 2
+    nv, nf = int(counts[0]), int(counts[1])
+    verts = np.array([l[:3] for l in lines[first:first + nv]], dtype=np.float64).reshape(nv, 3)
+    faces = []
+    for l in lines[first + nv:first + nv + nf]:
+        k = int(l[0])
+        idx = [int(t) for t in l[1:1 + k]]
+        for j in range(1, k - 1):
+            faces.append((idx[0], idx[j], idx[j + 1]))
+    return verts, np.array(faces, dtype=np.int64).reshape(-1, 3)
 
 
 def load_mesh(path):
-    """.obj (text), .stl (ascii/binary), .ply (ascii/binary little endian) or .npz with arrays `vertices` [V,3] and
+    """.obj (text), .stl (ascii/binary), .ply (ascii/binary little endian), .off (text) or .npz with arrays `vertices` [V,3] and
     `faces` [F,3].  STL repeats every vertex per triangle; identical positions are merged (as open3d does when it
     reads an STL) so that center() and the vertex count match the reference loader.  Anything else -- .dae in
     particular, which needs the scene transforms assimp applies -- raises instead of yielding an empty mesh."""
@@ -262,6 +284,9 @@ def load_mesh(path):
     elif ext == ".ply":
         with open(path, "rb") as f:
             mesh = TriMesh(*_parse_ply(f.read()))
+    elif ext == ".off":
+        with open(path, "r") as f:
+            mesh = TriMesh(*_parse_off(f.read()))
     else:
         with open(path, "r") as f:
             mesh = TriMesh(*_parse_obj(f.read()))

@@ -143,6 +143,15 @@ def test_obj_stl_round_trip_and_polygon_triangulation(tmp_path):
     qp.write_text(quad)
     mq = mesh_io.load_mesh(str(qp))
     assert mq.faces.tolist() == [[0, 1, 2], [0, 2, 3], [0, 1, 2]]
+    off = "OFF\n# a unit square as one quad and a repeated triangle\n4 2 0\n0 0 0\n1 0 0\n1 1 0\n0 1 0\n4 0 1 2 3 255 0 0\n3 0 1 2\n"
+    op = tmp_path / "q.off"
+    op.write_text(off)
+    mo = mesh_io.load_mesh(str(op))
+    assert mo.faces.tolist() == [[0, 1, 2], [0, 2, 3], [0, 1, 2]] and mo.vertices.shape == (4, 3)
+    (tmp_path / "h.off").write_text("OFF 3 1 0\n0 0 0\n1 0 0\n0 1 0\n3 0 1 2\n")
+    assert mesh_io.load_mesh(str(tmp_path / "h.off")).faces.tolist() == [[0, 1, 2]]
+    with pytest.raises(ValueError):
+        mesh_io.load_mesh(str(tmp_path / "robot_link.dae"))  # refused by name, not read as an empty mesh
     with pytest.raises(RuntimeError):
         pv.MeshObjectFactory("does_not_exist.obj")  # sdf.py:102
 
