@@ -814,6 +814,8 @@ class ComposedSDF(ObjectFrameSDF):
         fused = self._fusable()
         if fused and points_in_object_frame.dtype == torch.float64:
             return self._call_f64(points_in_object_frame, S, A)
+        if not fused and points_in_object_frame.dtype == torch.float64:
+            return self._generic_f64(points_in_object_frame, S, A)
         flat, _, dtype, _ = _lib.as_query_points(points_in_object_frame, self._owner_device() if fused else None)
         P = flat.shape[0]
         dev = flat.device
@@ -956,6 +958,41 @@ class ComposedSDF(ObjectFrameSDF):
                                                         _lib.ptr(out_val), _lib.ptr(out_grad), None, self._query_flags,
                                                         _lib.stream_ptr()),
                        "pvamd_composed_query")
+
+    def _generic_f64(self, points, S, A):
+        """float64 query points over leaves that are not cached grids: sdf.py:395-431 runs transform_points, transform_normals
+        and the argmin in the query dtype, and every leaf is asked with the float64 image of the points (a MeshSDF leaf rounds
+        that image to float32 itself, sdf.py:132 -- ONE rounding, of the float64 result, where transforming in float32 rounds
+        every product).  Plain torch on the GPU: this is the reference's own dtype path, not a hot one; results in float64."""
+        dev = _lib.require_gpu()
+        pts_shape = points.shape
+        flat = points.detach().reshape(-1, 3).to(device=dev, dtype=torch.float64)
+        P = flat.shape[0]
+        m = tf.as_matrix(self.obj_frame_to_link_frame).to(device=dev, dtype=torch.float64).reshape(S, A, 4, 4)
+        best_v = best_g = None
+        for i, sdf in enumerate(self.sdfs):
+            M = m[i]  # (A, 4, 4) object frame -> leaf frame
+            # separate, unfused float64 operations in a fixed order (the test restates them in numpy)
+            x = [M[:, r, 0, None] * flat[None, :, 0] + M[:, r, 1, None] * flat[None, :, 1] + M[:, r, 2, None] * flat[None, :, 2]
+                 + M[:, r, 3, None] for r in range(3)]
+            v, g = sdf(torch.stack(x, dim=-1))  # (A, P), (A, P, 3) in the leaf frame
+            v = v.to(device=dev, dtype=torch.float64).reshape(A, P)
+            g = g.to(device=dev, dtype=torch.float64).reshape(A, P, 3)
+            # back to the object frame with R^T of the (rigid) object -> leaf rotation (sdf.py:409)
+            g = torch.stack([M[:, 0, j, None] * g[..., 0] + M[:, 1, j, None] * g[..., 1] + M[:, 2, j, None] * g[..., 2]
+                             for j in range(3)], dim=-1)
+            if best_v is None:
+                best_v, best_g = v, g
+            else:  # torch.argmin (sdf.py:421): the first minimum wins, a NaN counts as the minimum
+                take = (v < best_v) | (torch.isnan(v) & ~torch.isnan(best_v))
+                best_v = torch.where(take, v, best_v)
+                best_g = torch.where(take.unsqueeze(-1), g, best_g)
+        if self.tsf_batch is not None:
+            best_v = best_v.reshape(*self.tsf_batch, *pts_shape[:-1])
+            best_g = best_g.reshape(*self.tsf_batch, *pts_shape[:-1], 3)
+        else:
+            best_v, best_g = best_v.reshape(-1), best_g.reshape(-1, 3)
+        return best_v.to(points.device), best_g.to(points.device)
 
     def _generic(self, flat, S, A):
         """Leaves that are not cached grids (MeshSDF -- the reference's own tests/test_sdf.py:61-80 -- SphereSDF, nested

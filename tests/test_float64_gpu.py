@@ -175,3 +175,50 @@ def test_composed_and_robot_keep_float64_points_in_float64(A):
     v32, _ = comp(pts.float().cuda())
     assert v32.dtype == torch.float32
     assert (v32.double().cpu().numpy().reshape(A, -1) != oval).mean() > 0.01
+
+
+@pytest.mark.parametrize("A", [1, 3])
+def test_float64_points_over_mesh_leaves_are_transformed_in_float64(A):
+    """sdf.py:395-431 with MeshSDF leaves (the reference's own tests/test_sdf.py:61-80 composition) and float64 points: the
+    transform runs in float64 and its RESULT is what the mesh query rounds to float32 (sdf.py:132) -- one rounding, where a
+    float32 transform rounds every product -- the gradient comes back through R^T in float64 and the first minimum wins.
+    Restated here in numpy around the oracle's mesh query, operation for operation: equal bit for bit."""
+    from pytorch_volumetric_amd import mesh_io
+    objs = [pv.MeshObjectFactory(H.mesh_path("box_template.obj"), scale=0.2), pv.MeshObjectFactory(H.mesh_path("probe.obj"))]
+    objs[0].jitter_seed, objs[1].jitter_seed = 5, 9
+    leaves = [pv.MeshSDF(o) for o in objs]
+    S, P = 2, 3000
+    tfm = H.random_rigid(S * A, seed=7 + A, trans=0.05).double()
+    tfm = tfm + 1e-11 * torch.randn(tfm.shape, dtype=torch.float64, generator=torch.Generator().manual_seed(2)) * \
+        torch.tensor([[1.0], [1.0], [1.0], [0.0]], dtype=torch.float64)
+    comp = pv.ComposedSDF(leaves, None)
+    comp.set_transforms(pv.Transform3d(matrix=tfm), batch_dim=(A,) if A > 1 else None, known_rigid=True)
+    pts = (torch.rand(P, 3, dtype=torch.float64, generator=torch.Generator().manual_seed(4)) - 0.5) * 0.5
+    val, grad = comp(pts.cuda())
+    assert val.dtype == torch.float64 and grad.dtype == torch.float64 and val.shape == ((A, P) if A > 1 else (P,))
+    p, m = pts.numpy(), tfm.numpy().reshape(S, A, 4, 4)
+    best_v = best_g = None
+    rounded_differently = 0
+    for i in range(S):
+        M = m[i]
+        x = np.stack([M[:, r, 0, None] * p[None, :, 0] + M[:, r, 1, None] * p[None, :, 1] + M[:, r, 2, None] * p[None, :, 2]
+                      + M[:, r, 3, None] for r in range(3)], axis=-1)
+        x32 = x.astype(np.float32).reshape(-1, 3)
+        m32, p32 = M.astype(np.float32), p.astype(np.float32)
+        in_f32 = np.stack([m32[:, r, 0, None] * p32[None, :, 0] + m32[:, r, 1, None] * p32[None, :, 1]
+                           + m32[:, r, 2, None] * p32[None, :, 2] + m32[:, r, 3, None] for r in range(3)], axis=-1)
+        rounded_differently += int((in_f32.reshape(-1, 3) != x32).sum())
+        _, od, og, _, _ = oracle.mesh_query(H.oracle_mesh_from_factory(objs[i]), x32, seed=objs[i].jitter_seed)
+        v, g = od.astype(np.float64).reshape(A, P), og.astype(np.float64).reshape(A, P, 3)
+        g = np.stack([M[:, 0, j, None] * g[..., 0] + M[:, 1, j, None] * g[..., 1] + M[:, 2, j, None] * g[..., 2]
+                      for j in range(3)], axis=-1)
+        if best_v is None:
+            best_v, best_g = v, g
+        else:
+            take = (v < best_v) | (np.isnan(v) & ~np.isnan(best_v))
+            best_v, best_g = np.where(take, v, best_v), np.where(take[..., None], g, best_g)
+    assert rounded_differently > 0  # the float32 transform is a different set of query points
+    assert np.array_equal(val.cpu().numpy().reshape(A, P), best_v, equal_nan=True)
+    assert np.array_equal(grad.cpu().numpy().reshape(A, P, 3), best_g, equal_nan=True)
+    v32, g32 = comp(pts.float().cuda())  # float32 points: the float32 kernels, float32 out
+    assert v32.dtype == torch.float32 and np.allclose(v32.double().cpu().numpy().reshape(A, P), best_v, atol=1e-5)
