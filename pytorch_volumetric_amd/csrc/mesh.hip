@@ -706,7 +706,7 @@ PVAMD_DEV bool scan_begin(const MeshArgs& m, GroupShared<WITH_RAY>& g, Wave<WITH
 // flags most of the tiles -- is HANDED OVER: it appends itself to a list in the caller's scratch and stops; a
 // second launch spreads the tiles of every listed group over kHeavyParts blocks of four waves (one per 64-record pass),
 // folding into the group's scratch slots with global atomicMin / atomicAdd, and a third writes the listed groups'
-// outputs.  The few-points path (below) is the same three launches with EVERY group listed up front.
+// outputs.  The few-points path (below) lists EVERY group up front, in a launch of its own, and needs no third launch.
 // scratch: int count | int entries[cap][2] (point group, transform) | u64 best[cap][64] | int hits[cap][64] |
 //          float dir[cap][64][3] (the jittered ray of each point, drawn once) | float reach[cap][64] (an upper bound
 //          of each point's distance to the mesh to start from, +inf when none was worked out) | float bound[cap][16]
@@ -1008,15 +1008,17 @@ __global__ __launch_bounds__(64 * SLICES) void chamfer_mesh_kernel(MeshArgs m, c
 // ---- the listed groups: tiles spread over blocks ----------------------------------------------------------------
 // A wave walks its flagged tiles one after the other; for a heavy group, or with only a few hundred point groups in
 // the whole query, that serial walk -- not throughput -- sets the time.
-//   list    few points: every group is listed up front, slots = (no face, 0 hits); otherwise the scan above lists the
-//           heavy ones as it finds them
-//   parts   (nparts blocks of four waves per listed group)  block y takes the tiles ti % nparts == y, wave w the w-th
-//           64-record pass of each; starts from the slot's bound; folds into the slots with global atomicMin / atomicAdd
-//   finish  (one wave per listed group)  outputs from the slots
+//   list    few points: every group is listed up front (hand_over_all_kernel: rays, a bound and a first candidate per
+//           point, the group's wave bound, its points in processing order); otherwise the scan above lists the heavy
+//           ones as it finds them
+//   parts   (nparts blocks of two or four waves per listed group)  block y takes the tiles ti % nparts == y, its waves
+//           the 64-record passes of each; starts from the slot's bound; folds into the slots with global atomicMin /
+//           atomicAdd.  Few points: the block that folds a group's last part in also writes the group's outputs
+//   finish  (heavy groups only: one wave per listed group)  outputs from the slots
 // (A `first` launch that visited the nearest tile and handed its bound on cost what it saved in the few-points path: C1
 // 0.159 vs 0.158 ms, 1000 points 0.089 vs 0.063 ms without it.)
-// block = one point group, two waves: wave 0 draws the rays and clears the slots, wave 1 works out the bound (two
-// independent serial chains: 5 + 8 us one after the other, 8 side by side)
+// block = one point group, two waves: wave 0 draws the rays, works out the group's bound and stores its points, wave 1
+// works out the per-point bound (two independent serial chains: 5 + 8 us one after the other, 8 side by side)
 __global__ __launch_bounds__(128) void hand_over_all_kernel(MeshArgs m, const int* __restrict__ order, const float* __restrict__ pts,
                                                             int64_t P, uint64_t seed, int64_t index_base, HandOver ho, int groups) {
     __shared__ float reach_of_lane[64];
@@ -1203,10 +1205,10 @@ __global__ __launch_bounds__(64 * WAVES, PVAMD_MESH_PARTS_WAVES) void mesh_parts
 
 __global__ __launch_bounds__(64) void mesh_query_finish_kernel(MeshArgs m, const int* __restrict__ order,
                                                                const float* __restrict__ pts, int64_t P, HandOver ho,
-                                                               int known, QueryOut out) {
-    const int listed = known >= 0 ? known : min(*ho.count, ho.cap);
+                                                               QueryOut out) {
+    const int listed = min(*ho.count, ho.cap);
     for (int slot = blockIdx.x; slot < listed; slot += gridDim.x) {
-        const int64_t k = (int64_t)(known >= 0 ? slot : ho.entries[2 * slot]) * 64 + threadIdx.x;
+        const int64_t k = (int64_t)ho.entries[2 * slot] * 64 + threadIdx.x;
         if (k >= P) continue;
         const int64_t i = order ? (int64_t)order[k] : k;
         write_query(m, out, i, v3(pts[3 * i], pts[3 * i + 1], pts[3 * i + 2]), ho.best[(int64_t)slot * 64 + threadIdx.x],
@@ -1306,22 +1308,13 @@ static MeshArgs mesh_args(const pvamd_mesh_t& mesh) {
 }
 
 constexpr int kMaxFaces = 1 << 26;  // queue entries are record << 6 | lane
-#ifndef PVAMD_MESH_FILL_WAVES
-#define PVAMD_MESH_FILL_WAVES 32768
-#endif
 #ifndef PVAMD_MESH_MAX_SLICES
 #define PVAMD_MESH_MAX_SLICES 8
 #endif
-constexpr int kFillWaves = PVAMD_MESH_FILL_WAVES;  // 4 x (256 CUs x 4 SIMDs x 8 waves): short waves, several rounds
 #ifndef PVAMD_MESH_MIN_PARTS
 #define PVAMD_MESH_MIN_PARTS 4
 #endif
-#ifndef PVAMD_MESH_MAX_PARTS
-#define PVAMD_MESH_MAX_PARTS 32
-#endif
-constexpr int kMaxParts = PVAMD_MESH_MAX_PARTS;     // C1 (157 groups): 0.143 ms with 26-39 parts, 0.155 with 52, 0.17 with 104
-constexpr int kMinParts = PVAMD_MESH_MIN_PARTS;     // below this the single launch wins (A/B on the drill: 30k points 0.27 vs
-                                                    // 0.34 ms with 17 parts; 100k points 0.51 vs 0.39 ms with 5)
+constexpr int kMinParts = PVAMD_MESH_MIN_PARTS;     // fewer parts than this (a mesh of less than ~12 tiles): the single launch
 
 // How many waves share one 64-point group (every wave needs tiles of its own: ti % slices == wave).
 //   many groups           -> 2: the least replicated per-wave work (2 M points on the 62-tile drill: 1.9 ms with 2, 2.05
@@ -1449,7 +1442,6 @@ extern "C" int pvamd_mesh_query(const pvamd_mesh_t* mesh, const float* points, c
                            ho, (int)groups);
         const dim3 grid((unsigned)groups, (unsigned)parts);
         switch (aw) {
-            case 1: hipLaunchKernelGGL((mesh_parts_all_kernel<1>), grid, dim3(64), 0, s, m, order, points, P, jitter_seed, index_base, ho, out); break;
             case 2: hipLaunchKernelGGL((mesh_parts_all_kernel<2>), grid, dim3(128), 0, s, m, order, points, P, jitter_seed, index_base, ho, out); break;
             default: hipLaunchKernelGGL((mesh_parts_all_kernel<4>), grid, dim3(256), 0, s, m, order, points, P, jitter_seed, index_base, ho, out); break;
         }
@@ -1466,7 +1458,7 @@ extern "C" int pvamd_mesh_query(const pvamd_mesh_t* mesh, const float* points, c
     }
     if (heavy) {
         launch_heavy_parts<true>(m, order, nullptr, points, P, jitter_seed, index_base, ho, ntiles, s);
-        hipLaunchKernelGGL(mesh_query_finish_kernel, dim3(list_blocks(ho.cap)), dim3(64), 0, s, m, order, points, P, ho, -1, out);
+        hipLaunchKernelGGL(mesh_query_finish_kernel, dim3(list_blocks(ho.cap)), dim3(64), 0, s, m, order, points, P, ho, out);
     }
     return (int)hipGetLastError();
 }

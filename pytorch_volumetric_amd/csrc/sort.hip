@@ -159,7 +159,7 @@ __global__ __launch_bounds__(256) void order_scatter_kernel(const float* __restr
 // quarter of the call.  Every thread keeps its (up to 16) points and their cells in registers: the points are read once,
 // the curve position is worked out once, and the scan of the 4096 cell counters is a wave scan + 16 wave totals (five
 // barriers in all; the first version read the points three times and scanned with twenty barriers: 25 us for 10k points).
-constexpr int kSmallCells = 4096, kSmallShift = 18, kSmallPer = 16;
+constexpr int kSmallCells = 4096, kSmallPer = 16;  // 16^3 cells: the leading 12 bits of a 30-bit key
 __global__ __launch_bounds__(1024) void order_small_kernel(const float* __restrict__ pts, int P, int* __restrict__ order,
                                                            int* __restrict__ inv, float* __restrict__ sorted_pts) {
     __shared__ unsigned hist[kSmallCells];
@@ -213,7 +213,7 @@ __global__ __launch_bounds__(1024) void order_small_kernel(const float* __restri
         cell[k] = 0u;
         if (1024 * k < P) {  // uniform over the block: the one workgroup is bound by its vector ALUs
 #ifdef PVAMD_ORDER_MORTON
-            cell[k] = morton_key30(x[k], y[k], z[k], blo, bhi) >> kSmallShift;
+            cell[k] = morton_key30(x[k], y[k], z[k], blo, bhi) >> 18;
 #else
             cell[k] = hilbert_cell16(x[k], y[k], z[k], blo, scale);
 #endif

@@ -15,7 +15,7 @@ PARTS = [int(x) for x in sys.argv[3].split(',')] if len(sys.argv) > 3 else (0, 3
 for n in SIZES:
     q = H.uniform_points(n, box[0], box[1], seed=n).cuda()
     row = []
-    for waves in (4, 2):
+    for waves in (4, 2):  # (one wave per block was 0.139 ms on C1 against 0.104: no longer instantiated)
         for parts in PARTS:
             if parts == 0 and waves != 4:
                 continue
