@@ -9,6 +9,8 @@
 // kernels are visibly less compact, C5 7.9 -> 8.8 ms).  Cells come out in Z order; the order of the points inside a cell is whatever the atomics make it -- it may
 // differ from run to run, and no result depends on it (the mesh kernels and the composed kernel return the same bits
 // for any processing order; tests/test_mesh_gpu.py, tests/test_robot_gpu.py).
+#include <cstring>
+#include <rocprim/device/device_radix_sort.hpp>
 #include "common.h"
 #include "morton.h"
 
@@ -154,6 +156,37 @@ __global__ __launch_bounds__(256) void order_scatter_kernel(const float* __restr
     }
 }
 
+// ---- 1.5 million points and more: keys + a library radix sort ----
+// The counting sort's two passes of P random atomics over 2^21 counters (8 MB: they execute memory-side) take 0.28 ms for
+// 2 M points and grow linearly; rocPRIM's radix sort of the same (cell, index) pairs over the 21 key bits takes about a
+// third of that (profiles/r04_mesh_variants.txt, section 10).  It is stable: points of one cell come out in index order.
+__global__ __launch_bounds__(256) void order_keys_kernel(const float* __restrict__ pts, int64_t P, const unsigned* __restrict__ box,
+                                                         unsigned* __restrict__ keys, int* __restrict__ index, int bits_per_axis) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= P) return;
+    float lo[3], hi[3];
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+        lo[d] = order_decode(box[d]);
+        hi[d] = order_decode(box[3 + d]);
+    }
+    keys[i] = PVAMD_ORDER_KEY(pts[3 * i], pts[3 * i + 1], pts[3 * i + 2], lo, hi, bits_per_axis) >> (30 - 3 * bits_per_axis);
+    index[i] = (int)i;
+}
+
+__global__ __launch_bounds__(256) void order_gather_kernel(const float* __restrict__ pts, int64_t P, const int* __restrict__ order,
+                                                           int* __restrict__ inv, float* __restrict__ sorted_pts) {
+    const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= P) return;
+    const int64_t i = order[k];
+    if (inv) inv[i] = (int)k;
+    if (sorted_pts) {
+        sorted_pts[3 * k] = pts[3 * i];
+        sorted_pts[3 * k + 1] = pts[3 * i + 1];
+        sorted_pts[3 * k + 2] = pts[3 * i + 2];
+    }
+}
+
 // ---- up to 16384 points: the whole thing in ONE workgroup (bounds, 16^3-cell histogram in LDS, scan, scatter) ----
 // The seven launches above cost ~4.5 us each whatever their size; for the 10k-point query of BASELINE C1 that was a
 // quarter of the call.  Every thread keeps its (up to 16) points and their cells in registers: the points are read once,
@@ -270,6 +303,27 @@ extern "C" int pvamd_morton_order(const float* points, int64_t P, int32_t* order
         return (int)hipGetLastError();
     }
     unsigned* w = reinterpret_cast<unsigned*>(scratch);
+    if (P >= PVAMD_ORDER_LIBRARY_SORT_FROM) {
+        // scratch: [8] bounds codes | keys [P] | index [P] | sorted keys [P] | the library's temporary storage
+        const int64_t want = (P + 255) / 256;
+        hipLaunchKernelGGL(order_init_kernel, dim3(1), dim3(256), 0, s, w, 0);
+        hipLaunchKernelGGL(order_bounds_kernel, dim3(want < 512 ? (unsigned)want : 512u), dim3(256), 0, s, points, P, w);
+        unsigned* keys = w + kBoxWords;
+        int* index = reinterpret_cast<int*>(keys + P);
+        unsigned* keys_sorted = reinterpret_cast<unsigned*>(index + P);
+        void* temp = reinterpret_cast<void*>((reinterpret_cast<uintptr_t>(keys_sorted + P) + 255) & ~(uintptr_t)255);  // the library's alignment
+        const int bits = PVAMD_MORTON_ORDER_BITS(P);
+        hipLaunchKernelGGL(order_keys_kernel, dim3((unsigned)want), dim3(256), 0, s, points, P, w, keys, index, bits / 3);
+        size_t need = 0;
+        hipError_t e = rocprim::radix_sort_pairs(nullptr, need, keys, keys_sorted, index, order_out, (size_t)P, 0u, (unsigned)bits, s);
+        if (e != hipSuccess) return (int)e;
+        if (need > (size_t)PVAMD_ORDER_LIBRARY_TEMP_BYTES(P)) return PVAMD_E_SHAPE;  // the header's bound no longer holds
+        e = rocprim::radix_sort_pairs(temp, need, keys, keys_sorted, index, order_out, (size_t)P, 0u, (unsigned)bits, s);
+        if (e != hipSuccess) return (int)e;
+        if (inv_out || sorted_points_out)
+            hipLaunchKernelGGL(order_gather_kernel, dim3((unsigned)want), dim3(256), 0, s, points, P, order_out, inv_out, sorted_points_out);
+        return (int)hipGetLastError();
+    }
 #ifdef PVAMD_ORDER_BITS_OVERRIDE
     const int bits = PVAMD_ORDER_BITS_OVERRIDE < PVAMD_MORTON_ORDER_BITS(P) ? PVAMD_ORDER_BITS_OVERRIDE : PVAMD_MORTON_ORDER_BITS(P), shift = 30 - bits, cells = 1 << bits;
 #else

@@ -48,7 +48,8 @@ def curve_cells(pts, bits):
     return key
 
 
-@pytest.mark.parametrize("P", [1, 5, 300, 10_000, 16_384, 16_385, 65_535, 65_536, 262_144, (1 << 20) + 77])
+@pytest.mark.parametrize("P", [1, 5, 300, 10_000, 16_384, 16_385, 65_535, 65_536, 262_144, (1 << 20) + 77, (3 << 19) - 1,
+                               (3 << 19) + 77])
 def test_order_is_a_permutation_that_walks_the_cells_along_the_hilbert_curve(P):
     pts = H.uniform_points(P, [-0.7, -0.7, -0.2], [0.7, 0.7, 1.5], seed=P).cuda()
     order, inv, spts = _lib.morton_order(pts, min_points=0, want_inverse=True, want_sorted=True)
@@ -58,7 +59,10 @@ def test_order_is_a_permutation_that_walks_the_cells_along_the_hilbert_curve(P):
     assert torch.equal(spts, pts[order.long()])
     cells = curve_cells(pts.cpu().numpy(), 21 if P >= (1 << 20) else (18 if P >= (1 << 16) else (15 if P > 16384 else 12)))
     walked = cells[o]
-    assert (np.diff(walked) >= 0).all()  # cells in curve order; inside a cell any order
+    assert (np.diff(walked) >= 0).all()  # cells in curve order; inside a cell any order ...
+    if P >= (3 << 19):  # ... except from 1.5 M points on (a stable library sort of (cell, index) pairs): index order
+        same = np.diff(walked) == 0
+        assert (np.diff(o)[same] > 0).all()
 
 
 def test_a_full_grid_is_walked_cell_to_face_neighbour():
