@@ -454,6 +454,9 @@ PVAMD_DEV void visit_tile(const MeshArgs& m, GroupShared<WITH_RAY>& g, WaveLocal
     STAT(1, 1);
     TIC(t_visit);
     unsigned gm = 0u;
+#ifdef PVAMD_MESH_STATS
+    unsigned mine_groups = 0u;
+#endif
     {
         // lanes = groups: the 16 group spheres at (c, Q) ...
         const bool gv = lane < kGroupsPerTile && lane * kGroup < n;
@@ -477,6 +480,9 @@ PVAMD_DEV void visit_tile(const MeshArgs& m, GroupShared<WITH_RAY>& g, WaveLocal
             bool need = sphere_may_improve(wv.s, dist2, r);
             if (WITH_RAY) need = need || sphere_may_hit(dist2, dot(w, wv.dn), r);
             STAT(9, 1);
+#ifdef PVAMD_MESH_STATS
+            if (need && wv.live) mine_groups |= 1u << b;
+#endif
             if (__any(need && wv.live)) gm |= 1u << b;
         }
     }
@@ -487,6 +493,12 @@ PVAMD_DEV void visit_tile(const MeshArgs& m, GroupShared<WITH_RAY>& g, WaveLocal
     for (int pass = pass_lo; pass < pass_hi; ++pass) {
         if (((gm >> (pass * (64 / kGroup))) & ((1u << (64 / kGroup)) - 1u)) == 0u) continue;
         STAT(2, 1);
+#ifdef PVAMD_MESH_STATS
+        {
+            const int st_points = __popcll(__ballot(((mine_groups >> (pass * (64 / kGroup))) & 0xFu) != 0u));
+            STAT(22, st_points);
+        }
+#endif
         const int idx = pass * 64 + lane;
         const f32x4 a0 = P0[idx], a1 = P1[idx], a2 = P2[idx];
         const float am0 = P4[idx].w;

@@ -14,7 +14,7 @@ NAMES = ["tile_passes (64 tile spheres each)", "tiles_visited", "record_passes (
          "survivors (tested per point)", "closest_pairs", "ray_pairs", "drains", "survivors_any_near (rect per point)",
          "enqueues", "group tests per point", "-", "-", "-", "-", "-", "-", "cycles in drain_closest", "cycles in visit_tile (all)",
          "cycles in survivor loops (incl. their drains)", "cycles in scan_mesh (main launch)", "cycles in seed + greedy",
-         "cycles in parts_of_group"]
+         "cycles in parts_of_group", "points needing a group of the pass (summed over record passes)"]
 
 
 def stats(reset=True):
@@ -33,22 +33,27 @@ def report(tag, P, F):
           f"pairs per drain = {(st[4] + st[5]) / max(1, st[6]):.1f}")
 
 
-m = mesh_io.uv_sphere_mesh(0.1, 250, 200)
-sphere = pv.MeshObjectFactory(mesh=m)
-n = 1 << (int(sys.argv[1]) if len(sys.argv) > 1 else 19)
-src = H.uniform_points(n, [-0.15] * 3, [0.15] * 3, seed=2).cuda()
-W = torch.eye(4).unsqueeze(0).cuda()
-pv.batch_chamfer_dist(W, src, sphere, scale=1000.0)
-stats()
-pv.batch_chamfer_dist(W, src, sphere, scale=1000.0)
-report("C5 chamfer sphere (1/4 of the points)", n, m.faces.shape[0])
+def main():
+    m = mesh_io.uv_sphere_mesh(0.1, 250, 200)
+    sphere = pv.MeshObjectFactory(mesh=m)
+    n = 1 << (int(sys.argv[1]) if len(sys.argv) > 1 else 19)
+    src = H.uniform_points(n, [-0.15] * 3, [0.15] * 3, seed=2).cuda()
+    W = torch.eye(4).unsqueeze(0).cuda()
+    pv.batch_chamfer_dist(W, src, sphere, scale=1000.0)
+    stats()
+    pv.batch_chamfer_dist(W, src, sphere, scale=1000.0)
+    report("C5 chamfer sphere (1/4 of the points)", n, m.faces.shape[0])
 
-drill = pv.MeshObjectFactory(H.mesh_path("ycb_power_drill.npz"))
-stats()
-c = pv.CachedSDF("drill", 0.002, drill.bounding_box(padding=0.05), pv.MeshSDF(drill), device="cuda", cache_path=None)
-report("cache build drill 0.002 pad 0.05", int(np.prod(c.voxels.shape)), 15728)
+    drill = pv.MeshObjectFactory(H.mesh_path("ycb_power_drill.npz"))
+    stats()
+    c = pv.CachedSDF("drill", 0.002, drill.bounding_box(padding=0.05), pv.MeshSDF(drill), device="cuda", cache_path=None)
+    report("cache build drill 0.002 pad 0.05", int(np.prod(c.voxels.shape)), 15728)
 
-pts = H.uniform_points(10000, [-0.2] * 3, [0.2] * 3, seed=1).cuda()
-stats()
-pv.MeshSDF(drill)(pts)
-report("10k random points, drill", 10000, 15728)
+    pts = H.uniform_points(10000, [-0.2] * 3, [0.2] * 3, seed=1).cuda()
+    stats()
+    pv.MeshSDF(drill)(pts)
+    report("10k random points, drill", 10000, 15728)
+
+
+if __name__ == "__main__":
+    main()
