@@ -433,7 +433,7 @@ def leg_c4(torch, dist, Wk, pv, timer, gate, robots, rank, world, steps, padding
     out = {"config": f"C4: RobotSDF 8 links, link grids res 0.02 padding {padding}, A={A} x P={P}, points sharded x{world}",
            "scaling": "strong", "n_gpus": world, "steps": steps, "unit": "(configuration, point) pairs/s",
            "link_grid_voxels": [int(s._packed.shape[0]) for s in robot.sdf.sdfs],
-           "call": "robot(points): Morton-bucketed fused kernel + un-permute, output allocation included" if bucketed
+           "call": "robot(points): points sorted along a Hilbert curve, fused kernel over the buckets + un-permute, output allocation included" if bucketed
                    else "robot.query_into(points, val, grad): fused kernel, caller's buffers",
            "sharded": {"gather": False, "value": pairs / t, "ms_per_step": t / steps * 1e3,
                        "hbm_write_rate": {"achieved_GBs": BYTES_PER_PAIR_C4 * pairs / t / 1e9,
@@ -579,7 +579,8 @@ def leg_c3(torch, Wk, pv, timer, gate, cached, rank, world, steps, small=False):
 def leg_c1(torch, np, Wk, pv, gate, world):
     """BASELINE configs[0]: MeshSDF on the YCB drill (15,728 triangles), 10,000 of the 0.002 m grid points (the reference's
     tests/test_sdf.py:46-48) -- the reference's CPU path (Embree) config, here one call of the GPU mesh query (point sort +
-    list / parts / finish launches).  Every rank runs the whole case (replicas)."""
+    list / parts launches; the block that folds a group's last part in writes its outputs).  Every rank runs the whole case
+    (replicas)."""
     drill = Wk.build_drill()
     sdf = pv.MeshSDF(drill)
     _, grid_pts = pv.get_coordinates_and_points_in_grid(0.002, drill.bounding_box(0.01))
@@ -591,7 +592,7 @@ def leg_c1(torch, np, Wk, pv, gate, world):
             "scaling": "replicas", "n_gpus": world, "unit": "points/s", "value": 10_000 / (call_ms * 1e-3),
             "ms_per_call": call_ms, "ms_per_call_synchronized_each": synced_ms,
             "roofline": valu_roofline("c1_mesh_query", call_ms),
-            "note": "a 10,000-point call is latency- as much as throughput-bound (four dependent launches): the VALU roofline "
+            "note": "a 10,000-point call is latency- as much as throughput-bound (three dependent launches: sort, list, parts): the VALU roofline "
                     "says how busy the ALUs are, not that they are the limit"}
 
 

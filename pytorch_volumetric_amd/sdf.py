@@ -827,7 +827,7 @@ class ComposedSDF(ObjectFrameSDF):
             with _lib.on_device(dev):
                 grids = self._leaf_grids(dev)
                 if self._bucketing_pays(A, P, flat):
-                    # one Morton sort of the shared point set, amortised over the A configurations; the kernel then
+                    # one spatial sort (Hilbert curve) of the shared point set, amortised over the A configurations; the kernel then
                     # sees spatially compact wave tiles and a second pass restores the caller's point order
                     _, inv, spts = _lib.morton_order(flat, min_points=0, want_inverse=True, want_sorted=True)
                     Pp = -(-P // 256) * 256
@@ -1005,7 +1005,7 @@ class ComposedSDF(ObjectFrameSDF):
         best_v = torch.empty((A, P), dtype=torch.float32, device=dev)
         best_g = torch.empty((A, P, 3), dtype=torch.float32, device=dev)
         slab = 65535  # the glue kernels carry the configuration in a grid dimension; the reference takes any batch
-        # MeshSDF leaves want their points in a spatial order; every leaf sees a rigid image of the SAME points, so ONE Morton
+        # MeshSDF leaves want their points in a spatial order; every leaf sees a rigid image of the SAME points, so ONE spatial
         # order of the object-frame points (repeated per configuration) serves all of them instead of a sort per leaf
         shared = None
         if any(isinstance(s, MeshSDF) for s in self.sdfs) and getattr(self, "_rigid", True):

@@ -50,7 +50,7 @@ def warm_up(device=None, freeze_gc=True):
                                                 many.shape[0], _lib.ptr(val), _lib.ptr(grad), None, flags, _lib.stream_ptr()),
                        "pvamd_composed_query")
         comp.bucket_points = True
-        comp(many)                                            # packed records + un-permute, Morton order
+        comp(many)                                            # packed records + un-permute, spatial order
         comp(few.double())                                    # float64 entry
         W = torch.eye(4, device=dev).unsqueeze(0)
         pv.batch_chamfer_dist(W, many[:4096], obj_sdf=cached)        # chamfer_grid.hip
