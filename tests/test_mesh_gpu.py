@@ -58,10 +58,11 @@ def test_c1_drill_10k_grid_points_match_oracle(tile_split):
     assert 0.05 < (d < 0).mean() < 0.9
 
 
-@pytest.mark.parametrize("n", [1, 63, 64, 65, 1000, 12_000, 40_000, 131_072])
+@pytest.mark.parametrize("n", [1, 63, 64, 65, 1000, 4100, 12_000, 16_500, 40_000, 131_072, 524_288, 524_289])
 def test_tile_split_path_for_every_group_count(n):
-    """Partial last group, a single point, counts on both sides of the size where the three-launch path hands over to the
-    single launch, and every waves-per-group choice of the latter."""
+    """Partial last group, a single point, every tiles-per-block rule of the two-launch path (1 / 1.5 / 3 / groups / 512 tiles
+    per block, four and two waves per block), counts on both sides of the 8192 groups where it hands over to the single launch,
+    and every waves-per-group choice of the latter."""
     obj = factory("ycb_power_drill.npz")
     bb = obj.bounding_box(padding_ratio=0.3)
     pts = H.uniform_points(n, bb[:, 0], bb[:, 1], seed=100 + n)
