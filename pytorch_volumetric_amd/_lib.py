@@ -35,6 +35,7 @@ def tiles_floats(F):
 
 
 MESH_SCRATCH_GROUPS = 8192
+MESH_SMALL_POINTS = 16384  # PVAMD_MESH_SMALL_POINTS
 
 
 def mesh_scratch_slots(P):
@@ -45,7 +46,7 @@ def mesh_scratch_slots(P):
 
 def mesh_scratch_bytes(P):
     """PVAMD_MESH_SCRATCH_BYTES(P)"""
-    return 64 + mesh_scratch_slots(P) * (64 * 40 + 8 + 64)
+    return 64 + mesh_scratch_slots(P) * (64 * 40 + 8 + 64) + 24 * MESH_SMALL_POINTS
 
 
 _c_float_p = ctypes.POINTER(ctypes.c_float)
@@ -157,6 +158,10 @@ SIGNATURES = {
                                         ctypes.c_uint64,
                                         ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
                                         ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]),
+    "pvamd_mesh_query_unordered": (ctypes.c_int, [ctypes.POINTER(MeshDesc), ctypes.c_void_p, ctypes.c_int64, ctypes.c_uint64,
+                                                  ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
+                                                  ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
+                                                  ctypes.c_void_p]),
     "pvamd_sample_surface": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int32, ctypes.c_int64, ctypes.c_uint64,
                                             ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]),
     "pvamd_chamfer_mesh": (ctypes.c_int, [ctypes.POINTER(MeshDesc), ctypes.c_void_p, ctypes.c_int32, ctypes.c_void_p,

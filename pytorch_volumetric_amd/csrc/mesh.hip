@@ -20,6 +20,7 @@
 #include "common.h"
 #include "mesh_math.h"
 #include "morton.h"
+#include "order_small.h"
 #include "wave_ops.h"
 
 namespace pvamd {
@@ -733,10 +734,16 @@ struct HandOver {
     float* reach;
     float* pts;    // [cap][64][3]: the group's points (for the chamfer calls: transformed), so that the blocks of the parts launch
                    // read them with one coalesced load instead of the order -> point chain
+    // by POINT INDEX (queries of up to kSmallPoints points that bring no order: pvamd_mesh_query_unordered), filled by the
+    // launch that also sorts, gathered into the slots by the next one
+    unsigned long long* p_best;  // [kSmallPoints]
+    float* p_dir;                // [kSmallPoints][3]
+    float* p_reach;              // [kSmallPoints]
     float* bound;  // [cap][16]: the group's wave bound (c, rho, ray axis, k, rho_k, any lane live), worked out once when it is listed
     int cap;  // 0: nothing is handed over
 };
 constexpr int kBoundFloats = 16;
+constexpr int kSmallPoints = PVAMD_MESH_SMALL_POINTS;
 constexpr int kHandOverHeader = 64;  // bytes
 static __host__ __device__ inline HandOver hand_over(void* scratch, int cap) {
     HandOver h;
@@ -749,6 +756,10 @@ static __host__ __device__ inline HandOver hand_over(void* scratch, int cap) {
     h.reach = reinterpret_cast<float*>(base + kHandOverHeader + (size_t)cap * 8 + (size_t)cap * 64 * 24);
     h.bound = reinterpret_cast<float*>(base + kHandOverHeader + (size_t)cap * 8 + (size_t)cap * 64 * 28);
     h.pts = reinterpret_cast<float*>(base + kHandOverHeader + (size_t)cap * 8 + (size_t)cap * 64 * 28 + (size_t)cap * 64);
+    char* tail = base + kHandOverHeader + (size_t)cap * (8 + 64 * 40 + 64);
+    h.p_best = reinterpret_cast<unsigned long long*>(tail);
+    h.p_dir = reinterpret_cast<float*>(tail + (size_t)kSmallPoints * 8);
+    h.p_reach = reinterpret_cast<float*>(tail + (size_t)kSmallPoints * 20);
     h.cap = scratch ? cap : 0;
     return h;
 }
@@ -1017,6 +1028,66 @@ __global__ __launch_bounds__(64 * SLICES) void chamfer_mesh_kernel(MeshArgs m, c
     chamfer_accumulate(m, wv.s.p, k < N, sh.g.best[lane], scale, W ? out_sum + b : out_sum, i, W ? 0 : per);
 }
 
+// An upper bound of a point's distance to the mesh, by a greedy descent tile -> group -> record along the smallest
+// |p - ctr| + r (every sphere contains whole triangles), and the exact distance to that record's triangle: a candidate like
+// any other (`found` = (d^2, face), what the slots start from) and a bound that is a real distance instead of the far side
+// of a sphere.  The blocks of the parts launch cannot hand each other their finds, so each would otherwise start from the
+// tile-sphere bound (a tile radius too wide) and queue 3x the pairs.  Whole waves call this (v_readlane hands the tile
+// spheres round); a NaN / inf point comes back with no finite bound.
+PVAMD_DEV float greedy_bound(const MeshArgs& m, V3 p, unsigned long long& found) {
+    const int lane = threadIdx.x & 63;
+    float bound = INFINITY;
+    found = kBestInit;
+    if (m.F <= 0) return bound;
+    const int ntiles = (m.F + kTile - 1) / kTile;
+    const f32x4* spheres = reinterpret_cast<const f32x4*>(m.tiles);
+    auto reach_of = [&](f32x4 sp) {
+        const V3 w = v3(sp.x - p.x, sp.y - p.y, sp.z - p.z);
+        return fast_sqrt(dot(w, w)) * 1.00001f + (sp.w + 1.1e-19f);  // slack: 1 ulp + the flushed denormals
+    };
+    int ti = 0;
+    // every lane against every tile sphere: 64 spheres per vector load, handed round with v_readlane
+    for (int base = 0; base < ntiles; base += 64) {
+        const f32x4 mine = spheres[base + lane < ntiles ? base + lane : base];
+        const int n = min(64, ntiles - base);
+        for (int t = 0; t < n; ++t) {
+            const f32x4 sp = {__int_as_float(__builtin_amdgcn_readlane(__float_as_int(mine.x), t)),
+                              __int_as_float(__builtin_amdgcn_readlane(__float_as_int(mine.y), t)),
+                              __int_as_float(__builtin_amdgcn_readlane(__float_as_int(mine.z), t)),
+                              __int_as_float(__builtin_amdgcn_readlane(__float_as_int(mine.w), t))};
+            const float b = reach_of(sp);
+            if (b < bound) { bound = b; ti = base + t; }
+        }
+    }
+    int gi = 0;
+    const int ngroups = (min(kTile, m.F - ti * kTile) + kGroup - 1) / kGroup;
+    for (int k = 0; k < kGroupsPerTile; ++k) {
+        if (k >= ngroups) break;
+        const float b = reach_of(spheres[ntiles + ti * kGroupsPerTile + k]);
+        if (b < bound) { bound = b; gi = k; }
+    }
+    const int j0 = ti * kTile + gi * kGroup;
+    float nearest = INFINITY;
+    int jn = -1;
+    for (int k = 0; k < kGroup; ++k) {
+        if (j0 + k >= m.F) break;
+        const float b = reach_of(record_plane(m.rec, j0 + k, kPlaneSphere));
+        if (b < nearest) { nearest = b; jn = j0 + k; }
+    }
+    bound = fminf(bound, nearest);
+#ifndef PVAMD_MESH_NO_GREEDY_EXACT
+    if (jn >= 0 && fabsf(p.x) < INFINITY && fabsf(p.y) < INFINITY && fabsf(p.z) < INFINITY) {
+        const f32x4 A = record_plane(m.rec, jn, kPlaneA), B = record_plane(m.rec, jn, kPlaneB), C = record_plane(m.rec, jn, kPlaneC);
+        const V3 qp = sub(closest_point_triangle(p, xyz(A), xyz(B), xyz(C)), p);
+        const float d2 = dot(qp, qp);
+        found = ((unsigned long long)(unsigned)__float_as_int(d2) << 32) | (unsigned)__float_as_int(A.w);
+        if (!(found < kBestInit)) found = kBestInit;  // a NaN d2
+        else bound = fminf(bound, fast_sqrt(d2) * 1.00001f + 1.1e-19f);
+    }
+#endif
+    return bound * 1.00001f;  // a NaN / inf point: never a finite bound
+}
+
 // ---- the listed groups: tiles spread over blocks ----------------------------------------------------------------
 // A wave walks its flagged tiles one after the other; for a heavy group, or with only a few hundred point groups in
 // the whole query, that serial walk -- not throughput -- sets the time.
@@ -1065,69 +1136,81 @@ __global__ __launch_bounds__(128) void hand_over_all_kernel(MeshArgs m, const in
         }
         return;
     }
-    // An upper bound of the point's distance to the mesh, by a greedy descent tile -> group -> record along the smallest
-    // |p - ctr| + r (every sphere contains whole triangles).  The blocks of the parts launch cannot hand each other their
-    // finds, so each would otherwise start from the tile-sphere bound (a tile radius too wide) and queue 3x the pairs.
-    float bound = INFINITY;
-    unsigned long long found = kBestInit;
-    if (m.F > 0) {
-        const V3 p = v3(pts[3 * i], pts[3 * i + 1], pts[3 * i + 2]);
-        const int ntiles = (m.F + kTile - 1) / kTile;
-        const f32x4* spheres = reinterpret_cast<const f32x4*>(m.tiles);
-        auto reach_of = [&](f32x4 sp) {
-            const V3 w = v3(sp.x - p.x, sp.y - p.y, sp.z - p.z);
-            return fast_sqrt(dot(w, w)) * 1.00001f + (sp.w + 1.1e-19f);  // slack: 1 ulp + the flushed denormals
-        };
-        int ti = 0;
-        // every lane against every tile sphere: 64 spheres per vector load, handed round with v_readlane (a scalar load per
-        // tile is a memory round trip per tile: 62 of them in a row were half of this launch)
-        for (int base = 0; base < ntiles; base += 64) {
-            const f32x4 mine = spheres[base + lane < ntiles ? base + lane : base];
-            const int n = min(64, ntiles - base);
-            for (int t = 0; t < n; ++t) {
-                const f32x4 sp = {__int_as_float(__builtin_amdgcn_readlane(__float_as_int(mine.x), t)),
-                                  __int_as_float(__builtin_amdgcn_readlane(__float_as_int(mine.y), t)),
-                                  __int_as_float(__builtin_amdgcn_readlane(__float_as_int(mine.z), t)),
-                                  __int_as_float(__builtin_amdgcn_readlane(__float_as_int(mine.w), t))};
-                const float b = reach_of(sp);
-                if (b < bound) { bound = b; ti = base + t; }
-            }
-        }
-        int gi = 0;
-        const int ngroups = (min(kTile, m.F - ti * kTile) + kGroup - 1) / kGroup;
-        for (int k = 0; k < kGroupsPerTile; ++k) {
-            if (k >= ngroups) break;
-            const float b = reach_of(spheres[ntiles + ti * kGroupsPerTile + k]);
-            if (b < bound) { bound = b; gi = k; }
-        }
-        const int j0 = ti * kTile + gi * kGroup;
-        float nearest = INFINITY;
-        int jn = -1;
-        for (int k = 0; k < kGroup; ++k) {
-            if (j0 + k >= m.F) break;
-            const float b = reach_of(record_plane(m.rec, j0 + k, kPlaneSphere));
-            if (b < nearest) { nearest = b; jn = j0 + k; }
-        }
-        bound = fminf(bound, nearest);
-#ifndef PVAMD_MESH_NO_GREEDY_EXACT
-        // the exact distance to that record's triangle: a candidate like any other (the slots start from it), and a bound
-        // that is a real distance instead of the far side of a sphere
-        if (jn >= 0 && fabsf(p.x) < INFINITY && fabsf(p.y) < INFINITY && fabsf(p.z) < INFINITY) {
-            const f32x4 A = record_plane(m.rec, jn, kPlaneA), B = record_plane(m.rec, jn, kPlaneB), C = record_plane(m.rec, jn, kPlaneC);
-            const V3 qp = sub(closest_point_triangle(p, xyz(A), xyz(B), xyz(C)), p);
-            const float d2 = dot(qp, qp);
-            found = ((unsigned long long)(unsigned)__float_as_int(d2) << 32) | (unsigned)__float_as_int(A.w);
-            if (!(found < kBestInit)) found = kBestInit;  // a NaN d2
-            else bound = fminf(bound, fast_sqrt(d2) * 1.00001f + 1.1e-19f);
-        }
-#endif
-    }
+    unsigned long long found;
+    const float bound = greedy_bound(m, v3(pts[3 * i], pts[3 * i + 1], pts[3 * i + 2]), found);
     ho.best[slot] = found;
-    ho.reach[slot] = bound * 1.00001f;  // a NaN / inf point: never a finite bound
-    reach_of_lane[lane] = bound * 1.00001f;
+    ho.reach[slot] = bound;
+    reach_of_lane[lane] = bound;
     __syncthreads();
 }
 __global__ void hand_over_none_kernel(HandOver ho) { *ho.count = 0; }
+
+// Few points that bring no processing order (pvamd_mesh_query_unordered, P <= 16384): the sort is one workgroup on one CU
+// for ~16 us, and what the list launch works out per POINT -- the jittered ray, the greedy bound and the first candidate --
+// does not need the order.  ONE launch: block 0 sorts, every other block takes 512 points in caller order (waves 0-7 the
+// rays, waves 8-15 the bounds: two independent serial chains side by side) and stores by point index; the list launch that
+// follows only gathers them into the slots and works out the groups' wave bounds.  C1: sort 15.8 + list 12.1 us ->
+// 15.8 + 4.
+constexpr int kPrepPoints = 512;
+__global__ __launch_bounds__(1024) void mesh_small_prep_kernel(MeshArgs m, const float* __restrict__ pts, int P, uint64_t seed,
+                                                               int64_t index_base, int* __restrict__ order, HandOver ho) {
+    if (blockIdx.x == 0) {
+        order_small_block(pts, P, order, nullptr, nullptr);
+        return;
+    }
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int i = ((int)blockIdx.x - 1) * kPrepPoints + (wave & 7) * 64 + lane;
+    const int ii = i < P ? i : P - 1;  // whole waves work (greedy_bound hands the tile spheres round the lanes)
+    if (((int)blockIdx.x - 1) * kPrepPoints + (wave & 7) * 64 >= P) return;  // a wave past the end
+    if (wave < 8) {
+        const V3 dir = jitter_dir(m.ray_dir, seed, index_base + ii);
+        if (i < P) {
+            float* o = ho.p_dir + 3 * (int64_t)i;
+            o[0] = dir.x; o[1] = dir.y; o[2] = dir.z;
+        }
+    } else {
+        unsigned long long found;
+        const float bound = greedy_bound(m, v3(pts[3 * ii], pts[3 * ii + 1], pts[3 * ii + 2]), found);
+        if (i < P) {
+            ho.p_best[i] = found;
+            ho.p_reach[i] = bound;
+        }
+    }
+}
+
+// ... and the list launch of that path: one wave per group gathers its points' rays, bounds and candidates into the slot
+// and works out the group's wave bound (what hand_over_all_kernel does in one go when the order comes with the call)
+__global__ __launch_bounds__(64) void hand_over_gather_kernel(MeshArgs m, const int* __restrict__ order, const float* __restrict__ pts,
+                                                              int64_t P, HandOver ho, int groups) {
+    const int g = blockIdx.x, lane = threadIdx.x;
+    const int64_t slot = (int64_t)g * 64 + lane;
+    const int64_t i = point_index(order, slot, P);
+    const V3 dir = v3(ho.p_dir[3 * i], ho.p_dir[3 * i + 1], ho.p_dir[3 * i + 2]);
+    const float reach = ho.p_reach[i];
+    ho.best[slot] = ho.p_best[i];
+    ho.reach[slot] = reach;
+    ho.hits[slot] = 0;
+    float* o = ho.dir + slot * 3;
+    o[0] = dir.x; o[1] = dir.y; o[2] = dir.z;
+    Wave<true> wv{};
+    wv.s.p = v3(pts[3 * i], pts[3 * i + 1], pts[3 * i + 2]);
+    float* q = ho.pts + slot * 3;
+    q[0] = wv.s.p.x; q[1] = wv.s.p.y; q[2] = wv.s.p.z;
+    const float inv_len = 1.f / sqrt_rn(dot(dir, dir));
+    wv.dir = dir;
+    wv.dn = v3(dir.x * inv_len, dir.y * inv_len, dir.z * inv_len);
+    const bool any_live = wave_setup(m, wv);
+    if (any_live) {
+        set_reach(wv.s, reach);
+        refresh_bound(wv);
+    }
+    store_bound(ho.bound + (int64_t)g * kBoundFloats, wv.wb, any_live);
+    if (lane == 0) {
+        ho.entries[2 * g] = g;
+        ho.entries[2 * g + 1] = 0;
+        if (g == 0) *ho.count = groups;
+    }
+}
 
 #ifndef PVAMD_MESH_PARTS_WAVES
 #define PVAMD_MESH_PARTS_WAVES 7  // waves per SIMD the parts kernels are held to (C1: 0.165 ms at the allocator's 5, 0.144 at 6-7;
@@ -1411,9 +1494,10 @@ static void launch_heavy_parts(const MeshArgs& m, const int* order, const float*
     else hipLaunchKernelGGL((mesh_parts_kernel<WITH_RAY, 4>), grid, dim3(256), 0, s, m, order, W, points, P, seed, index_base, ho);
 }
 
-extern "C" int pvamd_mesh_query(const pvamd_mesh_t* mesh, const float* points, const int32_t* order, int64_t P,
-                                uint64_t jitter_seed, int64_t index_base, float* out_closest, float* out_dist, float* out_grad,
-                                int32_t* out_face, float* out_normal, void* scratch, void* stream) {
+// sort_into != nullptr: the caller brings no order; one is worked out into sort_into (P <= kSmallPoints)
+static int mesh_query_impl(const pvamd_mesh_t* mesh, const float* points, const int32_t* order, int32_t* sort_into, int64_t P,
+                           uint64_t jitter_seed, int64_t index_base, float* out_closest, float* out_dist, float* out_grad,
+                           int32_t* out_face, float* out_normal, void* scratch, void* stream) {
     if (P < 0) return PVAMD_E_SHAPE;
     if (P == 0) return 0;
     if (!mesh || !out_dist || !out_grad) return PVAMD_E_NULL;
@@ -1449,9 +1533,22 @@ extern "C" int pvamd_mesh_query(const pvamd_mesh_t* mesh, const float* points, c
         if (parts > ntiles) parts = ntiles;
     }
 #endif
-    if (ho.cap > 0 && groups <= ho.cap && few) {
-        hipLaunchKernelGGL(hand_over_all_kernel, dim3((unsigned)groups), dim3(128), 0, s, m, order, points, P, jitter_seed, index_base,
-                           ho, (int)groups);
+    const bool two_launches = ho.cap > 0 && groups <= ho.cap && few;
+    if (sort_into) {
+        order = sort_into;
+        if (two_launches) {  // the sort in block 0 of the launch that works the rays and bounds out per point
+            hipLaunchKernelGGL(mesh_small_prep_kernel, dim3(1 + (unsigned)((P + kPrepPoints - 1) / kPrepPoints)), dim3(1024), 0, s, m,
+                               points, (int)P, jitter_seed, index_base, sort_into, ho);
+            hipLaunchKernelGGL(hand_over_gather_kernel, dim3((unsigned)groups), dim3(64), 0, s, m, order, points, P, ho, (int)groups);
+        } else {
+            const int rc = pvamd_morton_order(points, P, sort_into, nullptr, nullptr, sort_into, stream);  // (one launch: no scratch used)
+            if (rc != 0) return rc;
+        }
+    }
+    if (two_launches) {
+        if (!sort_into)
+            hipLaunchKernelGGL(hand_over_all_kernel, dim3((unsigned)groups), dim3(128), 0, s, m, order, points, P, jitter_seed,
+                               index_base, ho, (int)groups);
         const dim3 grid((unsigned)groups, (unsigned)parts);
         switch (aw) {
             case 2: hipLaunchKernelGGL((mesh_parts_all_kernel<2>), grid, dim3(128), 0, s, m, order, points, P, jitter_seed, index_base, ho, out); break;
@@ -1473,6 +1570,22 @@ extern "C" int pvamd_mesh_query(const pvamd_mesh_t* mesh, const float* points, c
         hipLaunchKernelGGL(mesh_query_finish_kernel, dim3(list_blocks(ho.cap)), dim3(64), 0, s, m, order, points, P, ho, out);
     }
     return (int)hipGetLastError();
+}
+
+extern "C" int pvamd_mesh_query(const pvamd_mesh_t* mesh, const float* points, const int32_t* order, int64_t P,
+                                uint64_t jitter_seed, int64_t index_base, float* out_closest, float* out_dist, float* out_grad,
+                                int32_t* out_face, float* out_normal, void* scratch, void* stream) {
+    return mesh_query_impl(mesh, points, order, nullptr, P, jitter_seed, index_base, out_closest, out_dist, out_grad, out_face,
+                           out_normal, scratch, stream);
+}
+
+extern "C" int pvamd_mesh_query_unordered(const pvamd_mesh_t* mesh, const float* points, int64_t P, uint64_t jitter_seed,
+                                          int64_t index_base, float* out_closest, float* out_dist, float* out_grad,
+                                          int32_t* out_face, float* out_normal, int32_t* order_scratch, void* scratch, void* stream) {
+    if (P > kSmallPoints) return PVAMD_E_SHAPE;
+    if (P > 0 && !order_scratch) return PVAMD_E_NULL;
+    return mesh_query_impl(mesh, points, nullptr, order_scratch, P, jitter_seed, index_base, out_closest, out_dist, out_grad,
+                           out_face, out_normal, scratch, stream);
 }
 
 // W != nullptr: B transforms x N points, grid (groups, B).  W == nullptr: the flat call -- N = B * per transformed points.

@@ -206,18 +206,27 @@ class ObjectFactory(abc.ABC):
         normal = torch.empty((P, 3), dtype=torch.float32, device=dev) if compute_normal else None
         desc = self._mesh_desc()
         with _lib.on_device(dev):
-            if order is None:
-                order = _lib.morton_order(flat)
             scratch = None
             if P > 0 and getattr(self, "tile_split", True):
                 # lets the kernel spread a point group's tiles over several workgroups (every group of a small query, the
                 # heavy groups of a large one)
                 scratch = torch.empty((_lib.mesh_scratch_bytes(P) // 8,), dtype=torch.int64, device=dev)
-            _lib.check(lib.pvamd_mesh_query(ctypes.byref(desc), _lib.ptr(flat), _lib.ptr(order), P,
-                                            ctypes.c_uint64(self.jitter_seed),
-                                            int(index_base), _lib.ptr(closest), _lib.ptr(dist), _lib.ptr(grad),
-                                            _lib.ptr(face), _lib.ptr(normal), _lib.ptr(scratch), _lib.stream_ptr()),
-                       "pvamd_mesh_query")
+            if order is None and 0 < P <= _lib.MESH_SMALL_POINTS and scratch is not None:
+                # few points: the processing order is worked out inside the query's first launch (one workgroup of it)
+                order_scratch = torch.empty((P,), dtype=torch.int32, device=dev)
+                _lib.check(lib.pvamd_mesh_query_unordered(ctypes.byref(desc), _lib.ptr(flat), P,
+                                                          ctypes.c_uint64(self.jitter_seed), int(index_base),
+                                                          _lib.ptr(closest), _lib.ptr(dist), _lib.ptr(grad), _lib.ptr(face),
+                                                          _lib.ptr(normal), _lib.ptr(order_scratch), _lib.ptr(scratch),
+                                                          _lib.stream_ptr()), "pvamd_mesh_query_unordered")
+            else:
+                if order is None:
+                    order = _lib.morton_order(flat)
+                _lib.check(lib.pvamd_mesh_query(ctypes.byref(desc), _lib.ptr(flat), _lib.ptr(order), P,
+                                                ctypes.c_uint64(self.jitter_seed),
+                                                int(index_base), _lib.ptr(closest), _lib.ptr(dist), _lib.ptr(grad),
+                                                _lib.ptr(face), _lib.ptr(normal), _lib.ptr(scratch), _lib.stream_ptr()),
+                           "pvamd_mesh_query")
         self._last_face_ids = face
         return SDFQuery(_restore(closest, lead, (3,), dtype, device), _restore(dist, lead, (), dtype, device),
                         _restore(grad, lead, (3,), dtype, device),
