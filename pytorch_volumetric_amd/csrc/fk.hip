@@ -85,13 +85,17 @@ __global__ __launch_bounds__(64) void chain_fk_kernel(const pvamd_joint_t* __res
 // (v_mfma_f32_4x4x1_16b_f32, the statement of transform_stack_kernel -- bit-identical to the oracle's fma chains).
 typedef float f32x4m __attribute__((ext_vector_type(4)));
 
-__global__ __launch_bounds__(64) void configure_chain_kernel(const pvamd_joint_t* __restrict__ joints, int F,
+// Four waves per block: the frame walk is wave 0's (lane = configuration); the sines / cosines in front of it and the MFMA
+// chains behind it are spread over all four (A = 200: 17.3 -> 9.8 us per launch, A = 20: 10.2 -> 7.7; they were 7 + 32 serial
+// iterations of one wave at 64 configurations).
+constexpr int kConfigureThreads = 256;
+__global__ __launch_bounds__(kConfigureThreads) void configure_chain_kernel(const pvamd_joint_t* __restrict__ joints, int F,
                                                              const float* __restrict__ q, int A, int M,
                                                              const float* __restrict__ offset_inv, int S,
                                                              float* __restrict__ sincos, float* __restrict__ scratch,
                                                              float* __restrict__ link_world, float* __restrict__ out) {
     extern __shared__ float leafm[];  // [S][12][64]: the leaf frames of this block's 64 configurations, then the joint table
-    const int lane = threadIdx.x;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int a0 = blockIdx.x * 64;
     const int a = a0 + lane;
     const bool live = a < A;
@@ -104,13 +108,13 @@ __global__ __launch_bounds__(64) void configure_chain_kernel(const pvamd_joint_t
         const uint32_t* src = reinterpret_cast<const uint32_t*>(joints);
         uint32_t* dst = reinterpret_cast<uint32_t*>(sj);
         const int words = F * (int)(sizeof(pvamd_joint_t) / 4);
-        for (int w = lane; w < words; w += 64) dst[w] = src[w];
+        for (int w = threadIdx.x; w < words; w += kConfigureThreads) dst[w] = src[w];
     }
     // phase 0: every sine / cosine of the block, lanes = (configuration, joint) pairs -- ~100 instructions each that would
     // otherwise sit in every lane's serial frame walk (with A = 20 only 20 lanes walk; all 64 work here)
     {
         const int nA0 = A - a0 < 64 ? A - a0 : 64;
-        for (int idx = lane; idx < nA0 * M; idx += 64) {
+        for (int idx = threadIdx.x; idx < nA0 * M; idx += kConfigureThreads) {
             const float qv = q[(int64_t)a0 * M + idx];
             const float sv = sinf(qv), cv = cosf(qv);  // (joint values are a few radians: the small-argument path of both)
             ssc[2 * idx] = sv;
@@ -123,7 +127,7 @@ __global__ __launch_bounds__(64) void configure_chain_kernel(const pvamd_joint_t
     }
     __syncthreads();
     float m[12];
-    for (int f = 0; f < F; ++f) {
+    for (int f = 0; f < (wave == 0 ? F : 0); ++f) {
         const pvamd_joint_t& J = sj[f];  // wave-uniform LDS reads (broadcast)
         float P[12];
         if (J.parent < 0) {
@@ -174,12 +178,12 @@ __global__ __launch_bounds__(64) void configure_chain_kernel(const pvamd_joint_t
             }
         }
     }
-    __syncthreads();  // one wave per block: orders the LDS writes above against the regrouped reads below
+    __syncthreads();  // the leaf frames wave 0 left in LDS, for all four waves
     // phase 2: 16 (leaf, configuration) pairs per MFMA chain; lane l: pair = l / 4, j = l % 4
     const int nA = A - a0 < 64 ? A - a0 : 64;
     const int pairs = S * nA;
     const int j = lane & 3;
-    for (int p0 = 0; p0 < pairs; p0 += 16) {
+    for (int p0 = 16 * wave; p0 < pairs; p0 += 16 * (kConfigureThreads / 64)) {
         int p = p0 + (lane >> 2);
         const bool pl = p < pairs;
         if (!pl) p = pairs - 1;  // MFMA needs the whole wave
@@ -223,7 +227,7 @@ extern "C" int pvamd_configure_chain(const pvamd_joint_t* joints, int32_t F, con
     if (M > 0 && !q) return PVAMD_E_NULL;
     const size_t lds = (size_t)S * 12 * 64 * sizeof(float) + (size_t)F * sizeof(pvamd_joint_t) + (size_t)64 * M * 2 * sizeof(float);
     if (lds > 150 * 1024) return PVAMD_E_SHAPE;  // ~50 SDF-carrying links: use pvamd_chain_fk + pvamd_transform_stack
-    hipLaunchKernelGGL(configure_chain_kernel, dim3((A + 63) / 64), dim3(64), lds, (hipStream_t)stream, joints, F, q, A, M,
+    hipLaunchKernelGGL(configure_chain_kernel, dim3((A + 63) / 64), dim3(kConfigureThreads), lds, (hipStream_t)stream, joints, F, q, A, M,
                        offset_inv, S, sincos_out, scratch, link_world_out, stack_out);
     return (int)hipGetLastError();
 }

@@ -32,7 +32,7 @@ class RobotSDF(sdf.ObjectFrameSDF):
         self.dtype = self.chain.dtype
         self.device = self.chain.device
         self.q = None
-        self.object_to_link_frames: typing.Optional[tf.Transform3d] = None
+        self._stack, self._stack_obj = None, None  # object_to_link_frames: the (S*A, 4, 4) stack / the Transform3d around it
         self.joint_names = self.chain.get_joint_parameter_names()
         self.frame_names = self.chain.get_frame_names(exclude_fixed=False)
         self.sdf: typing.Optional[sdf.ComposedSDF] = None
@@ -115,9 +115,21 @@ class RobotSDF(sdf.ObjectFrameSDF):
                 stack = torch.empty_like(link_world_d)
                 _lib.check(lib.pvamd_transform_stack(_lib.ptr(offset_inv), _lib.ptr(link_world_d), S, A,
                                                      _lib.ptr(stack), _lib.stream_ptr()), "pvamd_transform_stack")
-        self.object_to_link_frames = tf.Transform3d(matrix=stack)
+        self._stack, self._stack_obj = stack, None  # the Transform3d is built when object_to_link_frames is read
         if self.sdf is not None:
-            self.sdf.set_transforms(self.object_to_link_frames, batch_dim=self.configuration_batch, known_rigid=True)
+            self.sdf.set_transforms(stack, batch_dim=self.configuration_batch, known_rigid=True)
+
+    @property
+    def object_to_link_frames(self) -> typing.Optional[tf.Transform3d]:
+        """model_to_sdf.py:113: the [A*]S object -> link transforms of the current configuration, leaf-major."""
+        if self._stack_obj is None and self._stack is not None:
+            self._stack_obj = tf.Transform3d(matrix=self._stack)
+        return self._stack_obj
+
+    @object_to_link_frames.setter
+    def object_to_link_frames(self, value):
+        self._stack_obj = value
+        self._stack = None if value is None else tf.as_matrix(value)
 
     def _configure(self, lib, dev, q, A, M, S, offset_inv, stack=None, sincos=None):
         """pvamd_configure_chain on the current stream: q (A, M) float32 on `dev` -> the (S*A, 4, 4) obj->leaf stack.  The
@@ -156,12 +168,14 @@ class RobotSDF(sdf.ObjectFrameSDF):
             hit = self.__dict__.get("_cfg_stack")
             if hit is None or hit[0] != key:  # the stack this entry point writes is its own, re-used call after call
                 stack = torch.empty((S * A, 4, 4), dtype=torch.float32, device=dev)
-                hit = self._cfg_stack = (key, stack, tf.Transform3d(matrix=stack))
+                hit = self._cfg_stack = (key, stack)
             self._configure(lib, dev, q, A, M, S, self._offset_inv_dev(dev), stack=hit[1])
             self.q, self.configuration_batch = q, (A,)
-            self.object_to_link_frames = hit[2]
-            if self.sdf.obj_frame_to_link_frame is not hit[2] or self.sdf.tsf_batch != (A,):
-                self.sdf.set_transforms(hit[2], batch_dim=(A,), known_rigid=True)
+            if self._stack is not hit[1]:
+                self._stack, self._stack_obj = hit[1], None
+            cur = self.sdf._tf_matrix
+            if cur is None or cur.data_ptr() != hit[1].data_ptr() or cur.shape != hit[1].shape or self.sdf.tsf_batch != (A,):
+                self.sdf.set_transforms(hit[1], batch_dim=(A,), known_rigid=True)
             self.sdf._inverse_frames = None  # surface_bounding_box rebuilds them from the (re-written) stack when asked
             self.sdf.query_into(points, out_val, out_grad)
 

@@ -612,7 +612,7 @@ class ComposedSDF(ObjectFrameSDF):
             from the shared object frame to each leaf frame, leaf-major when batched
         """
         self.sdfs = sdfs
-        self.obj_frame_to_link_frame = None
+        self._tf_obj, self._tf_matrix = None, None  # obj_frame_to_link_frame: the Transform3d (built when asked for) / its matrices
         self.link_frame_to_obj_frame = None
         self.tsf_batch = None
         self._tf_dev = None
@@ -620,6 +620,19 @@ class ComposedSDF(ObjectFrameSDF):
         self._grids_key = None
         self._plan = None
         self.set_transforms(obj_frame_to_each_frame)
+
+    @property
+    def obj_frame_to_link_frame(self):
+        """The [B*]S object -> leaf transforms as a Transform3d (sdf.py:343,377).  A planner that re-configures every step
+        hands over a bare (S*A, 4, 4) stack; the object around it is built when somebody asks (1.2 us per step otherwise)."""
+        if self._tf_obj is None and self._tf_matrix is not None:
+            self._tf_obj = tf.Transform3d(matrix=self._tf_matrix)
+        return self._tf_obj
+
+    @obj_frame_to_link_frame.setter
+    def obj_frame_to_link_frame(self, value):
+        self._tf_obj = value
+        self._tf_matrix = None if value is None else tf.as_matrix(value)
 
     def ith_transform_slice(self, i):
         if self.tsf_batch is None:
@@ -646,7 +659,7 @@ class ComposedSDF(ObjectFrameSDF):
                 raise ValueError(f"{S_tsf} transforms != {S} SDFs x batch {batch_dim}")
         # validated: now commit
         self.tsf_batch, self._tf_dev, self._tf_dev64 = batch_dim, None, None
-        self.obj_frame_to_link_frame = tsf if hasattr(tsf, "get_matrix") else tf.Transform3d(matrix=m)
+        self._tf_obj, self._tf_matrix = (tsf if hasattr(tsf, "get_matrix") else None), m
         # The reference inverts with a general matrix inverse (sdf.py:380).  Rigid stacks (every RobotSDF stack, and
         # what the fused kernel's leaf-culling spheres and R^T gradient rotation assume) use the exact R^T form;
         # anything else -- scale, shear, a drifted rotation -- takes the general inverse and the unfused path, whose
@@ -757,7 +770,7 @@ class ComposedSDF(ObjectFrameSDF):
 
     def _tf_device(self, dev):
         if self._tf_dev is None or self._tf_dev.device != dev:
-            self._tf_dev = tf.as_matrix(self.obj_frame_to_link_frame).to(device=dev, dtype=torch.float32).contiguous()
+            self._tf_dev = self._tf_matrix.to(device=dev, dtype=torch.float32).contiguous()
         return self._tf_dev
 
     def _call_plan(self):
@@ -791,7 +804,7 @@ class ComposedSDF(ObjectFrameSDF):
         # allocations in the final shapes around one C-ABI call (RobotSDF.__call__ in a planner's loop)
         if plan is not None and type(p) is torch.Tensor and p.dtype is torch.float32 and p.device == plan[0] and \
                 p.is_contiguous() and p.dim() >= 1 and p.shape[-1] == 3 and self._rigid and \
-                self.obj_frame_to_link_frame is not None and _lib.current_device_index() == plan[1]:
+                self._tf_matrix is not None and _lib.current_device_index() == plan[1]:
             P = p.numel() // 3
             batch = self.tsf_batch
             A = math.prod(batch) if batch is not None else 1
@@ -869,7 +882,7 @@ class ComposedSDF(ObjectFrameSDF):
         P = flat.shape[0]
         tf64 = self.__dict__.get("_tf_dev64")
         if tf64 is None or tf64.device != dev:
-            tf64 = self._tf_dev64 = tf.as_matrix(self.obj_frame_to_link_frame).to(device=dev, dtype=torch.float64).contiguous()
+            tf64 = self._tf_dev64 = self._tf_matrix.to(device=dev, dtype=torch.float64).contiguous()
         val = torch.empty((A, P), dtype=torch.float64, device=dev)
         grad = torch.empty((A, P, 3), dtype=torch.float64, device=dev)
         with _lib.on_device(dev):
@@ -921,7 +934,7 @@ class ComposedSDF(ObjectFrameSDF):
             # float64 query points stay float64 (sdf.py:395-431 over sdf.py:545-547), as in __call__ / _call_f64
             flat = points.detach().reshape(-1, 3).to(device=dev, dtype=torch.float64).contiguous()
             P = flat.shape[0]
-            sub = tf.as_matrix(self.obj_frame_to_link_frame).to(device=dev, dtype=torch.float64).reshape(S, A, 4, 4)[:, pick].contiguous()
+            sub = self._tf_matrix.to(device=dev, dtype=torch.float64).reshape(S, A, 4, 4)[:, pick].contiguous()
             val = torch.empty((count, P), dtype=torch.float64, device=dev)
             grad = torch.empty((count, P, 3), dtype=torch.float64, device=dev)
             if P > 0:
@@ -977,7 +990,7 @@ class ComposedSDF(ObjectFrameSDF):
         pts_shape = points.shape
         flat = points.detach().reshape(-1, 3).to(device=dev, dtype=torch.float64)
         P = flat.shape[0]
-        m = tf.as_matrix(self.obj_frame_to_link_frame).to(device=dev, dtype=torch.float64).reshape(S, A, 4, 4)
+        m = self._tf_matrix.to(device=dev, dtype=torch.float64).reshape(S, A, 4, 4)
         best_v = best_g = None
         for i, sdf in enumerate(self.sdfs):
             M = m[i]  # (A, 4, 4) object frame -> leaf frame
