@@ -296,7 +296,7 @@ int pvamd_morton_keys(const float* points, int64_t P, const float* box, int32_t*
 /* from 1.5 million points on: (cell, index) pairs through rocPRIM's radix sort (stable: the points of a cell in index
  * order) -- keys, indices, sorted keys and the library's temporary storage in scratch                            */
 #define PVAMD_ORDER_LIBRARY_SORT_FROM (3 << 19)  /* 1.5 M: the counting sort still wins at 1 M (0.165 against 0.196 ms) */
-#define PVAMD_ORDER_LIBRARY_TEMP_BYTES(P) (8 * (int64_t)(P) + (4 << 20))  /* + 256 for its alignment, below */
+#define PVAMD_ORDER_LIBRARY_TEMP_BYTES(P) (8 * (int64_t)(P) + (int64_t)(P) / 32 * 4 + (4 << 20))  /* rocPRIM 4.2 asks for 8.063 B per pair (tools/rocprim_temp.hip); + 256 for its alignment, below */
 #define PVAMD_MORTON_ORDER_SCRATCH_BYTES(P) ((P) >= PVAMD_ORDER_LIBRARY_SORT_FROM \
     ? 4 * (8 + 3 * (int64_t)(P)) + 256 + PVAMD_ORDER_LIBRARY_TEMP_BYTES(P) \
     : 4 * (8 + (1 << PVAMD_MORTON_ORDER_BITS(P)) + (int64_t)(P) + 2048))

@@ -310,7 +310,7 @@ def as_query_points(points, device=None, keep_f64=False):
 def morton_order_scratch_words(P):
     """PVAMD_MORTON_ORDER_SCRATCH_BYTES(P) / 4"""
     if P >= (3 << 19):  # the library radix sort: keys, indices, sorted keys + its temporary storage (and its alignment)
-        return 8 + 3 * P + 64 + (8 * P + (4 << 20)) // 4
+        return 8 + 3 * P + 64 + (8 * P + P // 32 * 4 + (4 << 20)) // 4
     return 8 + (1 << (21 if P >= (1 << 20) else (18 if P >= (1 << 16) else 15))) + P + 2048
 
 

@@ -63,8 +63,8 @@ def test_buffer_size_macros_match_the_python_mirrors():
     #include <stdio.h>
     #include "pvamd.h"
     int main(void) {
-      long long v[] = {0, 1, 255, 256, 257, 15728, 99500, 1 << 20, 1 << 21, (1 << 24) + 5};
-      for (int i = 0; i < 10; ++i)
+      long long v[] = {0, 1, 255, 256, 257, 15728, 99500, 1 << 20, 1 << 21, (1 << 24) + 5, 67108877};
+      for (int i = 0; i < 11; ++i)
         printf("%lld %lld %lld %lld\n", (long long)PVAMD_REC_FLOATS(v[i]), (long long)PVAMD_TILES_FLOATS(v[i]),
                (long long)PVAMD_MESH_SCRATCH_BYTES(v[i]), (long long)PVAMD_MORTON_ORDER_SCRATCH_BYTES(v[i]));
       printf("%d %d %d %d\n", PVAMD_TRI_REC, PVAMD_TRI_TILE, PVAMD_TRI_GROUP, PVAMD_MESH_SCRATCH_GROUPS);
@@ -72,7 +72,7 @@ def test_buffer_size_macros_match_the_python_mirrors():
     exe = "/tmp/_pvamd_sizes"
     subprocess.run(["gcc", "-x", "c", "-", "-I", os.path.join(ROOT, "include"), "-o", exe], input=src.encode(), check=True)
     out = [[int(x) for x in line.split()] for line in subprocess.run([exe], capture_output=True, check=True).stdout.decode().splitlines()]
-    for n, row in zip((0, 1, 255, 256, 257, 15728, 99500, 1 << 20, 1 << 21, (1 << 24) + 5), out):
+    for n, row in zip((0, 1, 255, 256, 257, 15728, 99500, 1 << 20, 1 << 21, (1 << 24) + 5, 67108877), out):
         assert row == [_lib.rec_floats(n), _lib.tiles_floats(n), _lib.mesh_scratch_bytes(n),
                        4 * _lib.morton_order_scratch_words(n)], (n, row)
     assert out[-1] == [_lib.TRI_REC, _lib.TRI_TILE, _lib.TRI_GROUP, _lib.MESH_SCRATCH_GROUPS]
