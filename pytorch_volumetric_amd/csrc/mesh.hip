@@ -1523,6 +1523,7 @@ static int mesh_query_impl(const pvamd_mesh_t* mesh, const float* points, const 
     // (in halves of a tile)
     const int half_tiles = groups <= 64 ? 2 : (groups <= 256 ? 3 : (groups < 2048 ? 6 : (int)(groups / 256)));
     int parts = (2 * ntiles + half_tiles - 1) / half_tiles;
+    if (parts > 65535) parts = 65535;  // gridDim.y (a mesh of more than 16.7 M triangles)
     int aw = (int64_t)groups * parts * 4 > 100000 ? 2 : 4;
     bool few = parts >= kMinParts;
 #ifdef PVAMD_MESH_TUNE
