@@ -65,40 +65,6 @@ def morton_order(points, bits=10):
     return np.argsort(key, kind="stable")
 
 
-def hilbert_order(points, bits=10):
-    """Permutation that sorts 3-D points along a Hilbert curve (2^bits cells per axis over their bounding box): consecutive
-    cells are face neighbours at every level, so runs of consecutive triangles (the kernels' groups of 16 and tiles of 256)
-    are compact patches without the Z curve's jumps across octant boundaries.  Skilling's transform, vectorised."""
-    p = np.asarray(points, dtype=np.float64).reshape(-1, 3)
-    if len(p) == 0:
-        return np.zeros((0,), dtype=np.int64)
-    lo, hi = p.min(axis=0), p.max(axis=0)
-    cell = np.clip(((p - lo) / np.maximum(hi - lo, 1e-30) * (2 ** bits - 1)).astype(np.int64), 0, 2 ** bits - 1)
-    X = [cell[:, 0].copy(), cell[:, 1].copy(), cell[:, 2].copy()]
-    Q = 1 << (bits - 1)
-    while Q > 1:
-        P = Q - 1
-        for d in range(3):
-            hit = (X[d] & Q) != 0
-            t = np.where(hit, 0, (X[0] ^ X[d]) & P)
-            X[0] = np.where(hit, X[0] ^ P, X[0] ^ t)
-            if d:
-                X[d] = X[d] ^ t
-        Q >>= 1
-    X[1] ^= X[0]
-    X[2] ^= X[1]
-    t = np.zeros_like(X[0])
-    Q = 1 << (bits - 1)
-    while Q > 1:
-        t = np.where((X[2] & Q) != 0, t ^ (Q - 1), t)
-        Q >>= 1
-    key = np.zeros(len(p), dtype=np.int64)
-    for b in range(bits):
-        for d in range(3):
-            key |= (((X[d] ^ t) >> b) & 1) << (3 * b + (2 - d))
-    return np.argsort(key, kind="stable")
-
-
 def patch_order(points, leaf=16, tile=256):
     """Permutation that puts 3-D points (triangle centroids) into compact runs: a median split along the longest axis of
     the bounding box, recursively, with the split position rounded to whole tiles (then to whole leaves inside a tile), so
