@@ -377,6 +377,17 @@ PVAMD_DEV void tile_passes(const pvamd_grid_t* __restrict__ grids, int S, const 
 // drained 64 at a time with the leaf constants from per-lane global reads (v1) or an LDS table (v3), and a per-lane leaf
 // bitmask walked after the loop (v2) -- the queue's drains and merges are chains of dependent LDS / memory round trips
 // that the wave waits out (SQ_WAIT_ANY + 64 %), and the bitmask walk runs ~3 iterations at 2 live lanes.
+#ifdef PVAMD_COMPOSED_STATS  // tools/band_rate.py: how often the exact-root band is entered (a variant build only)
+__device__ unsigned long long g_band_stats[4];  // 64-point visits | visits that enter the band | lanes in the band | lanes the exact roots turn back
+extern "C" int pvamd_debug_band_stats(unsigned long long* out, int reset) {
+    (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_band_stats), sizeof(g_band_stats));
+    if (reset) { unsigned long long z[4] = {}; (void)hipMemcpyToSymbol(HIP_SYMBOL(g_band_stats), z, sizeof(z)); }
+    return 0;
+}
+#define BAND_STAT(i, v) do { if ((threadIdx.x & 63) == 0) atomicAdd(&g_band_stats[i], (unsigned long long)(v)); } while (0)
+#else
+#define BAND_STAT(i, v)
+#endif
 constexpr float kNearTie = 0.99999952316284179688f;  // 1 - 2^-21: sqrt_rn(n2_b) == sqrt_rn(n2_a) needs n2_b >= n2_a (1 - 2^-22)
 constexpr int kNoLeaf = kUnnormalised - 1;           // "no candidate yet": loses every (value, leaf) tie
 
@@ -456,9 +467,11 @@ PVAMD_DEV void tile_passes_split(const pvamd_grid_t* __restrict__ grids, int S, 
                 uint64_t take = __builtin_amdgcn_ballot_w64(!(n2 >= best[k].n2)) &
                                 __builtin_amdgcn_ballot_w64(best[k].n2 == best[k].n2) & ~vm;
                 const uint64_t near = take & __builtin_amdgcn_ballot_w64(n2 >= mul_rn(best[k].n2, kNearTie));
+                BAND_STAT(0, 1);
                 if (__builtin_expect(near != 0, 0)) {
                     // the two roots may round to the same float32, in which case the incumbent stays: decide exactly
                     const float ra = sqrt_rn_sumsq(best[k].n2), rb = sqrt_rn_sumsq(n2);
+                    BAND_STAT(1, 1); BAND_STAT(2, __popcll(near)); BAND_STAT(3, __popcll(near & __builtin_amdgcn_ballot_w64(!(rb < ra))));
                     take &= ~(near & __builtin_amdgcn_ballot_w64(!(rb < ra)));
                 }
                 const bool t = __builtin_amdgcn_inverse_ballot_w64(take);
