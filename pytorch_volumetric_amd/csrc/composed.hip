@@ -431,9 +431,14 @@ PVAMD_DEV void tile_passes_split(const pvamd_grid_t* __restrict__ grids, int S, 
             const pvamd_grid_t& g = grids[s];
 #pragma unroll
             for (int k = 0; k < PPP; ++k) {
+#if defined(PVAMD_ABLATE) && (PVAMD_ABLATE & 4)  // timing experiment only: the leaf-frame coordinates for one add each (what an
+                // affine computed elsewhere -- on the matrix pipe, say -- could save at the very most)
+                const float x = px[k] + M[3], y = py[k] + M[7], z = pz[k] + M[11];
+#else
                 const float x = affine_row(M[0], M[1], M[2], M[3], px[k], py[k], pz[k]);
                 const float y = affine_row(M[4], M[5], M[6], M[7], px[k], py[k], pz[k]);
                 const float z = affine_row(M[8], M[9], M[10], M[11], px[k], py[k], pz[k]);
+#endif
                 uint64_t vm = in_range_mask(g, x, y, z);
 #if defined(PVAMD_ABLATE) && (PVAMD_ABLATE & 1)  // timing experiment only (tools/r4_ablate.sh): no in-range look-ups
                 vm = 0;
