@@ -12,10 +12,13 @@ GPU, RCCL); under torchrun it uses the ranks it was given.  The headline line is
 C4 (RobotSDF, 200 configurations x 262,144 points) strong-scaled over points with the results left sharded and with
 the RCCL all-gather in the timed step, and C5 (chamfer, 2M points -> 99,500 triangles) with its B-float all-reduce.
 
-Prints ONE JSON line (rank 0).  `value`/`ms_per_step` are the wall time of exactly the K steps asked for.
-`roofline` is the dominant kernel (pvamd::cached_query_wave): algorithmic 28 B/query over the kernel's per-launch
-duration, which is measured live but SEPARATELY from the K timed steps (HIP events around a >=2000-launch hipGraph of
-the same call on the same buffers), so that it does not depend on K.  `cpu_baseline` = the C oracle on the host cores.
+The LAST stdout line (rank 0) is the contract line: compact JSON, < 4 KB (tests/test_bench_launch.py asserts the size),
+built by `compact_line()` from the long record.  The long record (every leg's detail, latency percentiles, README legs) is
+written to `bench_detail.json` (--detail PATH) and to stderr, never to the contract line.  `value` / `ms_per_step` are the
+wall time of exactly the K steps asked for.  `roofline` is the dominant kernel (pvamd::cached_query_wave), 28 B/query over
+its per-launch duration: `frac` uses the committed rocprofv3 kernel-trace average of this command when there is one for
+this point count (profiles/rNN_kernel_stats.json), `frac_events` the live HIP-event figure of this run (a separate
+>= 2000-launch hipGraph of the same call, so it does not depend on K).  `cpu_baseline` = the restatements on the host cores.
 """
 import argparse
 import json
@@ -51,7 +54,9 @@ def parse_args():
     ap.add_argument("--no-large", action="store_true", help="skip the secondary 64M-point (cache-exceeding) run")
     ap.add_argument("--no-legs", action="store_true", help="skip the C4 / C5 legs")
     ap.add_argument("--small-legs", action="store_true", help="functional test: C4 with 8 x 16,384 and C5 with 65,536 points")
-    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="wall budget of the CPU baseline samples (both figures)")
+    ap.add_argument("--cpu-seconds", type=float, default=4.0, help="wall budget of the CPU baseline samples (both figures)")
+    ap.add_argument("--detail", default=os.path.join(ROOT, "bench_detail.json"), help="where rank 0 writes the long record")
+    ap.add_argument("--latency-calls", type=int, default=20_000, help="calls per entry of the call-latency leg")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL over xGMI)")
     ap.add_argument("--share-gpu", action="store_true",
                     help="functional test on a 1-GPU box: every rank uses cuda:0 and collectives go through gloo")
@@ -175,12 +180,12 @@ def time_eager_kernel(torch, np, fn, reps):
 
 
 def cpu_baseline(torch, np, cached, pts, seconds):
-    """The reference's CPU path for this workload, restated (the reference itself cannot be imported: third-party packages
-    absent), on the host cores with the OpenMP / torch threads pinned (OMP_PROC_BIND=close, OMP_PLACES=cores: set in main()
-    before either runtime starts).  `value` = the OP-FOR-OP torch restatement of sdf.py:535-571 (oracle/torch_opforop.py: the
-    ~25 stock ops and their intermediates -- what a reference user runs on CPU); `fused_port` = the one-pass C/OpenMP
-    restatement (oracle/pvamd_oracle.c), faster than anything the reference executes.  Each figure is the MEDIAN of 5
-    samples of (budget / 5) seconds each.  Only reached after every GPU timing is done."""
+    """The reference's CPU path for this workload, restated (the reference cannot be imported: third-party packages absent), on
+    the host cores with the threads pinned (OMP_PROC_BIND=close, OMP_PLACES=cores: set in main() before either runtime starts).
+    `value` = `baseline_opforop`: the op-for-op torch restatement of sdf.py:535-571 (oracle/torch_opforop.py: the ~25 stock ops
+    and their intermediates -- what a reference user runs on CPU); `baseline_fused` = the one-pass C / OpenMP restatement
+    (oracle/pvamd_oracle.c), faster than anything the reference executes.  Each figure is the MEDIAN of 3 samples of whole
+    passes; 60 % of the budget goes to the first, 40 % to the second.  Only reached after every GPU timing is done."""
     from oracle import oracle
     from oracle.torch_opforop import CachedOpForOp
     from tests import helpers as H
@@ -188,14 +193,12 @@ def cpu_baseline(torch, np, cached, pts, seconds):
     host_pts = pts.cpu().numpy()
     n_pts = len(host_pts)
 
-    def samples(fn, budget, count=5):
-        """median throughput of `count` samples, each as many whole passes over the points as fit budget / count seconds"""
-        for _ in range(3):
-            fn()  # warm: thread pools up, pages touched
+    def samples(fn, budget, count=3):
+        fn()  # warm: thread pools up, pages touched
         per, t0 = [], time.perf_counter()
         for _ in range(count):
             a, passes = time.perf_counter(), 0
-            while passes == 0 or time.perf_counter() - a < budget / count:
+            while passes == 0 or time.perf_counter() - a < budget / (count + 1):
                 fn()
                 passes += 1
             per.append(n_pts * passes / (time.perf_counter() - a))
@@ -207,21 +210,17 @@ def cpu_baseline(torch, np, cached, pts, seconds):
                         cached.bb.cpu())
     tp = pts.cpu()
     o_med, o_min, o_max, o_n, o_t = samples(lambda: ref(tp), seconds * 0.6)
-    oracle.cached_query(og, host_pts[:1000])
     f_med, f_min, f_max, f_n, f_t = samples(lambda: oracle.cached_query(og, host_pts), seconds * 0.4)
     pin = {k: os.environ.get(k) for k in ("OMP_PROC_BIND", "OMP_PLACES", "OMP_NUM_THREADS")}
-    return {"value": o_med, "unit": "queries/s", "cores": torch.get_num_threads(), "kind": "op-for-op restatement",
-            "what": "median of the samples of the op-for-op torch restatement of CachedSDF.__call__ (sdf.py:535-571, "
-                    "oracle/torch_opforop.py) on the host cores -- the reference's own op sequence with its intermediates; the "
-                    "absent third-party view (multidim_indexing) is replaced by the three expressions its call sites amount to",
-            "sample": f"median of {o_n} samples of whole passes over {n_pts} of the same query points, {o_t:.1f} s wall in all, "
-                      f"{torch.get_num_threads()} torch threads",
+    return {"value": o_med, "unit": "queries/s", "cores": torch.get_num_threads(), "kind": "port",
+            "baseline_opforop": o_med, "baseline_fused": f_med, "value_is": "baseline_opforop",
+            "sample": f"median of {o_n} samples of whole passes over the same {n_pts} points, {o_t:.1f} s wall",
             "spread": {"min": o_min, "max": o_max, "samples": o_n},
             "host_cpus": os.cpu_count(), "thread_pinning": pin,
+            "opforop_source": "oracle/torch_opforop.py (sdf.py:535-571 op for op, torch CPU)",
             "fused_port": {"value": f_med, "unit": "queries/s", "cores": oracle.num_threads(), "kind": "port",
-                           "what": "oracle/pvamd_oracle.c: one fused pass per point (C, OpenMP), no intermediates",
-                           "sample": f"median of {f_n} samples of whole passes over {n_pts} points, {f_t:.1f} s wall in all, "
-                                     f"{oracle.num_threads()} OpenMP threads",
+                           "source": "oracle/pvamd_oracle.c (one fused pass per point, C + OpenMP)",
+                           "sample": f"median of {f_n} samples of whole passes over {n_pts} points, {f_t:.1f} s wall",
                            "spread": {"min": f_min, "max": f_max, "samples": f_n}}}
 
 
@@ -245,25 +244,28 @@ def time_calls(torch, np, fn, reps=400):
     return back_to_back * 1e3, float(np.median(each)) * 1e3
 
 
-VALU_PROFILE = "r04_valu_session.json"  # tools/valu_session.sh: counters, kernel time, opcode mix and issue rates of ONE session
+PROFILE_ROUNDS = ("r05", "r04")  # committed profile files are looked up newest round first
 
 
-def oracle_pin_string(np):
-    """What the oracle is pinned to, read from the booleans tests/golden/make_golden.py wrote into the committed vectors."""
+def profile_path(suffix):
+    for rnd in PROFILE_ROUNDS:
+        path = os.path.join(ROOT, "profiles", f"{rnd}_{suffix}")
+        if os.path.exists(path):
+            return path
+    return None
+
+
+def oracle_pins(np):
+    """What the oracle is pinned to: the booleans tests/golden/make_golden.py wrote into the committed vectors (False = the
+    vectors were generated over a shim of that third-party package, i.e. parity unpinned there)."""
     try:
         z = np.load(os.path.join(ROOT, "tests", "golden", "reference_lifted.npz"))
-        pins = {k: bool(z[f"pinned/{k}"]) for k in ("view", "transform", "embree")}
+        return {k: bool(z[f"pinned/{k}"]) for k in ("view", "transform", "embree")}
     except Exception:
-        pins = {"view": False, "transform": False, "embree": False}
-    real = [k for k, v in pins.items() if v]
-    if all(pins.values()):
-        return "oracle/pvamd_oracle.c (in-repo CPU restatement), pinned to vectors generated over the real multidim_indexing / pytorch_kinematics / open3d"
-    return ("oracle/pvamd_oracle.c (in-repo CPU restatement; third-party arithmetic UNPINNED: golden vectors generated over "
-            + ("shims of multidim_indexing's view, pytorch_kinematics' Transform3d and no Embree scene" if not real else
-               f"the real {real} and shims for the rest") + " -- tests/golden/make_golden.py, pinned/* in reference_lifted.npz)")
+        return {"view": False, "transform": False, "embree": False}
 
 
-def call_latency(torch, np, fn, calls=100_000, drain_every=256):
+def call_latency(torch, np, fn, calls=20_000, drain_every=256):
     """Host time of every single call of a loop (perf_counter around the call; the launch is asynchronous), the queue drained
     every `drain_every` calls outside the timed span: what a planner that issues one query per step sees, incl. the tail."""
     for _ in range(200):
@@ -283,39 +285,45 @@ def call_latency(torch, np, fn, calls=100_000, drain_every=256):
             "p99_9_us": float(np.percentile(us, 99.9)), "max_us": float(us.max()), "calls_above_1ms": int((us > 1000).sum())}
 
 
+def valu_session():
+    path = profile_path("valu_session.json")
+    return (json.load(open(path)), os.path.basename(path)) if path else (None, None)
+
+
+def valu_model():
+    """Once per record: how every VALU roofline below is formed (the per-leg objects carry numbers only)."""
+    prof, name = valu_session()
+    return {"file": None if name is None else f"profiles/{name}", "n_simd": N_SIMD,
+            "issue_rates_ns": None if prof is None else prof["issue_rates_ns"],
+            "ceiling": "1024 SIMDs / max(f_slow * t_slow, t_best) wave64 VALU inst/s, with the call's own dynamic opcode mix",
+            "f_slow": "share of VALU instructions that are not an f32 add / mul / fma (SQ_INSTS_VALU_* class counters)",
+            "frac": "SQ_INSTS_VALU and kernel time of ONE rocprofv3 session (tools/valu_session.sh) against that ceiling",
+            "frac_this_run": "the same instruction count over THIS run's time"}
+
+
 def valu_roofline(kernel_key, ms, launches_per_step=1):
-    """Roofline object of a vector-ALU-bound leg, every number from ONE committed rocprofv3 session (profiles/
-    r04_valu_session.json, tools/valu_session.sh): SQ_INSTS_VALU per call, the kernels' time in that session, the dynamic
-    opcode mix of the call (SQ_INSTS_VALU_* class counters) and the two issue rates measured by tools/valu_rate.bin on the
-    same box minutes apart.  `frac` = this run's time against the ceiling of the call's own mix (below);
-    `frac_same_session` = the session's own kernel time against it."""
-    path = os.path.join(ROOT, "profiles", VALU_PROFILE)
+    """Roofline object of a vector-ALU-bound leg.  Every number behind `frac` comes from ONE committed rocprofv3 session
+    (profiles/rNN_valu_session.json): SQ_INSTS_VALU per call, the kernels' time in that session, the dynamic opcode mix and the
+    issue rates tools/valu_rate.bin measured minutes apart on the same box.  `frac_this_run` divides the session's instruction
+    count by this run's time instead (numerator and time from different sessions: secondary)."""
+    prof, name = valu_session()
     try:
-        prof = json.load(open(path))
         entry = prof["workloads"][kernel_key]
         rates = prof["issue_rates_ns"]
     except Exception as exc:
-        return {"bound": "valu", "achieved": None, "note": f"no committed session for {kernel_key} in profiles/{VALU_PROFILE}: {exc!r}"}
+        return {"bound": "valu", "achieved": None, "frac": None, "note": f"no committed session for {kernel_key}: {exc!r}"[:120]}
     inst = entry["SQ_INSTS_VALU"] * launches_per_step
     f_slow = entry["mix"]["slow_fraction"]
-    # ns per wave64 instruction per SIMD at which THIS mix can issue at best: its slow-group share alone (f_slow x t_slow), or
-    # the fastest stream the micro-benchmark found at all (fast- and slow-group opcodes issue side by side: a weighted sum
-    # of the two rates is NOT a ceiling -- C4 runs 9 % above it)
+    # ns per wave64 instruction per SIMD at which THIS mix can issue at best: its slow-group share alone, or the fastest stream
+    # the micro-benchmark found at all (fast and slow opcodes issue side by side: a weighted sum of the two is NOT a ceiling)
     t_mix = max(f_slow * rates["slow"], rates["best_any"])
     peak = N_SIMD / (t_mix * 1e-9)
-    achieved = inst / (ms * 1e-3)
     sess_ms = entry["kernel_ms_same_session"] * launches_per_step
-    return {"bound": "valu", "achieved": achieved / 1e9, "peak": peak / 1e9, "unit": "G wave64 VALU inst/s", "frac": achieved / peak,
-            "frac_same_session": inst / (sess_ms * 1e-3) / peak, "kernel_ms_same_session": sess_ms,
-            "valu_inst_per_step": inst, "active_lanes_per_inst": entry.get("active_lanes"),
-            "opcode_mix": entry["mix"], "issue_rates_ns": rates,
-            "reading": "ceiling = 1024 SIMDs / max(f_slow x t_slow, t_best) with the call's own dynamic opcode mix (f_slow: every "
-                       "instruction that is not an f32 add / mul / fma -- compares, v_cndmask, min/max/med3, converts, integer ops, "
-                       "transcendentals, f64) and the issue times tools/valu_rate.bin measured in the same session (t_slow: a "
-                       "stream of slow-group opcodes; t_best: the fastest stream of the whole table)",
-            "source": f"profiles/{VALU_PROFILE}[workloads][{kernel_key}]: {entry.get('workload')} ({entry.get('command')}); "
-                      "instruction counts, opcode mix, session kernel time and issue rates all read from that one committed "
-                      "file; `achieved` divides its SQ_INSTS_VALU by THIS run's time"}
+    achieved = inst / (sess_ms * 1e-3)
+    return {"bound": "valu", "achieved": achieved / 1e9, "peak": peak / 1e9, "unit": "G wave64 VALU inst/s",
+            "frac": achieved / peak, "frac_this_run": inst / (ms * 1e-3) / peak, "kernel_ms_same_session": sess_ms,
+            "valu_inst_per_step": inst, "active_lanes_per_inst": entry.get("active_lanes"), "slow_fraction": f_slow,
+            "session": f"profiles/{name}[workloads][{kernel_key}]"}
 
 
 class LegSkipped(Exception):
@@ -357,36 +365,30 @@ class Gate:
 
 
 def read_traffic(P):
-    """HBM-side bytes per launch from the committed PMC passes (NOT measured in this run: rocprofv3 --pmc cannot run
-    inside the benchmark)."""
-    for name in ("r04_traffic.json", "r03_traffic.json", "r02_traffic.json"):
-        path = os.path.join(ROOT, "profiles", name)
-        if os.path.exists(path):
-            try:
-                tj = json.load(open(path))
-                if tj.get("points") == P:
-                    return tj.get("hbm_bytes_per_launch"), (
-                        f"profiles/{name}: rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE passes of this workload "
-                        "(FETCH_SIZE x2, the gfx950 correction of MI355X_MICROARCH.md); read from the committed file, "
-                        "not measured in this run")
-            except Exception:
-                pass
-    return None, "no committed PMC pass for this point count"
+    """HBM-side bytes per launch from the committed PMC passes (NOT measured in this run: rocprofv3 --pmc cannot run inside the
+    benchmark); FETCH_SIZE x2 is the gfx950 correction of MI355X_MICROARCH.md."""
+    path = profile_path("traffic.json")
+    if path:
+        try:
+            tj = json.load(open(path))
+            if tj.get("points") == P:
+                return tj.get("hbm_bytes_per_launch"), f"profiles/{os.path.basename(path)} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes)"
+        except Exception:
+            pass
+    return None, None
 
 
 def read_rocprof_kernel_us(P):
-    """Average duration of the dominant kernel's launches at this point count in the committed rocprofv3 --kernel-trace of
-    the driver-shaped command (tools/profile_bench.sh -> profiles/r04_kernel_stats.json), for `roofline.frac_rocprof`."""
-    path = os.path.join(ROOT, "profiles", "r04_kernel_stats.json")
+    """Average duration of the dominant kernel's launches at this point count in the committed rocprofv3 --kernel-trace of the
+    driver-shaped command (tools/profile_bench.sh -> profiles/rNN_kernel_stats.json)."""
+    path = profile_path("kernel_stats.json")
     try:
-        ks = json.load(open(path))
-        row = ks["dominant"]
+        row = json.load(open(path))["dominant"]
         if row.get("points") == P:
-            return row["avg_us"], (f"profiles/r04_kernel_stats.json: rocprofv3 --kernel-trace of `{ks.get('command')}`, "
-                                   f"{row['calls']} launches of {row['kernel']}; read from the committed file")
+            return row["avg_us"], int(row["calls"]), f"profiles/{os.path.basename(path)}"
     except Exception:
         pass
-    return None, "no committed kernel trace for this point count"
+    return None, None, None
 
 
 # ------------------------------------------------------------------------------------------------ legs: C4 and C5
@@ -401,7 +403,10 @@ def leg_c4(torch, dist, Wk, pv, timer, gate, robots, rank, world, steps, padding
     sharded over the ranks (strong scaling: the total work is fixed).  Leg 1 leaves (val, grad) sharded -- no
     collective; leg 2 times ShardedSDF.__call__: query into packed records + ONE RCCL all-gather + the unpack kernel that
     writes (A, P[, 3]) order (model_to_sdf.py:117-125 on every rank's slice); leg 3 shards the CONFIGURATIONS instead
-    (rows gathered in place, no unpack: SURVEY.md 8(e))."""
+    (rows gathered in place, no unpack: SURVEY.md 8(e)).  100 KB link grids: the allocation-free entry (query_into, what a
+    planner loop calls).  README-size grids: the drop-in call robot(points), which sorts the shared point set along a Hilbert
+    curve once per call and un-permutes (ComposedSDF.bucket_points), output allocation included; for those the leg also times
+    the prepared form (prepare_points once, query_prepared per step: no sort; order="sorted" also drops the un-permute)."""
     A, P = (8, 1 << 14) if small else (200, 1 << 18)
     robot = build_robot(Wk, robots, padding)
     robot.set_joint_configuration(Wk.c4_joint_configs(A))
@@ -412,8 +417,6 @@ def leg_c4(torch, dist, Wk, pv, timer, gate, robots, rank, world, steps, padding
     val = torch.empty((A, n), dtype=torch.float32, device="cuda")
     grad = torch.empty((A, n, 3), dtype=torch.float32, device="cuda")
 
-    # 100 KB link grids: the allocation-free entry (query_into, what a planner loop would call).  README-size grids: the
-    # drop-in call robot(points), which sorts the shared point set once per call and un-permutes (ComposedSDF.bucket_points)
     bucketed = robot.sdf._bucketing_pays(A, n, mine)
     if bucketed:
         def one_step():
@@ -430,22 +433,34 @@ def leg_c4(torch, dist, Wk, pv, timer, gate, robots, rank, world, steps, padding
     gate()
     t = timer(sharded_steps)
     pairs = A * P * steps
-    out = {"config": f"C4: RobotSDF 8 links, link grids res 0.02 padding {padding}, A={A} x P={P}, points sharded x{world}",
+    out = {"config": f"C4: RobotSDF 8 links, grids res 0.02 padding {padding}, A={A} x P={P}, points sharded x{world}",
            "scaling": "strong", "n_gpus": world, "steps": steps, "unit": "(configuration, point) pairs/s",
            "link_grid_voxels": [int(s._packed.shape[0]) for s in robot.sdf.sdfs],
-           "call": "robot(points): points sorted along a Hilbert curve, fused kernel over the buckets + un-permute, output allocation included" if bucketed
+           "call": "robot(points): Hilbert sort + fused kernel + un-permute, outputs allocated" if bucketed
                    else "robot.query_into(points, val, grad): fused kernel, caller's buffers",
            "sharded": {"gather": False, "value": pairs / t, "ms_per_step": t / steps * 1e3,
-                       "hbm_write_rate": {"achieved_GBs": BYTES_PER_PAIR_C4 * pairs / t / 1e9,
-                                          "frac_of_hbm_peak": BYTES_PER_PAIR_C4 * pairs / t / 1e9 / (HBM_PEAK_GBS * world),
-                                          "note": "16 B written per pair; NOT what bounds this kernel"}}}
+                       "hbm_write_GBs": BYTES_PER_PAIR_C4 * pairs / t / 1e9,
+                       "frac_of_hbm_peak": BYTES_PER_PAIR_C4 * pairs / t / 1e9 / (HBM_PEAK_GBS * world)}}
     if not bucketed and not small and world == 1:
         out["sharded"]["roofline"] = valu_roofline("c4_composed_query_wave", t / steps * 1e3)
     if bucketed:
-        out["sharded"]["bound"] = ("L1->L2 request rate: the un-permute pass is A x P 16-byte gathers (one request each) at the "
-                                   "chip's gather ceiling of ~1.15e11/s (profiles/r03_cq64_counters.md) = "
-                                   f"{A * n / 1.15e11 * 1e3:.2f} ms of this step, the sorted query kernel is gather-bound at ~90 % L2 "
-                                   "hits (profiles/r02_readme_grid_counters.txt); the direct, unsorted call takes ~3x as long")
+        out["sharded"]["bound"] = "L1->L2 request rate (16-byte gathers; profiles/r04_unpermute.txt, r03_cq64_counters.md)"
+        if hasattr(robot.sdf, "prepare_points"):
+            handle = robot.sdf.prepare_points(mine)
+            for order in ("sorted", "caller"):
+                def prepared_step(order=order):
+                    return robot.sdf.query_prepared(handle, order=order)
+
+                settle(torch, prepared_step, seconds=0.1)
+                tp = timer(lambda: [prepared_step() for _ in range(steps)])
+                out["sharded"][f"prepared_{order}_ms"] = tp / steps * 1e3
+            v0, g0 = robot(mine)
+            v1, g1 = robot.sdf.query_prepared(handle, order="caller")
+            v2, g2 = robot.sdf.query_prepared(handle, order="sorted")
+            idx = handle.order.long()
+            out["sharded"]["prepared_equals_direct"] = bool(torch.equal(v0, v1) and torch.equal(g0, g1) and
+                                                            torch.equal(v0[:, idx], v2) and torch.equal(g0[:, idx], g2))
+            del v0, g0, v1, g1, v2, g2, handle
     if with_gather and (world > 1 or use_pg):
         sharded = pv.ShardedSDF(robot, gather=True, compute_device=torch.device("cuda"))
         gsteps = max(2, steps // 4)
@@ -472,12 +487,10 @@ def leg_c4(torch, dist, Wk, pv, timer, gate, robots, rank, world, steps, padding
                            (check["backend"] == "nccl" or world == 1 or getattr(sharded, "last_path", "") != "packed"))
         out["gathered"] = {"gather": True, "value": A * P * gsteps / tg, "ms_per_step": tg / gsteps * 1e3, "steps": gsteps,
                            "self_check": check,
-                           "collective": f"packed (val, grad) records, all_gather_into_tensor x1 ({dist.get_backend()}), "
-                                         "unpack kernel writes (A, P) / (A, P, 3)",
+                           "collective": f"packed (val, grad) records, all_gather_into_tensor x1 ({dist.get_backend()}), unpack kernel",
                            "bytes_received_per_rank": recv,
                            "xgmi_lower_bound_ms": None if not recv or world < 2 else recv / (world - 1) / (XGMI_LINK_GBS * 1e9) * 1e3,
-                           "xgmi_note": f"each of the {world - 1} peers sends its slab over its own ~{XGMI_LINK_GBS:.0f} GB/s link, "
-                                        "in parallel (full mesh): time >= one slab / link rate; a ring would take (W - 1) x that",
+                           "xgmi_model": f"full mesh: each of {world - 1} peers sends its slab over its own {XGMI_LINK_GBS:.0f} GB/s link",
                            "path": getattr(sharded, "last_path", None), "equals_unsharded_call": same,
                            "output_shape": [list(full[0].shape), list(full[1].shape)]}
         if not bucketed:
@@ -494,12 +507,11 @@ def leg_c4(torch, dist, Wk, pv, timer, gate, robots, rank, world, steps, padding
             same_c = bool(torch.equal(cfull[0][:, :65536], ref[0]) and torch.equal(cfull[1][:, :65536], ref[1]))
             out["gathered_by_configs"] = {"gather": True, "shard": "configs", "value": A * P * gsteps / tc,
                                           "ms_per_step": tc / gsteps * 1e3, "steps": gsteps,
-                                          "collective": f"all_gather_into_tensor x2 (val rows, grad rows; {dist.get_backend()}) "
-                                                        "straight into (A, P) / (A, P, 3): no packed records, no unpack pass",
+                                          "collective": f"all_gather_into_tensor x2 (val rows, grad rows; {dist.get_backend()}), no unpack",
                                           "bytes_received_per_rank": getattr(by_cfg, "bytes_received_per_rank", None),
                                           "equals_unsharded_call": same_c}
     else:
-        out["gathered"] = None if world > 1 else {"gather": True, "note": "single rank: nothing to gather, same as `sharded`"}
+        out["gathered"] = None
     return out
 
 
@@ -509,7 +521,9 @@ def leg_readme(torch, np, Wk, pv, timer, gate, robots, rank, world, A):
     101 slice `get_coordinates_and_points_in_grid(0.01, [[-1, 0.5], [0.02, 0.02], [-0.2, 0.8]])` -- through the drop-in
     call `robot(points)` (output allocation included).  Every rank runs the whole case (replicas: it is far too small to
     shard).  NOT like for like with the published figure: synthetic 7-DOF arm (the KUKA assets are not available
-    offline), one MI355X against an RTX 2080 Ti."""
+    offline), one MI355X against an RTX 2080 Ti.  `configure_plus_query_ms` = robot.configure_and_query_into(q_on_gpu, points,
+    val, grad) back to back (pvamd_configure_chain: sin / cos + FK + offset^-1 o world^-1 in ONE launch, then the query);
+    `_graph_ms` = the same two kernels replayed from a hipGraph (HIP events / 100)."""
     robot = build_robot(Wk, robots, 1.0)
     th = Wk.c4_joint_configs(A)
     _, pts = pv.get_coordinates_and_points_in_grid(0.01, np.array([[-1, 0.5], [0.02, 0.02], [-0.2, 0.8]]))
@@ -522,34 +536,26 @@ def leg_readme(torch, np, Wk, pv, timer, gate, robots, rank, world, A):
     th_dev = th.cuda().contiguous()
     sjc_dev_ms, _ = time_calls(torch, np, lambda: robot.set_joint_configuration(th_dev), reps=100)  # already on the GPU
     val, grad = robot(pts)
-    # a planner's step: new joint values (on the GPU) -> configure -> query, into the caller's buffers; eagerly and as one
-    # replayed hipGraph of the two kernels
     both_ms, _ = time_calls(torch, np, lambda: robot.configure_and_query_into(th_dev, pts, val, grad), reps=200)
     g = capture_graph(torch, lambda: robot.configure_and_query_into(th_dev, pts, val, grad), 100)
     g.replay()
     torch.cuda.synchronize()
     both_graph_ms = graph_ms_per_launch(torch, g, 100)
     del g
-    return {"config": f"reference README case: RobotSDF 8 links, link grids res 0.02 padding 1.0, A={A} x M={M} "
-                      "(README.md:177-183 slice points), robot(points)",
+    return {"config": f"README case: RobotSDF 8 links, grids res 0.02 padding 1.0, A={A} x M={M} slice points, robot(points)",
             "scaling": "replicas", "n_gpus": world, "unit": "ms per robot(points) call",
             "ms_per_call": call_ms, "ms_per_call_synchronized_each": synced_ms, "pairs_per_s": A * M / (call_ms * 1e-3),
             "set_joint_configuration_ms": sjc_ms, "set_joint_configuration_device_q_ms": sjc_dev_ms,
             "configure_plus_query_ms": both_ms, "configure_plus_query_graph_ms": both_graph_ms,
-            "configure": "pvamd_configure_chain: sin / cos + forward kinematics + offset^-1 o world^-1 (f32 MFMA) in ONE launch "
-                         "(round 3: H2D + sin + cos + chain_fk + transform_stack = 0.048 ms); `configure_plus_query_ms` = "
-                         "robot.configure_and_query_into(q_on_gpu, points, val, grad) back to back, `_graph_ms` = the same two "
-                         "kernels replayed from a hipGraph (HIP events / 100)",
             "output_shapes": [list(val.shape), list(grad.shape)],
             "published_ms": README_PUBLISHED_MS.get(A), "published_on": "RTX 2080 Ti, KUKA iiwa (README.md:196-200)",
-            "like_for_like": False,
-            "why_not": "synthetic 7-DOF arm with 8 ellipsoid links (KUKA assets unavailable offline); different GPU"}
+            "like_for_like": False, "why_not": "synthetic 7-DOF arm with 8 ellipsoid links (no KUKA assets offline); different GPU"}
 
 
 def leg_c3(torch, Wk, pv, timer, gate, cached, rank, world, steps, small=False):
     """BASELINE configs[2]: ComposedSDF of 8 transformed drills (the C2 cache under 8 rigid transforms), 4,194,304 query
     points, transform + lookup + min over leaves fused (sdf.py:392-433); the points sharded over the ranks, results left
-    sharded (a single configuration: the one-point-per-lane kernel)."""
+    sharded.  28 B/query algorithmic, but 8 leaf visits per point bound it: the vector ALUs, not HBM."""
     P = (1 << 16) if small else (1 << 22)
     comp = Wk.build_c3(cached)
     pts = Wk.c3_points(P)
@@ -571,16 +577,14 @@ def leg_c3(torch, Wk, pv, timer, gate, cached, rank, world, steps, small=False):
             "scaling": "strong", "n_gpus": world, "steps": steps, "unit": "queries/s", "value": P * steps / t,
             "ms_per_step": t / steps * 1e3, "call": "comp.query_into(points, val, grad): fused kernel, caller's buffers",
             "roofline": dict(valu_roofline("c3_composed_query", t / steps * 1e3) if (world == 1 and not small) else {"bound": "valu"},
-                             hbm_algorithmic_GBs=gbs, frac_of_hbm_peak=gbs / (HBM_PEAK_GBS * world),
-                             note="28 B/query algorithmic, but 8 leaf visits per point (the C4 kernel family, "
-                                  "legs.c4.sharded.roofline) bound it: the vector ALUs, not HBM")}
+                             hbm_algorithmic_GBs=gbs, frac_of_hbm_peak=gbs / (HBM_PEAK_GBS * world))}
 
 
 def leg_c1(torch, np, Wk, pv, gate, world):
     """BASELINE configs[0]: MeshSDF on the YCB drill (15,728 triangles), 10,000 of the 0.002 m grid points (the reference's
-    tests/test_sdf.py:46-48) -- the reference's CPU path (Embree) config, here one call of the GPU mesh query (point sort +
-    list / parts launches; the block that folds a group's last part in writes its outputs).  Every rank runs the whole case
-    (replicas)."""
+    tests/test_sdf.py:46-48) -- the reference's CPU path (Embree) config, here one call of the GPU mesh query.  Every rank runs
+    the whole case (replicas).  A 10,000-point call is latency- as much as throughput-bound (dependent launches): the VALU
+    roofline says how busy the ALUs are, not that they are the limit."""
     drill = Wk.build_drill()
     sdf = pv.MeshSDF(drill)
     _, grid_pts = pv.get_coordinates_and_points_in_grid(0.002, drill.bounding_box(0.01))
@@ -590,16 +594,15 @@ def leg_c1(torch, np, Wk, pv, gate, world):
     call_ms, synced_ms = time_calls(torch, np, lambda: sdf(pts), reps=100)
     return {"config": f"C1: MeshSDF on YcbPowerDrill ({drill.num_faces} triangles), 10,000 grid points, one call",
             "scaling": "replicas", "n_gpus": world, "unit": "points/s", "value": 10_000 / (call_ms * 1e-3),
-            "ms_per_call": call_ms, "ms_per_call_synchronized_each": synced_ms,
-            "roofline": valu_roofline("c1_mesh_query", call_ms),
-            "note": "a 10,000-point call is latency- as much as throughput-bound (three dependent launches: sort, list, parts): the VALU roofline "
-                    "says how busy the ALUs are, not that they are the limit"}
+            "ms_per_step": call_ms, "ms_per_call": call_ms, "ms_per_call_synchronized_each": synced_ms,
+            "roofline": valu_roofline("c1_mesh_query", call_ms)}
 
 
 def leg_c5(torch, dist, Wk, pv, timer, gate, rank, world, steps, small=False, use_pg=False):
     """BASELINE configs[4]: unidirectional chamfer, 2,097,152 source points -> 99,500-triangle mesh, the source
     points sharded over the ranks; each rank reduces its slice, then ONE all-reduce of B float64 partial sums (+ the
-    count) -- chamfer.py:79-94 with the mean taken over the global N."""
+    count) -- chamfer.py:79-94 with the mean taken over the global N.  `brute_force_equivalent_pairs_per_s` = pairs a plain
+    double loop would evaluate: the kernel culls, so it is a throughput equivalent, not work done."""
     N = (1 << 16) if small else (1 << 21)
     mesh = Wk.build_c5_mesh()
     pts = Wk.c5_points(N)
@@ -624,12 +627,147 @@ def leg_c5(torch, dist, Wk, pv, timer, gate, rank, world, steps, small=False, us
     return {"config": f"C5: chamfer, {N} points -> {F}-triangle sphere mesh, points sharded x{world}, B=1",
             "scaling": "strong", "n_gpus": world, "steps": steps, "unit": "points/s", "value": N * steps / t,
             "ms_per_step": t / steps * 1e3, "brute_force_equivalent_pairs_per_s": N * F * steps / t,
-            "brute_force_note": "pairs a plain double loop would evaluate; the kernel culls, so this is a throughput "
-                                "equivalent, not work done (no fraction of the fp32 peak is quoted from it)",
             "roofline": valu_roofline("c5_chamfer_mesh", t / steps * 1e3) if (world == 1 and not small) else None,
             "collective": None if (world == 1 and not use_pg) else f"all_reduce of B=1 float64 sums + count ({dist.get_backend()})",
             "chamfer_mm2": float(err[0]), "analytic_sphere_mm2": analytic,
             "rel_err_vs_analytic": abs(float(err[0]) - analytic) / analytic}
+
+
+CACHE_BUILDS = (("drill_0.01", "ycb_power_drill.npz", 0.01, 0.1, (37, 33, 40)),        # README.md:47 (the C2 cache)
+                ("drill_0.002", "ycb_power_drill.npz", 0.002, 0.01, (92, 73, 105)),    # tests/test_sdf.py:46
+                ("wrench_0.001", "offset_wrench_nogrip.obj", 0.001, 0.05, (218, 126, 111)))  # tests/test_model_to_sdf.py:272
+
+
+def leg_cache_build(torch, np, Wk, pv, gate, world, small=False):
+    """CachedSDF construction with the cache filled on the device -- coordinates, the mesh kernel over every
+    voxel centre (sdf.py:498-516 on the GPU instead of Embree on the host), packing into 16-byte records; cache_path=None, so
+    no pickle round trip.  Per build: wall time of the CachedSDF(...) call (median of 3, after one untimed build that grows
+    the allocator) and voxel centres per second.  Every rank builds all of them (replicas)."""
+    out = {"scaling": "replicas", "n_gpus": world, "unit": "voxel centres/s", "builds": {}}
+    gate()
+    for key, mesh_name, res, pad, want_shape in CACHE_BUILDS[:1] if small else CACHE_BUILDS:
+        obj = pv.MeshObjectFactory(Wk.mesh_path(mesh_name))
+        gt = pv.MeshSDF(obj)
+        gt(torch.zeros(64, 3).cuda())  # mesh upload + preparation: not part of a cache build's repeatable cost
+        times = []
+        for i in range(4):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            c = pv.CachedSDF(key, res, obj.bounding_box(padding=pad), gt, device="cuda", cache_path=None)
+            torch.cuda.synchronize()
+            if i:
+                times.append(time.perf_counter() - t0)
+        shape = tuple(int(x) for x in c._view.shape)
+        n = int(np.prod(shape))
+        ms = float(np.median(times)) * 1e3
+        entry = {"mesh": mesh_name, "triangles": obj.num_faces, "resolution": res, "padding": pad, "grid": list(shape),
+                 "grid_is_the_reference_size": shape == want_shape, "voxels": n, "ms": ms, "value": n / (ms * 1e-3)}
+        if world == 1 and not small:
+            roof = valu_roofline(f"build_{key}", ms)
+            if roof.get("frac") is not None:
+                entry["roofline"] = roof
+        out["builds"][key] = entry
+        del c
+        torch.cuda.empty_cache()
+    return out
+
+
+COMPACT_LIMIT = 4096  # bytes: the driver reads the tail of stdout; the contract line must fit it whole
+
+
+def sig(x, digits=5):
+    """floats to `digits` significant digits (the contract line carries numbers, not 17-digit reprs)"""
+    if isinstance(x, bool) or x is None or isinstance(x, (int, str)):
+        return x
+    if isinstance(x, float):
+        if x != x or x in (float("inf"), float("-inf")):
+            return None
+        return float(f"{x:.{digits}g}")
+    if isinstance(x, dict):
+        return {k: sig(v, digits) for k, v in x.items()}
+    if isinstance(x, (list, tuple)):
+        return [sig(v, digits) for v in x]
+    return x
+
+
+def pick(d, *keys):
+    return {k: d[k] for k in keys if isinstance(d, dict) and k in d}
+
+
+def compact_leg(name, leg):
+    """One number set per leg: ms_per_step, value, roofline.frac (+ the multi-rank facts of a gathered leg)."""
+    if not isinstance(leg, dict):
+        return None
+    if "error" in leg or "skipped" in leg:
+        return {"error": str(leg.get("error", "skipped"))[:80], **pick(leg, "ranks_without_a_result")}
+    if name == "cache_build":
+        return {k: {"ms": b["ms"], "value": b["value"], **({"roofline_frac": b["roofline"]["frac"]} if "roofline" in b else {})}
+                for k, b in leg.get("builds", {}).items()}
+    if name.startswith("readme"):
+        return pick(leg, "ms_per_call", "configure_plus_query_graph_ms", "published_ms")
+    body = leg.get("sharded", leg)
+    out = pick(body, "ms_per_step", "value", "prepared_sorted_ms", "prepared_caller_ms")
+    roof = body.get("roofline")
+    if isinstance(roof, dict) and roof.get("frac") is not None:
+        out["roofline_frac"] = roof["frac"]
+        out["bound"] = roof.get("bound")
+    g = leg.get("gathered")
+    if isinstance(g, dict) and "self_check" in g:
+        c = g["self_check"]
+        out["gathered"] = {"ranks": c["ranks"], "backend": c["backend"], "bytes_received_per_rank": g["bytes_received_per_rank"],
+                           "kernel_only_ms": c["kernel_only_ms"], "gathered_ms": c["gathered_ms"],
+                           "equals_unsharded_call": g["equals_unsharded_call"], "ok": c["ok"]}
+    gc_ = leg.get("gathered_by_configs")
+    if isinstance(gc_, dict):
+        out["gathered_by_configs_ms"] = gc_.get("ms_per_step")
+    if leg.get("collective"):
+        out["collective"] = leg["collective"][:60]
+    if "rel_err_vs_analytic" in leg:
+        out["rel_err_vs_analytic"] = leg["rel_err_vs_analytic"]
+    return out
+
+
+def compact_line(d, detail_name):
+    """The contract line (the task's bench contract) from the long record `d`."""
+    roof, cfg = d["roofline"], d["config"]
+    line = pick(d, "metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                "vs_baseline", "dtype", "data")
+    line["config"] = pick(cfg, "workload", "points_per_gpu", "oob_fraction", "ranks", "backend", "gather", "launch")
+    line["roofline"] = pick(roof, "bound", "achieved", "peak", "unit", "frac", "traffic", "algorithmic_bytes_per_launch", "kernel",
+                            "launch_us", "launch_source", "frac_rocprof", "frac_events", "launch_us_events", "frac_of_wall_ms_per_step")
+    cpu = d.get("cpu_baseline")
+    if cpu:
+        line["cpu_baseline"] = pick(cpu, "value", "unit", "cores", "kind", "sample", "host_cpus", "baseline_opforop", "baseline_fused")
+        line["cpu_baseline"]["fused_port"] = pick(cpu.get("fused_port", {}), "value", "cores")
+    par = d.get("parity")
+    if par:
+        line["parity"] = pick(par, "checked_points", "max_abs_val_err_vs_oracle", "grad_mismatches_vs_oracle", "parity_unpinned")
+    if "legs" in d:
+        line["legs"] = {k: compact_leg(k, v) for k, v in d["legs"].items()}
+    for key in ("all_in_range_batch", "mid_batch", "large_batch", "p1e8_batch"):
+        if key in d:
+            b = d[key]
+            line[key] = {"ms": b.get("ms_per_launch", b.get("kernel_ms_median")), "frac_of_8TBs": b["frac_of_8TBs"]}
+    if "latency" in d and "cached(points)" in d["latency"]:
+        line["latency_us"] = {"cached_p50": d["latency"]["cached(points)"]["p50_us"], "cached_p99": d["latency"]["cached(points)"]["p99_us"]}
+    if "legs_aborted" in d:
+        line["legs_aborted"] = d["legs_aborted"][:100]
+    line["detail"] = detail_name
+    return line
+
+
+def compact_text(d, detail_name):
+    """json text of the contract line, guaranteed under COMPACT_LIMIT: optional blocks are dropped, least important first, if
+    a run (many failing legs with long messages) should ever push it over."""
+    line = sig(compact_line(d, detail_name))
+    text = json.dumps(line, separators=(",", ":"))
+    for drop in ("latency_us", "all_in_range_batch", "mid_batch", "p1e8_batch", "large_batch", "legs", "parity"):
+        if len(text) < COMPACT_LIMIT:
+            break
+        line.pop(drop, None)
+        line["dropped_for_size"] = line.get("dropped_for_size", []) + [drop]
+        text = json.dumps(line, separators=(",", ":"))
+    return text
 
 
 def main():
@@ -728,65 +866,78 @@ def main():
     out = None
     if rank == 0:
         qps = world * P * args.steps / elapsed
-        achieved = BYTES_PER_QUERY * P / (k_ms * 1e-3) / 1e9
+        algo = BYTES_PER_QUERY * P
+        ev_gbs = algo / (k_ms * 1e-3) / 1e9
         traffic, traffic_source = read_traffic(P)
-        rocprof_us, rocprof_source = read_rocprof_kernel_us(P)
+        rocprof_us, rocprof_calls, rocprof_source = read_rocprof_kernel_us(P)
+        # `frac`: the committed rocprofv3 kernel-trace average of this very command when there is one for this point count (the
+        # figure a reader can recompute from profiles/); the live HIP-event figure otherwise.  A committed trace that no longer
+        # describes the kernel (events and trace more than 20 % apart) is not used.
+        stale = rocprof_us is not None and abs(rocprof_us * 1e-3 - k_ms) > 0.2 * k_ms
+        use_trace = rocprof_us is not None and not stale
+        launch_us = rocprof_us if use_trace else k_ms * 1e3
+        achieved = algo / (launch_us * 1e-6) / 1e9
         out = {
             "metric": "SDF (val+grad) queries/sec", "value": qps, "unit": "queries/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "C2: CachedSDF 0.01 m voxels (37x33x40, packed 16 B/voxel) on YcbPowerDrill, "
-                                   f"{P} uniform query points per GPU per step, BOUNDING_BOX out-of-range fallback",
+            "config": {"workload": f"C2: CachedSDF 0.01 m voxels (37x33x40) on YcbPowerDrill, {P} uniform points per GPU per step",
                        "points_per_gpu": P, "index_dtype": "f64" if cached._view.index_f64 else "f32",
+                       "out_of_range": "BOUNDING_BOX fallback, fused",
                        "launch": "one hipGraph of the K steps" if graph is not None else "eager",
-                       "timed_region": "barrier + synchronize | K steps | event-query spin + synchronize | barrier; "
-                                       "max over ranks",
+                       "timed_region": "barrier + sync | K steps | event spin + sync | barrier; max over ranks",
                        "gather": False, "parallelism": f"points x{world}", "ranks": world,
                        "backend": (dist.get_backend() if use_pg else None), "gpus_requested": args.gpus},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
-                         "kernel": "pvamd::cached_query_wave", "launch_ms_mean": k_ms, "launch_ms_best_replay": k_ms_best,
-                         "frac_best_replay": BYTES_PER_QUERY * P / (k_ms_best * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                         "frac_rocprof": None if rocprof_us is None else BYTES_PER_QUERY * P / (rocprof_us * 1e-6) / 1e9 / HBM_PEAK_GBS,
-                         "rocprof_launch_us": rocprof_us, "rocprof_source": rocprof_source,
-                         "timing": f"`frac` / `achieved` / `launch_ms_mean`: HIP events on the launch stream around a SEPARATE "
-                                   f"hipGraph of {kg_n} launches of the same call on the same buffers, / {kg_n}, MEAN of 5 "
-                                   "replays (the best replay is `launch_ms_best_replay`); NOT the K timed steps, so it does "
-                                   "not change with --steps.  `frac_rocprof`: the committed kernel trace's average.  "
-                                   "`frac_of_wall_ms_per_step`: the driver-timed K steps",
+                         "kernel": "pvamd::cached_query_wave", "algorithmic_bytes_per_launch": algo,
+                         "launch_us": launch_us, "launch_source": rocprof_source if use_trace else "hip events (this run)",
+                         "frac_is": "committed rocprofv3 kernel-trace average" if use_trace else "live HIP events",
+                         "rocprof_launch_us": rocprof_us, "rocprof_calls": rocprof_calls, "rocprof_source": rocprof_source,
+                         "rocprof_stale": bool(stale),
+                         "frac_rocprof": None if rocprof_us is None else algo / (rocprof_us * 1e-6) / 1e9 / HBM_PEAK_GBS,
+                         "frac_events": ev_gbs / HBM_PEAK_GBS, "launch_us_events": k_ms * 1e3,
+                         "launch_us_events_best_replay": k_ms_best * 1e3,
+                         "frac_events_best_replay": algo / (k_ms_best * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                         "events": f"HIP events around a separate hipGraph of {kg_n} launches of the same call, / {kg_n}, mean of 5 replays",
                          "eager_launch_ms": {"mean": e_mean, "median": e_med, "min": e_min},
                          "dropin_call": {"call": "val, grad = cached(points)  # CachedSDF.__call__, outputs allocated per call",
                                          "ms_per_call": d_call, "queries_per_s": P / (d_call * 1e-3),
                                          "ms_per_call_synchronized_each": d_sync,
-                                         "timing": "400 calls back to back + one synchronize, wall clock / 400; and the median "
-                                                   "of 200 calls each followed by a synchronize"},
-                         "algorithmic_bytes_per_launch": BYTES_PER_QUERY * P,
-                         "frac_of_wall_ms_per_step": BYTES_PER_QUERY * P / (elapsed / args.steps) / 1e9 / HBM_PEAK_GBS},
+                                         "timing": "400 calls back to back + one synchronize; median of 200 synchronized calls"},
+                         "frac_of_wall_ms_per_step": algo / (elapsed / args.steps) / 1e9 / HBM_PEAK_GBS},
+            "valu_model": valu_model(),
         }
 
     legs = {}
     emitted = threading.Lock()
 
     def emit(final):
-        """rank 0: the ONE JSON line, last on stdout (RCCL prints a version banner through C stdio, which would otherwise be
-        flushed after Python's own buffer at exit)."""
+        """rank 0: the long record -> --detail file and stderr; the compact contract line, LAST on stdout (RCCL prints a version
+        banner through C stdio, which would otherwise be flushed after Python's own buffer at exit)."""
         if not emitted.acquire(blocking=False):
             return
         if rank == 0:
             import ctypes
+            long_text = json.dumps(final)
+            try:
+                with open(args.detail, "w") as f:
+                    f.write(long_text + "\n")
+            except OSError as exc:
+                print(f"bench.py: could not write {args.detail}: {exc!r}", file=sys.stderr)
+            print("bench_detail " + long_text, file=sys.stderr, flush=True)
             sys.stdout.flush()
             try:
                 ctypes.CDLL(None).fflush(None)
             except Exception:
                 pass
-            print(json.dumps(final), flush=True)
+            print(compact_text(final, os.path.basename(args.detail)), flush=True)
 
     def on_deadline():
         # a rank is lost inside a leg's collective (the gate only covers failures BEFORE it): keep the headline
         if rank == 0:
             out["legs"] = dict(legs)
-            out["legs_aborted"] = (f"deadline of {args.legs_deadline:.0f} s passed while the legs were running (a rank stuck in a "
-                                   "collective?); the legs listed are those that had finished on rank 0")
+            out["legs_aborted"] = f"deadline of {args.legs_deadline:.0f} s passed inside the legs; listed: those finished on rank 0"
         emit(out)
         sys.stdout.flush()
         os._exit(0)
@@ -816,6 +967,7 @@ def main():
                 ("c4", lambda g: leg_c4(torch, dist, Wk, pv, timer, g, robots, rank, world, leg_steps, 0.1, True, sm, use_pg)),
                 ("c4_readme_grid", lambda g: leg_c4(torch, dist, Wk, pv, timer, g, robots, rank, world, leg_steps, 1.0, False, sm)),
                 ("c5", lambda g: leg_c5(torch, dist, Wk, pv, timer, g, rank, world, 5, sm, use_pg))]
+        spec += [("cache_build", lambda g: leg_cache_build(torch, np, Wk, pv, g, world, sm))]
         if not sm:
             spec += [("c1", lambda g: leg_c1(torch, np, Wk, pv, g, world)),
                      ("readme_a20", lambda g: leg_readme(torch, np, Wk, pv, timer, g, robots, rank, world, 20)),
@@ -830,7 +982,7 @@ def main():
                     time.sleep(1e6)  # "lost inside the leg": the other ranks wait in its first collective
                 legs[name] = fn(gate)
             except LegSkipped:
-                legs[name] = {"skipped": "another rank failed while preparing this leg; every rank skipped it together"}
+                legs[name] = {"skipped": "another rank failed while preparing this leg; every rank skipped it"}
             except Exception as exc:  # a failing leg must not take the headline line with it
                 legs[name] = {"error": repr(exc)}
                 if not gate.passed:
@@ -875,7 +1027,7 @@ def main():
         out["mid_batch"] = {"points": PM, "ms_per_launch": t_mid, "queries_per_s": PM / (t_mid * 1e-3),
                             "achieved_GBs": BYTES_PER_QUERY * PM / (t_mid * 1e-3) / 1e9,
                             "frac_of_8TBs": BYTES_PER_QUERY * PM / (t_mid * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                            "note": "working set inside the Infinity Cache: fabric, not HBM, bandwidth"}
+                            "note": "working set inside the 256 MB Infinity Cache"}
         del gm, mid, mval, mgrad
         # secondary: a batch far beyond the 256 MB Infinity Cache, where the kernel is HBM- rather than launch-bound
         PL = 1 << 26
@@ -890,6 +1042,19 @@ def main():
                               "achieved_GBs": BYTES_PER_QUERY * PL / (m * 1e-3) / 1e9,
                               "frac_of_8TBs": BYTES_PER_QUERY * PL / (m * 1e-3) / 1e9 / HBM_PEAK_GBS}
         del big, bval, bgrad
+        # secondary: the P = 1e8 launch SURVEY.md 8(d) asks for (2.8 GB of algorithmic traffic)
+        PH = 100_000_000
+        huge = Wk.c2_points(cached, PH, seed=100)
+        hval = torch.empty((PH,), dtype=torch.float32, device="cuda")
+        hgrad = torch.empty((PH, 3), dtype=torch.float32, device="cuda")
+        for _ in range(30):
+            cached.query_into(huge, hval, hgrad)
+        _, m, mn = time_eager_kernel(torch, np, lambda: cached.query_into(huge, hval, hgrad), 30)
+        out["p1e8_batch"] = {"points": PH, "kernel_ms_median": m, "kernel_ms_min": mn, "queries_per_s": PH / (m * 1e-3),
+                             "achieved_GBs": BYTES_PER_QUERY * PH / (m * 1e-3) / 1e9,
+                             "frac_of_8TBs": BYTES_PER_QUERY * PH / (m * 1e-3) / 1e9 / HBM_PEAK_GBS}
+        del huge, hval, hgrad
+        torch.cuda.empty_cache()
 
     if rank == 0 and world == 1 and not args.no_legs and not args.small_legs:
         # the tail of the drop-in calls (profiles/r04_stall.txt: the 20-40 ms step rounds 2-3 chased is CPython's generation-2
@@ -900,17 +1065,16 @@ def main():
             spts = spts.cuda()
             robot20 = build_robot(Wk, robots, 1.0)
             robot20.set_joint_configuration(Wk.c4_joint_configs(20))
-            cold = {"cached(points)": call_latency(torch, np, lambda: cached(spts), calls=20_000)}
+            n_calls = args.latency_calls
+            cold = {"cached(points)": call_latency(torch, np, lambda: cached(spts), calls=max(1000, n_calls // 4))}
             t0 = time.perf_counter()
             pv.warm_up()
             warm_ms = (time.perf_counter() - t0) * 1e3
-            out["latency"] = {"points": int(spts.shape[0]), "timing": "perf_counter around every call, queue drained every 256 calls "
-                              "outside the timed spans; 100,000 calls each after pv.warm_up() (kernel families launched once, "
-                              "gc.collect() + gc.freeze())", "warm_up_ms": warm_ms,
-                              "cached(points)": call_latency(torch, np, lambda: cached(spts)),
-                              "robot(points) A=20, README-size link grids": call_latency(torch, np, lambda: robot20(spts)),
-                              "before_warm_up_20000_calls": cold,
-                              "gc_frozen_objects": gc.get_freeze_count()}
+            out["latency"] = {"points": int(spts.shape[0]), "warm_up_ms": warm_ms,
+                              "timing": "perf_counter around every call, queue drained every 256 calls; after pv.warm_up()",
+                              "cached(points)": call_latency(torch, np, lambda: cached(spts), calls=n_calls),
+                              "robot(points) A=20, README-size link grids": call_latency(torch, np, lambda: robot20(spts), calls=n_calls),
+                              "before_warm_up": cold, "gc_frozen_objects": gc.get_freeze_count()}
         except Exception as exc:
             out["latency"] = {"error": repr(exc)}
 
@@ -927,7 +1091,8 @@ def main():
         out["config"]["oob_fraction"] = float(ooob.mean())
         out["parity"] = {"checked_points": n_chk, "max_abs_val_err_vs_oracle": max_err,
                          "grad_mismatches_vs_oracle": grad_mismatch,
-                         "oracle": oracle_pin_string(np)}
+                         "oracle": "oracle/pvamd_oracle.c (in-repo CPU restatement)", "oracle_pinned": oracle_pins(np),
+                         "parity_unpinned": not all(oracle_pins(np).values())}
         if not args.no_cpu_baseline and world == 1:  # the CPU baseline is timed on rank 0 of the 1-GPU run only
             out["cpu_baseline"] = cpu_baseline(torch, np, cached, pts, args.cpu_seconds)
     if use_pg:
