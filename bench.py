@@ -294,7 +294,8 @@ def valu_model():
     """Once per record: how every VALU roofline below is formed (the per-leg objects carry numbers only)."""
     prof, name = valu_session()
     return {"file": None if name is None else f"profiles/{name}", "n_simd": N_SIMD,
-            "issue_rates_ns": None if prof is None else prof["issue_rates_ns"],
+            "issue_rates_ns": None if prof is None else {k: v for k, v in prof["issue_rates_ns"].items()
+                                                         if isinstance(v, (int, float))},
             "ceiling": "1024 SIMDs / max(f_slow * t_slow, t_best) wave64 VALU inst/s, with the call's own dynamic opcode mix",
             "f_slow": "share of VALU instructions that are not an f32 add / mul / fma (SQ_INSTS_VALU_* class counters)",
             "frac": "SQ_INSTS_VALU and kernel time of ONE rocprofv3 session (tools/valu_session.sh) against that ceiling",

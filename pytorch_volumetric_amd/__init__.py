@@ -5,7 +5,8 @@ Every name pytorch_volumetric exports for that path is available here; see INTEG
 from pytorch_volumetric_amd import _lib, mesh_io, voxel
 from pytorch_volumetric_amd._lib import RULE_RES_F64, RULE_ROUND_FLOOR_HALF, RULE_ROUND_HALF_AWAY, RULE_VALID_ON_INDEX
 from pytorch_volumetric_amd.sdf import (CachedSDF, ComposedSDF, MeshObjectFactory, MeshSDF, ObjectFactory,
-                                        ObjectFrameSDF, OutOfBoundsStrategy, SDFQuery, SphereSDF, sample_mesh_points)
+                                        ObjectFrameSDF, OutOfBoundsStrategy, PreparedPoints, SDFQuery, SphereSDF,
+                                        sample_mesh_points)
 from pytorch_volumetric_amd.model_to_sdf import RobotSDF, aabb_to_ordered_end_points, cache_link_sdf_factory
 from pytorch_volumetric_amd.chamfer import (PlausibleDiversity, batch_chamfer_dist, pairwise_distance,
                                             pairwise_distance_chamfer)

@@ -182,6 +182,7 @@ SIGNATURES = {
                                              ctypes.c_void_p, ctypes.c_void_p]),
 }
 
+E_SHAPE = -2  # PVAMD_E_SHAPE (include/pvamd.h)
 _ERRORS = {-1: "a required pointer is NULL", -2: "a size/shape argument is out of range",
            -3: "a pointer is misaligned", -4: "unknown enum value"}
 

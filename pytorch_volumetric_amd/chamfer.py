@@ -51,16 +51,31 @@ def batch_chamfer_dist(world_to_object: torch.tensor, model_points_world_frame_e
     """
     W = tf.as_matrix(world_to_object)
     out_dtype, out_device = W.dtype, W.device
-    B = W.shape[0]
     if obj_sdf is None and obj_factory is None:
         raise ValueError("Either obj_sdf or obj_factory must be given")
+    sums, total_n = chamfer_partial_sums(W, model_points_world_frame_eval, obj_factory, obj_sdf, scale)
+    if reduce_group is not None:
+        import torch.distributed as dist
+        count = torch.tensor([float(total_n)], dtype=torch.float64, device=sums.device)
+        dist.all_reduce(sums, op=dist.ReduceOp.SUM, group=reduce_group)
+        dist.all_reduce(count, op=dist.ReduceOp.SUM, group=reduce_group)
+        total_n = count.item()
+    return (sums / total_n).to(device=out_device, dtype=out_dtype)  # no points at all: 0 / 0 = NaN, torch's mean of nothing
+
+
+def chamfer_partial_sums(W, points, obj_factory, obj_sdf, scale):
+    """The per-rank half of batch_chamfer_dist: sum over THESE points of (scale * d)^2 per transform, float64 on the GPU, and
+    the number of points -- what a run sharded over the points all-reduces (dist.sharded_chamfer).  W: (B, 4, 4)."""
+    B = W.shape[0]
     lib = _lib.load()
     dev = _lib.require_gpu()
-    pts = torch.as_tensor(model_points_world_frame_eval).detach().reshape(-1, 3).to(device=dev, dtype=torch.float32)
+    pts = torch.as_tensor(points).detach().reshape(-1, 3).to(device=dev, dtype=torch.float32)
     pts = pts.contiguous()
     N = pts.shape[0]
     Wd = W.detach().to(device=dev, dtype=torch.float32).contiguous()
     sums = torch.empty((B,), dtype=torch.float64, device=dev)
+    if N == 0:  # a rank whose shard is empty (fewer points than ranks): nothing to launch, it adds 0 to the all-reduce
+        return sums.zero_(), 0
 
     fused_grid = isinstance(obj_sdf, CachedSDF) and obj_sdf._dim == 3 and \
         obj_sdf.out_of_bounds_strategy == OutOfBoundsStrategy.BOUNDING_BOX
@@ -98,14 +113,7 @@ def batch_chamfer_dist(world_to_object: torch.tensor, model_points_world_frame_e
                 _lib.check(lib.pvamd_chamfer_mesh(ctypes.byref(desc), _lib.ptr(Wd), B, _lib.ptr(pts), _lib.ptr(order), N,
                                                   float(scale), _lib.ptr(sums), _lib.ptr(scratch), _lib.stream_ptr()),
                            "pvamd_chamfer_mesh")
-    total_n = N
-    if reduce_group is not None:
-        import torch.distributed as dist
-        count = torch.tensor([float(N)], dtype=torch.float64, device=dev)
-        dist.all_reduce(sums, op=dist.ReduceOp.SUM, group=reduce_group)
-        dist.all_reduce(count, op=dist.ReduceOp.SUM, group=reduce_group)
-        total_n = count.item()
-    return (sums / total_n).to(device=out_device, dtype=out_dtype)
+    return sums, N
 
 
 def pairwise_distance_chamfer(A_link_to_world_tfs, B_world_to_link_tfs=None,

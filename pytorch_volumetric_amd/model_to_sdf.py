@@ -83,6 +83,10 @@ class RobotSDF(sdf.ObjectFrameSDF):
         if joint_config is None:
             joint_config = torch.zeros(M, device=self.device, dtype=self.dtype)
         joint_config = torch.as_tensor(joint_config)
+        if joint_config.dim() == 0 or joint_config.shape[-1] != M:
+            # (the kernel reads q[a * M + joint]: a short float32 GPU vector, used where it is, would be read out of bounds)
+            raise ValueError(f"joint configuration of shape {tuple(joint_config.shape)} does not hold the {M} joint values "
+                             f"({', '.join(self.joint_names)}) in its last dimension")
         if len(joint_config.shape) > 1:
             self.configuration_batch = tuple(joint_config.shape[:-1])
             # a chain of fixed joints only has M == 0: reshape(-1, 0) cannot infer the batch
@@ -123,7 +127,10 @@ class RobotSDF(sdf.ObjectFrameSDF):
     def object_to_link_frames(self) -> typing.Optional[tf.Transform3d]:
         """model_to_sdf.py:113: the [A*]S object -> link transforms of the current configuration, leaf-major."""
         if self._stack_obj is None and self._stack is not None:
-            self._stack_obj = tf.Transform3d(matrix=self._stack)
+            # configure_and_query_into re-writes its stack in place on the next call: what the caller holds must not change
+            # under it (the reference returns a fresh object per configuration)
+            own = any(hit[1] is self._stack for hit in self.__dict__.get("_cfg_stack", {}).values())
+            self._stack_obj = tf.Transform3d(matrix=self._stack.clone() if own else self._stack)
         return self._stack_obj
 
     @object_to_link_frames.setter
@@ -131,22 +138,46 @@ class RobotSDF(sdf.ObjectFrameSDF):
         self._stack_obj = value
         self._stack = None if value is None else tf.as_matrix(value)
 
-    def _configure(self, lib, dev, q, A, M, S, offset_inv, stack=None, sincos=None):
+    def _configure(self, lib, dev, q, A, M, S, offset_inv, stack=None, sincos=None, one_launch_only=False):
         """pvamd_configure_chain on the current stream: q (A, M) float32 on `dev` -> the (S*A, 4, 4) obj->leaf stack.  The
-        frame scratch is kept per batch size (it is private to one call on one stream)."""
+        frame scratch is kept per (device, stream, batch size): it is private to one call on one stream, and two streams that
+        configure the same robot concurrently must not share it.  A robot with more SDF-carrying links than the one-launch
+        kernel can stage in LDS (PVAMD_E_SHAPE, ~50 links) takes sin / cos + pvamd_chain_fk + pvamd_transform_stack -- the same
+        fma chains, any S -- unless the caller needs the single launch (`one_launch_only`: graph capture)."""
         joints, F = self._joint_table_dev(dev)
-        key = (str(dev), A)
-        hit = self.__dict__.get("_cfg_scratch")
-        if hit is None or hit[0] != key:
-            hit = self._cfg_scratch = (key, torch.empty((F, 12, A), dtype=torch.float32, device=dev))
+        stream = _lib.stream_ptr()
+        key = (str(dev), stream.value, A)
+        hit = self._per_stream("_cfg_scratch", key, lambda: torch.empty((F, 12, A), dtype=torch.float32, device=dev))
         if stack is None:
             stack = torch.empty((S * A, 4, 4), dtype=torch.float32, device=dev)
         rc = lib.pvamd_configure_chain(joints.data_ptr(), F, q.data_ptr(), A, M, offset_inv.data_ptr(), S,
                                        None if sincos is None else sincos.data_ptr(), hit[1].data_ptr(), None,
-                                       stack.data_ptr(), _lib.stream_ptr())
-        if rc != 0:
+                                       stack.data_ptr(), stream)
+        if rc == _lib.E_SHAPE and S > 20 and not one_launch_only:
+            sin_q, cos_q = torch.sin(q), torch.cos(q)
+            if sincos is not None:
+                sincos.copy_(torch.stack((sin_q, cos_q), dim=-1))
+            link_world = torch.empty((S * A, 4, 4), dtype=torch.float32, device=dev)
+            _lib.check(lib.pvamd_chain_fk(joints.data_ptr(), F, q.data_ptr(), sin_q.data_ptr(), cos_q.data_ptr(), A, M,
+                                          hit[1].data_ptr(), link_world.data_ptr(), stream), "pvamd_chain_fk")
+            _lib.check(lib.pvamd_transform_stack(offset_inv.data_ptr(), link_world.data_ptr(), S, A, stack.data_ptr(), stream),
+                       "pvamd_transform_stack")
+        elif rc == _lib.E_SHAPE and one_launch_only:
+            raise ValueError(f"configure_and_query_into: {S} SDF-carrying links do not fit the one-launch configure kernel "
+                             "(about 50 at most); call set_joint_configuration(q) and query_into(...) instead")
+        elif rc != 0:
             _lib.check(rc, "pvamd_configure_chain")
         return stack
+
+    def _per_stream(self, name, key, make):
+        """(key, tensor) of a buffer kept per (device, stream, batch size); at most 8 keys are remembered."""
+        table = self.__dict__.setdefault(name, {})
+        hit = table.get(key)
+        if hit is None:
+            if len(table) >= 8:
+                table.pop(next(iter(table)))
+            hit = table[key] = (key, make())
+        return hit
 
     def configure_and_query_into(self, joint_config, points, out_val, out_grad):
         """A planner's inner step without host work between its two launches: joint values (A, M) float32 ALREADY ON THE GPU
@@ -164,19 +195,18 @@ class RobotSDF(sdf.ObjectFrameSDF):
         dev = q.device
         lib = _lib.load()
         with _lib.on_device(dev):
-            key = (str(dev), A)
-            hit = self.__dict__.get("_cfg_stack")
-            if hit is None or hit[0] != key:  # the stack this entry point writes is its own, re-used call after call
-                stack = torch.empty((S * A, 4, 4), dtype=torch.float32, device=dev)
-                hit = self._cfg_stack = (key, stack)
-            self._configure(lib, dev, q, A, M, S, self._offset_inv_dev(dev), stack=hit[1])
+            key = (str(dev), _lib.current_raw_stream(dev.index), A)
+            # the stack this entry point writes is its own (per stream), re-used call after call
+            hit = self._per_stream("_cfg_stack", key, lambda: torch.empty((S * A, 4, 4), dtype=torch.float32, device=dev))
+            self._configure(lib, dev, q, A, M, S, self._offset_inv_dev(dev), stack=hit[1], one_launch_only=True)
             self.q, self.configuration_batch = q, (A,)
             if self._stack is not hit[1]:
-                self._stack, self._stack_obj = hit[1], None
+                self._stack = hit[1]
+            self._stack_obj = None  # a Transform3d handed out earlier keeps the configuration it was read under (a copy)
             cur = self.sdf._tf_matrix
             if cur is None or cur.data_ptr() != hit[1].data_ptr() or cur.shape != hit[1].shape or self.sdf.tsf_batch != (A,):
                 self.sdf.set_transforms(hit[1], batch_dim=(A,), known_rigid=True)
-            self.sdf._inverse_frames = None  # surface_bounding_box rebuilds them from the (re-written) stack when asked
+            self.sdf.invalidate_transforms()  # this stack is re-written in place: drop everything derived from its old contents
             self.sdf.query_into(points, out_val, out_grad)
 
     def _offset_inv_dev(self, dev):
@@ -203,6 +233,14 @@ class RobotSDF(sdf.ObjectFrameSDF):
     def query_into(self, points, out_val, out_grad):
         """Allocation-free form of __call__ (see ComposedSDF.query_into); outputs are (A,P) and (A,P,3)."""
         self.sdf.query_into(points, out_val, out_grad)
+
+    def prepare_points(self, points_in_object_frame):
+        """Sort a re-used query point set once (ComposedSDF.prepare_points); query it under every later joint configuration
+        with query_prepared(handle, order="caller" | "sorted")."""
+        return self.sdf.prepare_points(points_in_object_frame)
+
+    def query_prepared(self, prepared, order="caller"):
+        return self.sdf.query_prepared(prepared, order=order)
 
 
 def cache_link_sdf_factory(resolution=0.01, padding=0.1, **kwargs):

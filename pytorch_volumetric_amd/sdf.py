@@ -598,6 +598,20 @@ class CachedSDF(ObjectFrameSDF):
         return out.reshape(*lead).bool().to(device=self.device)
 
 
+class PreparedPoints:
+    """A query point set sorted once along the Hilbert curve (ComposedSDF.prepare_points).
+    points: (P, 3) float32, caller order, on the leaves' GPU.  order: int32 (P,), order[j] = caller index of sorted position j.
+    inverse: int32 (P,), inverse[i] = sorted position of caller point i.  sorted_points = points[order]."""
+
+    def __init__(self, points, order, inverse, sorted_points, padded_points, lead, dtype):
+        self.points, self.order, self.inverse = points, order, inverse
+        self.sorted_points, self.padded_points = sorted_points, padded_points
+        self.lead, self.dtype = lead, dtype
+
+    def __len__(self):
+        return int(self.points.shape[0])
+
+
 class ComposedSDF(ObjectFrameSDF):
     """Minimum over S rigidly placed leaf SDFs (sdf.py:332-433).
 
@@ -626,7 +640,9 @@ class ComposedSDF(ObjectFrameSDF):
         """The [B*]S object -> leaf transforms as a Transform3d (sdf.py:343,377).  A planner that re-configures every step
         hands over a bare (S*A, 4, 4) stack; the object around it is built when somebody asks (1.2 us per step otherwise)."""
         if self._tf_obj is None and self._tf_matrix is not None:
-            self._tf_obj = tf.Transform3d(matrix=self._tf_matrix)
+            # a stack its owner re-writes in place is handed out as a copy: what the caller holds keeps its configuration
+            volatile = self.__dict__.get("_tf_volatile", False)
+            self._tf_obj = tf.Transform3d(matrix=self._tf_matrix.clone() if volatile else self._tf_matrix)
         return self._tf_obj
 
     @obj_frame_to_link_frame.setter
@@ -658,6 +674,7 @@ class ComposedSDF(ObjectFrameSDF):
             if math.prod(batch_dim) * S != S_tsf:
                 raise ValueError(f"{S_tsf} transforms != {S} SDFs x batch {batch_dim}")
         # validated: now commit
+        self._tf_volatile = False
         self.tsf_batch, self._tf_dev, self._tf_dev64 = batch_dim, None, None
         self._tf_obj, self._tf_matrix = (tsf if hasattr(tsf, "get_matrix") else None), m
         # The reference inverts with a general matrix inverse (sdf.py:380).  Rigid stacks (every RobotSDF stack, and
@@ -670,6 +687,19 @@ class ComposedSDF(ObjectFrameSDF):
         # the inverse frames only serve surface_bounding_box: built when first asked for (a planner that sets a new joint
         # configuration every step paid 0.09 of 0.16 ms of host time for them)
         self._inverse_of, self._inverse_frames = m, None
+
+    def invalidate_transforms(self):
+        """The transform stack handed to set_transforms was re-written IN PLACE (RobotSDF.configure_and_query_into): drop every
+        copy derived from its old contents -- the float64 widening of the float64 query path, the inverse frames of
+        surface_bounding_box, the Transform3d wrapper.  The float32 device stack aliases the caller's tensor and stays."""
+        self._tf_dev64 = None
+        self._inverse_frames = None
+        self._tf_volatile = True
+        if self._tf_matrix is not None:
+            self._inverse_of = self._tf_matrix
+        self._tf_obj = None
+        if self._tf_dev is not None and self._tf_matrix is not None and self._tf_dev.data_ptr() != self._tf_matrix.data_ptr():
+            self._tf_dev = None  # (a converted copy, not an alias: rebuilt on the next query)
 
     @property
     def link_frame_to_obj_frame(self):
@@ -872,6 +902,68 @@ class ComposedSDF(ObjectFrameSDF):
         else:
             val, grad = val.reshape(-1), grad.reshape(-1, 3)
         return val.to(device=out_device, dtype=dtype), grad.to(device=out_device, dtype=dtype)
+
+    # ---- prepared point sets: a planner that queries the SAME points under many configurations, step after step ----
+    def prepare_points(self, points_in_object_frame):
+        """Sort a point set along the Hilbert curve ONCE and keep the order: a handle for query_prepared().  The drop-in call
+        (__call__ with README-size leaf grids) pays this sort and an un-permute pass on every call (model_to_sdf.py:117-125
+        re-queried per joint configuration, README.md:150-200); a planner that re-uses its query points -- a fixed workspace
+        grid, a fixed set of collision spheres -- pays the sort here and, with order="sorted", nothing per call.
+        `points_in_object_frame`: [...] x N x 3, any float dtype / device (computed in float32 on the leaves' GPU)."""
+        if not self._fusable():
+            raise ValueError("prepare_points needs every leaf to be a CachedSDF with the BOUNDING_BOX strategy")
+        if not torch.is_tensor(points_in_object_frame):
+            points_in_object_frame = torch.as_tensor(points_in_object_frame)
+        flat, lead, dtype, device = _lib.as_query_points(points_in_object_frame, self._owner_device())
+        P = flat.shape[0]
+        if P == 0:
+            raise ValueError("prepare_points needs at least one point")
+        with _lib.on_device(flat.device):
+            order, inv, spts = _lib.morton_order(flat, min_points=0, want_inverse=True, want_sorted=True)
+            Pp = -(-P // 256) * 256
+            padded = spts if Pp == P else torch.cat((spts, spts[-1:].expand(Pp - P, 3))).contiguous()
+        return PreparedPoints(flat, order, inv, spts, padded, tuple(lead), dtype)
+
+    def query_prepared(self, prepared: "PreparedPoints", order="caller"):
+        """The fused query over a prepare_points() handle under the CURRENT transforms (set_transforms /
+        RobotSDF.set_joint_configuration between calls as usual).
+        order="caller": exactly what __call__(points) returns -- same shapes, same bits -- without the per-call sort.
+        order="sorted": (A..., P) / (A..., P, 3) with column j the result of caller point `prepared.order[j]` (flattened
+        index): no sort and no un-permute pass -- the kernel's own output order.  Same bits, permuted."""
+        if order not in ("caller", "sorted"):
+            raise ValueError('order must be "caller" or "sorted"')
+        if not self._fusable():
+            raise ValueError("query_prepared needs every leaf to be a CachedSDF with the BOUNDING_BOX strategy")
+        S = len(self.sdfs)
+        A = math.prod(self.tsf_batch) if self.tsf_batch is not None else 1
+        dev = self._owner_device()
+        if prepared.points.device != dev:
+            raise _lib.PvamdError(f"query_prepared: the leaf grids live on {dev}; the prepared points are on {prepared.points.device}")
+        P = prepared.points.shape[0]
+        lib = _lib.load()
+        val = torch.empty((A, P), dtype=torch.float32, device=dev)
+        grad = torch.empty((A, P, 3), dtype=torch.float32, device=dev)
+        with _lib.on_device(dev):
+            grids = self._leaf_grids(dev)
+            tfd = self._tf_device(dev)
+            if order == "sorted":
+                _lib.check(lib.pvamd_composed_query(_lib.ptr(grids), S, _lib.ptr(tfd), A, _lib.ptr(prepared.sorted_points), P,
+                                                    _lib.ptr(val), _lib.ptr(grad), None, self._query_flags, _lib.stream_ptr()),
+                           "pvamd_composed_query")
+            else:
+                Pp = prepared.padded_points.shape[0]
+                scratch = torch.empty((A, Pp, 4), dtype=torch.float32, device=dev)
+                _lib.check(lib.pvamd_composed_query_bucketed(_lib.ptr(grids), S, _lib.ptr(tfd), A, _lib.ptr(prepared.padded_points),
+                                                             _lib.ptr(prepared.inverse), P, Pp, _lib.ptr(scratch), _lib.ptr(val),
+                                                             _lib.ptr(grad), self._query_flags, _lib.stream_ptr()),
+                           "pvamd_composed_query_bucketed")
+        lead = (P,) if order == "sorted" else prepared.lead
+        out_device = self.sdfs[0].device
+        if self.tsf_batch is not None:
+            val, grad = val.reshape(*self.tsf_batch, *lead), grad.reshape(*self.tsf_batch, *lead, 3)
+        else:
+            val, grad = val.reshape(-1), grad.reshape(-1, 3)  # like __call__: flat without a transform batch (sdf.py:433)
+        return val.to(device=out_device, dtype=prepared.dtype), grad.to(device=out_device, dtype=prepared.dtype)
 
     def _call_f64(self, points, S, A):
         """float64 query points: transform, lookups and gradient rotation in float64 (`pvamd_composed_query_f64`), results

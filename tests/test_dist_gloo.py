@@ -208,3 +208,49 @@ def test_packed_one_collective_path_and_config_sharding_world2(P, A, batch):
 def test_config_sharding_needs_a_batch():
     with pytest.raises(ValueError):
         ShardedSDF(OracleLeaf(), shard="rows")
+
+
+def chamfer_worker(rank, world, port, N, results):
+    """sharded_chamfer with the kernel half (chamfer.chamfer_partial_sums) replaced by the oracle on the CPU: what is under
+    test is the split, the empty shard, the all-reduce of B float64 sums + the count and the division by the GLOBAL N."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from pytorch_volumetric_amd import chamfer
+        leaf = OracleLeaf()
+        seen = []
+
+        def partial_sums_on_the_cpu(W, points, obj_factory, obj_sdf, scale):
+            pts = torch.as_tensor(points).reshape(-1, 3)
+            seen.append(pts.shape[0])
+            sums = oracle.chamfer_grid(obj_sdf.grid, W.numpy(), pts.numpy(), scale) if len(pts) else np.zeros(len(W))
+            return torch.from_numpy(sums), pts.shape[0]
+
+        chamfer.chamfer_partial_sums = partial_sums_on_the_cpu
+        B = 3
+        W = H.random_rigid(B, seed=21, trans=0.05)
+        pts = H.uniform_points(N, [-0.1] * 3, [0.2] * 3, seed=22)
+        got = pv.sharded_chamfer(W, pts, obj_sdf=leaf, scale=1000.0)
+        whole = oracle.chamfer_grid(leaf.grid, W.numpy(), pts.numpy(), 1000.0) / N
+        start, stop, _ = shard_range(N, world, rank)
+        ok = seen == [stop - start] and got.shape == (B,) and got.dtype == W.dtype
+        # float64 partial sums in a different order than the single loop: 1e-12 relative, not bit equality
+        ok = ok and np.allclose(got.double().numpy(), whole, rtol=1e-6 if got.dtype == torch.float32 else 1e-12, atol=0)
+        results[rank] = (bool(ok), stop - start)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("N,world", [(1001, 2), (1, 2), (2, 3), (7, 3)])
+def test_sharded_chamfer_unequal_and_empty_shards(N, world):
+    """an odd point count (unequal shards) and fewer points than ranks (a rank whose shard is empty adds
+    zero sums and a zero count): the mean is over the global N either way (chamfer.py:79-94)."""
+    port = free_port()
+    results = mp.Manager().dict()
+    mp.spawn(chamfer_worker, args=(world, port, N, results), nprocs=world, join=True)
+    got = dict(results)
+    assert all(ok for ok, _ in got.values()), got
+    assert sum(n for _, n in got.values()) == N
+    if N < world:
+        assert any(n == 0 for _, n in got.values())

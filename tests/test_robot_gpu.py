@@ -46,7 +46,7 @@ def synthetic_arm(tmp_path, n_links=8):
                      f'<mesh filename="{names[i]}"/></geometry></visual></link>')
     for i in range(n_links - 1):
         parts.append(f'<joint name="j{i}" type="revolute"><parent link="link_{i}"/><child link="link_{i + 1}"/>'
-                     f'<origin xyz="0 0 0.18" rpy="0 0 0"/><axis xyz="{axes[i]}"/></joint>')
+                     f'<origin xyz="0 0 0.18" rpy="0 0 0"/><axis xyz="{axes[i % 7]}"/></joint>')
     parts.append('</robot>')
     return pv.build_serial_chain_from_urdf("\n".join(parts), f"link_{n_links - 1}")
 
@@ -223,6 +223,92 @@ def test_configure_and_query_into_is_two_launches_and_graph_capturable(tmp_path)
     assert torch.equal(val, v2) and torch.equal(grad.nan_to_num(7.0), g2.nan_to_num(7.0))
 
 
+def test_float64_queries_follow_a_stack_rewritten_in_place(tmp_path):
+    """configure_and_query_into re-writes its transform stack in place and skips set_transforms from the second call
+    on; the float64 widening of that stack (the float64 query path's own copy) must not survive it."""
+    robot = pv.RobotSDF(synthetic_arm(str(tmp_path)), path_prefix=str(tmp_path),
+                        link_sdf_cls=pv.cache_link_sdf_factory(resolution=0.02, padding=0.1, device="cuda", cache_path=None))
+    A, P = 6, 3000
+    g = torch.Generator().manual_seed(5)
+    q1, q2 = (torch.randn(A, 7, generator=g) * 0.6).cuda(), (torch.randn(A, 7, generator=g) * 0.6).cuda()
+    pts = H.uniform_points(P, [-0.5, -0.5, -0.1], [0.5, 0.5, 1.2], seed=4).cuda()
+    val, grad = torch.empty((A, P), device="cuda"), torch.empty((A, P, 3), device="cuda")
+    robot.configure_and_query_into(q1, pts, val, grad)
+    v1, _ = robot(pts.double())
+    frames1 = robot.object_to_link_frames.get_matrix().clone()
+    held = robot.object_to_link_frames  # what a caller keeps must not change under it on the next call
+    held_composed = robot.sdf.obj_frame_to_link_frame
+    robot.configure_and_query_into(q2, pts, val, grad)
+    v2, g2 = robot(pts.double())
+    assert torch.equal(held.get_matrix(), frames1) and torch.equal(held_composed.get_matrix(), frames1)
+    assert not torch.equal(robot.object_to_link_frames.get_matrix(), frames1)
+    bb2 = robot.sdf.surface_bounding_box(padding=0.0).clone()
+    robot.set_joint_configuration(q2)
+    w2, h2 = robot(pts.double())
+    assert v2.dtype == torch.float64 and not torch.equal(v1, v2)
+    assert torch.equal(v2, w2) and torch.equal(g2.nan_to_num(7.0), h2.nan_to_num(7.0))
+    assert torch.equal(bb2, robot.sdf.surface_bounding_box(padding=0.0))
+
+
+@pytest.mark.parametrize("n_links", [30, 60])
+def test_robots_with_many_links_configure(tmp_path, n_links):
+    """the one-launch configure kernel stages the leaf frames of 64 configurations in LDS -- more than 64 KB of it
+    from 21 SDF-carrying links on (an opt-in attribute of the launch), and past ~50 links it does not fit at all: those robots
+    take sin / cos + pvamd_chain_fk + pvamd_transform_stack.  Both against the oracle's FK + stack, bit for bit."""
+    chain = synthetic_arm(str(tmp_path), n_links=n_links)
+    robot = pv.RobotSDF(chain, path_prefix=str(tmp_path),
+                        link_sdf_cls=pv.cache_link_sdf_factory(resolution=0.04, padding=0.1, device="cuda", cache_path=None))
+    S, M, A = n_links, n_links - 1, 70
+    assert len(robot.sdf.sdfs) == S and len(robot.joint_names) == M
+    q = (torch.randn(A, M, generator=torch.Generator().manual_seed(n_links)) * 0.4).cuda()
+    robot.set_joint_configuration(q)
+    stack = robot.object_to_link_frames.get_matrix()
+    assert stack.shape == (S * A, 4, 4) and bool(torch.isfinite(stack).all())
+    # the same fma chains as the two-launch path, whichever the robot took
+    lib = pv._lib.load()
+    joints, F = robot._joint_table_dev(q.device)
+    scratch = torch.empty((F, 12, A), device="cuda")
+    lw = torch.empty((S * A, 4, 4), device="cuda")
+    st = torch.empty((S * A, 4, 4), device="cuda")
+    if n_links <= 40:
+        sincos = torch.empty((A, M, 2), device="cuda")
+        pv._lib.check(lib.pvamd_configure_chain(joints.data_ptr(), F, q.data_ptr(), A, M, robot._offset_inv_dev(q.device).data_ptr(), S,
+                                                sincos.data_ptr(), scratch.data_ptr(), None, st.data_ptr(), pv._lib.stream_ptr()),
+                      "pvamd_configure_chain")
+        assert torch.equal(st, stack)
+        sin_q, cos_q = sincos[..., 0].contiguous(), sincos[..., 1].contiguous()
+    else:
+        rc = lib.pvamd_configure_chain(joints.data_ptr(), F, q.data_ptr(), A, M, robot._offset_inv_dev(q.device).data_ptr(), S,
+                                       None, scratch.data_ptr(), None, st.data_ptr(), pv._lib.stream_ptr())
+        assert rc == pv._lib.E_SHAPE
+        sin_q, cos_q = torch.sin(q), torch.cos(q)
+        val, grad = torch.empty((A, 64), device="cuda"), torch.empty((A, 64, 3), device="cuda")
+        with pytest.raises(ValueError, match="one-launch"):
+            robot.configure_and_query_into(q, torch.zeros(64, 3, device="cuda"), val, grad)
+    pv._lib.check(lib.pvamd_chain_fk(joints.data_ptr(), F, q.data_ptr(), sin_q.data_ptr(), cos_q.data_ptr(), A, M,
+                                     scratch.data_ptr(), lw.data_ptr(), pv._lib.stream_ptr()), "pvamd_chain_fk")
+    pv._lib.check(lib.pvamd_transform_stack(robot._offset_inv_dev(q.device).data_ptr(), lw.data_ptr(), S, A, st.data_ptr(),
+                                            pv._lib.stream_ptr()), "pvamd_transform_stack")
+    torch.cuda.synchronize()
+    assert torch.equal(st, stack)
+    # ... and the query over that many leaves answers like the per-configuration loop
+    pts = H.uniform_points(2000, [-0.5, -0.5, -0.1], [0.5, 0.5, 0.18 * n_links], seed=9).cuda()
+    v, g = robot(pts)
+    robot.set_joint_configuration(q[3])
+    v3, g3 = robot(pts)
+    assert torch.equal(v[3], v3) and torch.equal(g[3].nan_to_num(7.0), g3.nan_to_num(7.0))
+
+
+def test_joint_values_of_the_wrong_length_are_refused(tmp_path):
+    """a float32 GPU vector used where it is must still hold M values (the kernel indexes q[a * M + joint])."""
+    robot = pv.RobotSDF(synthetic_arm(str(tmp_path)), path_prefix=str(tmp_path),
+                        link_sdf_cls=pv.cache_link_sdf_factory(resolution=0.04, padding=0.1, device="cuda", cache_path=None))
+    for bad in (torch.zeros(5, device="cuda"), torch.zeros(5), torch.zeros(3, 6, device="cuda"), torch.zeros(9)):
+        with pytest.raises(ValueError, match="joint"):
+            robot.set_joint_configuration(bad)
+    robot.set_joint_configuration(torch.zeros(7, device="cuda"))
+
+
 def test_query_into_and_graph_replay(tmp_path):
     """A planner-style inner loop: set_joint_configuration + query_into captured once in a hipGraph and replayed."""
     chain = synthetic_arm(str(tmp_path))
@@ -359,6 +445,46 @@ def test_bucketed_path_returns_the_direct_path_bits_in_caller_order(P):
         assert torch.equal(v_b, v_direct) and torch.equal(g_b.nan_to_num(4.0), g_direct.nan_to_num(4.0))
     robot.sdf.bucket_points = "auto"
     assert robot.sdf._bucketing_pays(200, 1 << 18) and not robot.sdf._bucketing_pays(2, 1 << 18)
+
+
+@pytest.mark.parametrize("P", [20_480, 20_481, 777, 1])
+def test_prepared_points_return_the_direct_path_bits(P):
+    """prepare_points once, query_prepared under several joint configurations: order="caller" is __call__'s result (shape and
+    bits) without the per-call sort; order="sorted" is the same bits in the handle's order, with neither sort nor un-permute
+    pass.  Both grid sizes (= both index modes), point counts on and off the tile width, batched point dims, float64 in."""
+    import workloads as Wk
+    for padding in (0.1, 1.0):
+        robot = Wk.build_c4(resolution=0.02, padding=padding)
+        pts = Wk.c4_points(P, seed=6)
+        handle = robot.prepare_points(pts)
+        assert len(handle) == P and handle.order.dtype == torch.int32
+        assert torch.equal(handle.sorted_points, pts[handle.order.long()])
+        assert torch.equal(handle.inverse.long()[handle.order.long()], torch.arange(P, device="cuda"))
+        for A, seed in ((9, 5), (1, 6), (9, 7)):
+            robot.set_joint_configuration(Wk.c4_joint_configs(A, seed=seed) if A > 1 else Wk.c4_joint_configs(2, seed=seed)[1])
+            robot.sdf.bucket_points = False
+            v_direct, g_direct = robot(pts)
+            robot.sdf.bucket_points = "auto"
+            v_c, g_c = robot.query_prepared(handle)
+            v_s, g_s = robot.query_prepared(handle, order="sorted")
+            assert v_c.shape == v_direct.shape and g_c.shape == g_direct.shape
+            assert torch.equal(v_c, v_direct) and torch.equal(g_c.nan_to_num(4.0), g_direct.nan_to_num(4.0))
+            idx = handle.order.long()
+            assert torch.equal(v_s, v_direct[..., idx]) and torch.equal(g_s.nan_to_num(4.0), g_direct[..., idx, :].nan_to_num(4.0))
+    if P == 20_480:  # batched point dims and a float64 / host point set come back like __call__'s
+        robot.set_joint_configuration(Wk.c4_joint_configs(3, seed=2))
+        batched = pts.reshape(10, 2048, 3).double().cpu()
+        h2 = robot.prepare_points(batched)
+        robot.sdf.bucket_points = False
+        v_direct, g_direct = robot(batched.float().cuda())
+        robot.sdf.bucket_points = "auto"
+        v_c, g_c = robot.query_prepared(h2)
+        assert v_c.shape == (3, 10, 2048) and g_c.shape == (3, 10, 2048, 3) and v_c.dtype == torch.float64
+        assert torch.equal(v_c.float(), v_direct) and torch.equal(g_c.float().nan_to_num(4.0), g_direct.nan_to_num(4.0))
+        v_s, _ = robot.query_prepared(h2, order="sorted")
+        assert v_s.shape == (3, 20_480) and torch.equal(v_s.float(), v_direct.reshape(3, -1)[:, h2.order.long()])
+        with pytest.raises(ValueError, match="order"):
+            robot.query_prepared(h2, order="hilbert")
 
 
 def test_auto_bucketing_looks_at_what_the_query_can_touch():
