@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define PVAMD_ABI_VERSION 9
+#define PVAMD_ABI_VERSION 10
 
 #define PVAMD_E_NULL      (-1)  /* a required pointer is NULL            */
 #define PVAMD_E_SHAPE     (-2)  /* a size/shape argument is out of range */
@@ -293,12 +293,14 @@ int pvamd_morton_keys(const float* points, int64_t P, const float* box, int32_t*
  * order_out: device [P] int32.  inv_out: device [P] int32 or NULL, inv[order[k]] = k.  sorted_points_out: device [P][3] or
  * NULL, the points in that order.  scratch: device, PVAMD_MORTON_ORDER_SCRATCH_BYTES(P) bytes, 4-byte aligned.          */
 #define PVAMD_MORTON_ORDER_BITS(P) ((P) >= (1 << 20) ? 21 : ((P) >= (1 << 16) ? 18 : 15))
-/* from 1.5 million points on: (cell, index) pairs through rocPRIM's radix sort (stable: the points of a cell in index
- * order) -- keys, indices, sorted keys and the library's temporary storage in scratch                            */
-#define PVAMD_ORDER_LIBRARY_SORT_FROM (3 << 19)  /* 1.5 M: the counting sort still wins at 1 M (0.165 against 0.196 ms) */
-#define PVAMD_ORDER_LIBRARY_TEMP_BYTES(P) (8 * (int64_t)(P) + (int64_t)(P) / 32 * 4 + (4 << 20))  /* rocPRIM 4.2 asks for 8.063 B per pair (tools/rocprim_temp.hip); + 256 for its alignment, below */
-#define PVAMD_MORTON_ORDER_SCRATCH_BYTES(P) ((P) >= PVAMD_ORDER_LIBRARY_SORT_FROM \
-    ? 4 * (8 + 3 * (int64_t)(P)) + 256 + PVAMD_ORDER_LIBRARY_TEMP_BYTES(P) \
+/* from 786,432 points on: (cell, index) pairs through a stable LSD radix sort (three 7-bit passes over 4096-pair tiles;
+ * csrc/sort.hip) -- the points of a cell come out in index order.  Scratch: bounds codes, supergroup totals and the tile
+ * histogram table (<= 512 words per tile), two key and two index arrays.                                             */
+#ifndef PVAMD_ORDER_RADIX_SORT_FROM
+#define PVAMD_ORDER_RADIX_SORT_FROM (3 << 18)  /* 786,432: counting sort 0.078 ms at 512 k, 0.166 at 1 M; radix 0.097 / 0.105 (profiles/r05_sort.txt) */
+#endif
+#define PVAMD_MORTON_ORDER_SCRATCH_BYTES(P) ((P) >= PVAMD_ORDER_RADIX_SORT_FROM \
+    ? 4 * (8 + 4 * (int64_t)(P) + 512 * (((int64_t)(P) + 4095) / 4096)) \
     : 4 * (8 + (1 << PVAMD_MORTON_ORDER_BITS(P)) + (int64_t)(P) + 2048))
 int pvamd_morton_order(const float* points, int64_t P, int32_t* order_out, int32_t* inv_out, float* sorted_points_out,
                        void* scratch, void* stream);

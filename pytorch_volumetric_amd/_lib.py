@@ -11,7 +11,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("PVAMD_LIB") or os.path.join(_HERE, "csrc", "libpvamd.so")  # PVAMD_LIB: A/B builds (tools/)
 
-ABI_VERSION = 9
+ABI_VERSION = 10
 OOB_LOOKUP_GT_SDF = 0
 OOB_BOUNDING_BOX = 1
 COMPOSED_INLINE_EXACT = 1
@@ -308,10 +308,13 @@ def as_query_points(points, device=None, keep_f64=False):
     return flat, lead, points.dtype if points.dtype.is_floating_point else torch.float32, points.device
 
 
+ORDER_RADIX_SORT_FROM = int(os.environ.get("PVAMD_RADIX_FROM", 3 << 18))  # PVAMD_ORDER_RADIX_SORT_FROM (the env: A/B builds only)
+
+
 def morton_order_scratch_words(P):
     """PVAMD_MORTON_ORDER_SCRATCH_BYTES(P) / 4"""
-    if P >= (3 << 19):  # the library radix sort: keys, indices, sorted keys + its temporary storage (and its alignment)
-        return 8 + 3 * P + 64 + (8 * P + P // 32 * 4 + (4 << 20)) // 4
+    if P >= ORDER_RADIX_SORT_FROM:  # the radix sort: supergroup totals + tile histograms (<= 512 words per 4096-pair tile), 2 key + 2 index arrays
+        return 8 + 4 * P + 512 * ((P + 4095) // 4096)
     return 8 + (1 << (21 if P >= (1 << 20) else (18 if P >= (1 << 16) else 15))) + P + 2048
 
 

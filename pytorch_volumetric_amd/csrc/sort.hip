@@ -1,4 +1,5 @@
-// Spatial processing order of a point set in seven small launches: bounds, Morton cell counts, scan (3), scatter.
+// Spatial processing order of a point set: up to 786,432 points in seven small launches (bounds, curve cell counts, scan (3),
+// scatter); beyond, an LSD radix sort of (cell, index) pairs (below).  All hand-written: no library call on this path.
 // Replaces `torch.argsort(morton keys)` (a ~10-launch rocprim radix sort, ~60 us for 10 k points and 0.14 ms for 262 k:
 // more than the mesh query of BASELINE C1 itself) in front of the mesh kernels and of the bucketed composed path.
 //
@@ -10,7 +11,6 @@
 // differ from run to run, and no result depends on it (the mesh kernels and the composed kernel return the same bits
 // for any processing order; tests/test_mesh_gpu.py, tests/test_robot_gpu.py).
 #include <cstring>
-#include <rocprim/device/device_radix_sort.hpp>
 #include "common.h"
 #include "morton.h"
 #include "order_small.h"
@@ -160,22 +160,188 @@ __global__ __launch_bounds__(256) void order_scatter_kernel(const float* __restr
     }
 }
 
-// ---- 1.5 million points and more: keys + a library radix sort ----
+// ---- 786,432 points and more: an LSD radix sort of (cell, index) pairs ----
 // The counting sort's two passes of P random atomics over 2^21 counters (8 MB: they execute memory-side) take 0.28 ms for
-// 2 M points and grow linearly; rocPRIM's radix sort of the same (cell, index) pairs over the 21 key bits takes about a
-// third of that (profiles/r04_mesh_variants.txt, section 10).  It is stable: points of one cell come out in index order.
-__global__ __launch_bounds__(256) void order_keys_kernel(const float* __restrict__ pts, int64_t P, const unsigned* __restrict__ box,
-                                                         unsigned* __restrict__ keys, int* __restrict__ index, int bits_per_axis) {
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= P) return;
+// 2 M points and grow linearly.  Here the 21 key bits go in three stable passes of 7 bits over 4096-pair tiles:
+//   histogram   one block per tile counts its 128 digits in LDS -> table[tile][digit], and adds them to the totals of its
+//               SUPERGROUP of G ~ sqrt(tiles) consecutive tiles (a few atomics per block; pass 1 computes the keys as well)
+//   scatter     one block per tile: where its keys of digit d go = (keys of smaller digits anywhere) + (digit d in earlier
+//               supergroups) + (digit d in earlier tiles of its own supergroup) -- 2 sqrt(tiles) coalesced, L2-resident
+//               reads per thread instead of a scan launch over the table; ranks inside the tile are STABLE (per wave,
+//               64 keys a round: the lanes that hold the same digit find each other with 7 ballots, the lowest of them
+//               bumps the wave's digit counter); the tile is reordered in LDS and leaves in runs of consecutive addresses
+// Stable throughout: the points of one cell come out in index order, the same permutation on every run.  Round 4 called
+// rocprim::radix_sort_pairs here (3 x 23.6 us + 4.9 us at 2 M pairs; 1.9 MB of template instantiations in the .so).
+constexpr int kRadixBits = 7;
+constexpr int kRadixBins = 1 << kRadixBits;
+constexpr int kRadixThreads = 256;
+constexpr int kRadixRounds = 16;                          // keys per thread
+constexpr int kRadixTile = kRadixThreads * kRadixRounds;  // 4096 pairs per block
+constexpr int kRadixMaxPasses = 3;
+static_assert(PVAMD_MORTON_ORDER_BITS(1ll << 40) <= kRadixBits * kRadixMaxPasses, "more key bits than radix passes");
+
+// table[tile][digit] and the supergroup totals from this block's LDS histogram
+PVAMD_DEV void radix_publish_histogram(const unsigned* hist, unsigned* __restrict__ table, unsigned* __restrict__ sgtotal, int G) {
+    if (threadIdx.x < kRadixBins) {
+        const unsigned c = hist[threadIdx.x];
+        table[(int64_t)blockIdx.x * kRadixBins + threadIdx.x] = c;
+        if (c) atomicAdd(sgtotal + (int64_t)(blockIdx.x / G) * kRadixBins + threadIdx.x, c);
+    }
+}
+
+// pass 1: the keys (cell along the curve) of one tile and the histogram of their lowest digit
+__global__ __launch_bounds__(kRadixThreads) void radix_keys_hist_kernel(const float* __restrict__ pts, int64_t P,
+                                                                         const unsigned* __restrict__ box,
+                                                                         unsigned* __restrict__ keys, int bits_per_axis,
+                                                                         unsigned* __restrict__ table,
+                                                                         unsigned* __restrict__ sgtotal, int G) {
+    __shared__ unsigned hist[kRadixBins];
+    if (threadIdx.x < kRadixBins) hist[threadIdx.x] = 0u;
     float lo[3], hi[3];
 #pragma unroll
     for (int d = 0; d < 3; ++d) {
         lo[d] = order_decode(box[d]);
         hi[d] = order_decode(box[3 + d]);
     }
-    keys[i] = PVAMD_ORDER_KEY(pts[3 * i], pts[3 * i + 1], pts[3 * i + 2], lo, hi, bits_per_axis) >> (30 - 3 * bits_per_axis);
-    index[i] = (int)i;
+    __syncthreads();
+    const int64_t t0 = (int64_t)blockIdx.x * kRadixTile;
+    for (int r = 0; r < kRadixRounds; ++r) {
+        const int64_t i = t0 + r * kRadixThreads + threadIdx.x;
+        if (i < P) {
+            const unsigned key = PVAMD_ORDER_KEY(pts[3 * i], pts[3 * i + 1], pts[3 * i + 2], lo, hi, bits_per_axis) >> (30 - 3 * bits_per_axis);
+            keys[i] = key;
+            atomicAdd(&hist[key & (kRadixBins - 1)], 1u);
+        }
+    }
+    __syncthreads();
+    radix_publish_histogram(hist, table, sgtotal, G);
+}
+
+__global__ __launch_bounds__(kRadixThreads) void radix_hist_kernel(const unsigned* __restrict__ keys, int64_t P, int shift,
+                                                                    unsigned* __restrict__ table,
+                                                                    unsigned* __restrict__ sgtotal, int G) {
+    __shared__ unsigned hist[kRadixBins];
+    if (threadIdx.x < kRadixBins) hist[threadIdx.x] = 0u;
+    __syncthreads();
+    const int64_t t0 = (int64_t)blockIdx.x * kRadixTile;
+#pragma unroll 4
+    for (int r = 0; r < kRadixRounds; ++r) {
+        const int64_t i = t0 + r * kRadixThreads + threadIdx.x;
+        if (i < P) atomicAdd(&hist[(keys[i] >> shift) & (kRadixBins - 1)], 1u);
+    }
+    __syncthreads();
+    radix_publish_histogram(hist, table, sgtotal, G);
+}
+
+// inclusive sum over the 64 lanes of a wave
+PVAMD_DEV unsigned wave_inclusive_sum(unsigned v, int lane) {
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const unsigned up = __shfl_up(v, off, 64);
+        if (lane >= off) v += up;
+    }
+    return v;
+}
+
+// FIRST: the index of a pair is its position (no index array yet).  LAST: only the indices leave (the order).
+template <bool FIRST, bool LAST>
+__global__ __launch_bounds__(kRadixThreads) void radix_scatter_kernel(const unsigned* __restrict__ keys_in,
+                                                                       const int* __restrict__ idx_in, int64_t P, int shift,
+                                                                       const unsigned* __restrict__ table,
+                                                                       const unsigned* __restrict__ sgtotal, int G, int nsg,
+                                                                       unsigned* __restrict__ keys_out, int* __restrict__ idx_out) {
+    __shared__ unsigned wave_hist[kRadixThreads / 64][kRadixBins];  // a wave's running digit counts, then its offset inside the tile's digit run
+    __shared__ unsigned base[kRadixBins];        // global position of the tile's first key of digit d, minus tile_start[d]
+    __shared__ unsigned tile_start[kRadixBins];  // where digit d starts inside the reordered tile
+    __shared__ unsigned carry[2];
+    __shared__ unsigned skeys[kRadixTile];
+    __shared__ int sidx[kRadixTile];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tile = blockIdx.x, sg = tile / G;
+    const int64_t t0 = (int64_t)tile * kRadixTile;
+    const int n = (int)(P - t0 < kRadixTile ? P - t0 : kRadixTile);
+    for (int k = tid; k < (kRadixThreads / 64) * kRadixBins; k += kRadixThreads) (&wave_hist[0][0])[k] = 0u;
+    // phase 0: where this tile's keys of digit d (= tid) start in the output
+    unsigned tot = 0, pre = 0;
+    if (tid < kRadixBins) {
+        for (int s2 = 0; s2 < nsg; ++s2) {
+            const unsigned c = sgtotal[(int64_t)s2 * kRadixBins + tid];
+            tot += c;
+            pre += s2 < sg ? c : 0u;
+        }
+        for (int t = sg * G; t < tile; ++t) pre += table[(int64_t)t * kRadixBins + tid];
+    }
+    const unsigned inc = wave_inclusive_sum(tot, lane);
+    if (tid == 63) carry[0] = inc;
+    __syncthreads();
+    if (tid < kRadixBins) base[tid] = inc - tot + (tid >= 64 ? carry[0] : 0u) + pre;
+    // phase 1: stable rank of every key among the keys of its digit in its wave's 1024-key slice (round by round)
+    unsigned key[kRadixRounds];
+    int idx[kRadixRounds];
+    unsigned rank[kRadixRounds];
+    const uint64_t below = (1ull << lane) - 1ull;
+#pragma unroll
+    for (int r = 0; r < kRadixRounds; ++r) {
+        const int e = wave * (64 * kRadixRounds) + r * 64 + lane;
+        const bool live = e < n;
+        key[r] = live ? keys_in[t0 + e] : 0xffffffffu;
+        if (!FIRST) idx[r] = live ? idx_in[t0 + e] : 0;
+        const unsigned d = (key[r] >> shift) & (kRadixBins - 1);
+        uint64_t same = __builtin_amdgcn_ballot_w64(live);
+#pragma unroll
+        for (int b = 0; b < kRadixBits; ++b) {
+            const bool bit = (d >> b) & 1u;
+            const uint64_t with = __builtin_amdgcn_ballot_w64(bit);
+            same &= bit ? with : ~with;
+        }
+        const unsigned before = (unsigned)__popcll(same & below);
+        const unsigned old = wave_hist[wave][d];
+        PVAMD_WAVE_SYNC();  // every lane has read the counter before the digit's first lane moves it
+        if (live && before == 0) wave_hist[wave][d] = old + (unsigned)__popcll(same);
+        PVAMD_WAVE_SYNC();
+        rank[r] = old + before;
+    }
+    __syncthreads();
+    // phase 2: the waves' counts per digit -> each wave's offset inside the digit's run; the runs' starts inside the tile
+    unsigned cnt = 0;
+    if (tid < kRadixBins) {
+        unsigned run = 0;
+#pragma unroll
+        for (int w2 = 0; w2 < kRadixThreads / 64; ++w2) {
+            const unsigned c = wave_hist[w2][tid];
+            wave_hist[w2][tid] = run;
+            run += c;
+        }
+        cnt = run;
+    }
+    const unsigned inc2 = wave_inclusive_sum(cnt, lane);
+    if (tid == 63) carry[1] = inc2;
+    __syncthreads();
+    if (tid < kRadixBins) {
+        const unsigned start = inc2 - cnt + (tid >= 64 ? carry[1] : 0u);
+        tile_start[tid] = start;
+        base[tid] -= start;  // (unsigned wrap-around is fine: base[d] + position inside the tile is the global position)
+    }
+    __syncthreads();
+    // phase 3: the tile in digit order, in LDS
+#pragma unroll
+    for (int r = 0; r < kRadixRounds; ++r) {
+        const int e = wave * (64 * kRadixRounds) + r * 64 + lane;
+        if (e < n) {
+            const unsigned d = (key[r] >> shift) & (kRadixBins - 1);
+            const unsigned at = tile_start[d] + wave_hist[wave][d] + rank[r];
+            skeys[at] = key[r];
+            sidx[at] = FIRST ? (int)(t0 + e) : idx[r];
+        }
+    }
+    __syncthreads();
+    // phase 4: out, in runs of consecutive addresses (one run per digit)
+    for (int i = tid; i < n; i += kRadixThreads) {
+        const unsigned k = skeys[i];
+        const unsigned g = base[(k >> shift) & (kRadixBins - 1)] + (unsigned)i;
+        if (!LAST) keys_out[g] = k;
+        idx_out[g] = sidx[i];
+    }
 }
 
 __global__ __launch_bounds__(256) void order_gather_kernel(const float* __restrict__ pts, int64_t P, const int* __restrict__ order,
@@ -212,23 +378,45 @@ extern "C" int pvamd_morton_order(const float* points, int64_t P, int32_t* order
         return (int)hipGetLastError();
     }
     unsigned* w = reinterpret_cast<unsigned*>(scratch);
-    if (P >= PVAMD_ORDER_LIBRARY_SORT_FROM) {
-        // scratch: [8] bounds codes | keys [P] | index [P] | sorted keys [P] | the library's temporary storage
+    if (P >= PVAMD_ORDER_RADIX_SORT_FROM) {
+        // scratch (words): [8] bounds codes | supergroup totals [3][nsg][128] | table [tiles][128] | keys A [P] | keys B [P] |
+        // index A [P] | index B [P]
         const int64_t want = (P + 255) / 256;
-        hipLaunchKernelGGL(order_init_kernel, dim3(1), dim3(256), 0, s, w, 0);
-        hipLaunchKernelGGL(order_bounds_kernel, dim3(want < 512 ? (unsigned)want : 512u), dim3(256), 0, s, points, P, w);  // (2048 blocks: 30-52 us for 2 M points against 20 -- they all reach their six atomics at once)
-        unsigned* keys = w + kBoxWords;
-        int* index = reinterpret_cast<int*>(keys + P);
-        unsigned* keys_sorted = reinterpret_cast<unsigned*>(index + P);
-        void* temp = reinterpret_cast<void*>((reinterpret_cast<uintptr_t>(keys_sorted + P) + 255) & ~(uintptr_t)255);  // the library's alignment
+        const int64_t tiles = (P + kRadixTile - 1) / kRadixTile;
+        int G = 1;
+        while ((int64_t)G * G < tiles) ++G;  // ~sqrt(tiles) tiles per supergroup
+        const int nsg = (int)((tiles + G - 1) / G);
         const int bits = PVAMD_MORTON_ORDER_BITS(P);
-        hipLaunchKernelGGL(order_keys_kernel, dim3((unsigned)want), dim3(256), 0, s, points, P, w, keys, index, bits / 3);
-        size_t need = 0;
-        hipError_t e = rocprim::radix_sort_pairs(nullptr, need, keys, keys_sorted, index, order_out, (size_t)P, 0u, (unsigned)bits, s);
-        if (e != hipSuccess) return (int)e;
-        if (need > (size_t)PVAMD_ORDER_LIBRARY_TEMP_BYTES(P)) return PVAMD_E_SHAPE;  // the header's bound no longer holds
-        e = rocprim::radix_sort_pairs(temp, need, keys, keys_sorted, index, order_out, (size_t)P, 0u, (unsigned)bits, s);
-        if (e != hipSuccess) return (int)e;
+        const int passes = (bits + kRadixBits - 1) / kRadixBits;
+        unsigned* sgtotal = w + kBoxWords;
+        unsigned* table = sgtotal + (int64_t)kRadixMaxPasses * nsg * kRadixBins;
+        unsigned* keys[2] = {table + tiles * kRadixBins, table + tiles * kRadixBins + P};
+        int* index[2] = {reinterpret_cast<int*>(keys[1] + P), reinterpret_cast<int*>(keys[1] + 2 * P)};
+        const int zero_words = kRadixMaxPasses * nsg * kRadixBins;
+        hipLaunchKernelGGL(order_init_kernel, dim3((zero_words + 255) / 256), dim3(256), 0, s, w, zero_words);
+        hipLaunchKernelGGL(order_bounds_kernel, dim3(want < 512 ? (unsigned)want : 512u), dim3(256), 0, s, points, P, w);  // (2048 blocks: 30-52 us for 2 M points against 20 -- they all reach their six atomics at once)
+        for (int p = 0; p < passes; ++p) {
+            unsigned* sgt = sgtotal + (int64_t)p * nsg * kRadixBins;
+            const unsigned* kin = keys[p & 1];
+            unsigned* kout = keys[(p + 1) & 1];
+            const int* iin = index[p & 1];
+            int* iout = p == passes - 1 ? order_out : index[(p + 1) & 1];
+            const int shift = p * kRadixBits;
+            if (p == 0)
+                hipLaunchKernelGGL(radix_keys_hist_kernel, dim3((unsigned)tiles), dim3(kRadixThreads), 0, s, points, P, w, keys[0], bits / 3,
+                                   table, sgt, G);
+            else
+                hipLaunchKernelGGL(radix_hist_kernel, dim3((unsigned)tiles), dim3(kRadixThreads), 0, s, kin, P, shift, table, sgt, G);
+            const bool first = p == 0, last = p == passes - 1;
+            if (first && last)
+                hipLaunchKernelGGL((radix_scatter_kernel<true, true>), dim3((unsigned)tiles), dim3(kRadixThreads), 0, s, kin, iin, P, shift, table, sgt, G, nsg, kout, iout);
+            else if (first)
+                hipLaunchKernelGGL((radix_scatter_kernel<true, false>), dim3((unsigned)tiles), dim3(kRadixThreads), 0, s, kin, iin, P, shift, table, sgt, G, nsg, kout, iout);
+            else if (last)
+                hipLaunchKernelGGL((radix_scatter_kernel<false, true>), dim3((unsigned)tiles), dim3(kRadixThreads), 0, s, kin, iin, P, shift, table, sgt, G, nsg, kout, iout);
+            else
+                hipLaunchKernelGGL((radix_scatter_kernel<false, false>), dim3((unsigned)tiles), dim3(kRadixThreads), 0, s, kin, iin, P, shift, table, sgt, G, nsg, kout, iout);
+        }
         if (inv_out || sorted_points_out)
             hipLaunchKernelGGL(order_gather_kernel, dim3((unsigned)want), dim3(256), 0, s, points, P, order_out, inv_out, sorted_points_out);
         return (int)hipGetLastError();

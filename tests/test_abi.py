@@ -35,6 +35,16 @@ def test_every_declared_symbol_is_exported_and_bound():
     assert sorted(_lib.SIGNATURES) == names, "ctypes binding and header disagree"
 
 
+def test_no_library_kernels_inside_the_shared_object():
+    """VERDICT r4 item 5: the spatial sort called rocprim::radix_sort_pairs from 1.5 M points on; the hot path is hand-written
+    throughout now -- no rocPRIM / hipCUB / Thrust instantiation is linked into libpvamd.so."""
+    out = subprocess.run(["nm", "-C", _lib.LIB_PATH], capture_output=True, text=True, check=True).stdout
+    for lib_name in ("rocprim", "hipcub", "thrust", "rocblas", "hipblas"):
+        assert lib_name not in out.lower(), f"{lib_name} symbols in libpvamd.so"
+    src = open(os.path.join(ROOT, "pytorch_volumetric_amd", "csrc", "sort.hip")).read()
+    assert "#include <rocprim" not in src
+
+
 def test_struct_layouts_match_the_header():
     """Compile a tiny C program against the header and compare sizeof/offsetof with the ctypes mirrors."""
     src = r'''
