@@ -735,7 +735,8 @@ def compact_line(d, detail_name):
                 "vs_baseline", "dtype", "data")
     line["config"] = pick(cfg, "workload", "points_per_gpu", "oob_fraction", "ranks", "backend", "gather", "launch")
     line["roofline"] = pick(roof, "bound", "achieved", "peak", "unit", "frac", "traffic", "algorithmic_bytes_per_launch", "kernel",
-                            "launch_us", "launch_source", "frac_rocprof", "frac_events", "launch_us_events", "frac_of_wall_ms_per_step")
+                            "launch_us", "launch_source", "frac_rocprof", "frac_events", "launch_us_events", "frac_of_wall_ms_per_step",
+                            "copy_same_bytes_us", "copy_same_bytes_frac")
     cpu = d.get("cpu_baseline")
     if cpu:
         line["cpu_baseline"] = pick(cpu, "value", "unit", "cores", "kind", "sample", "host_cpus", "baseline_opforop", "baseline_fused")
@@ -860,6 +861,15 @@ def main():
     torch.cuda.synchronize()
     k_ms, k_ms_best = graph_ms_per_launch(torch, kgraph, kg_n, reps=5, stats=True)
     del kgraph
+    # yardstick, timed the same way: a plain device-to-device copy that moves the same bytes (14 MB read + 14 MB written for
+    # the 1M-point launch; torch's own copy kernel) -- what the chip does with 28 MB per launch, launch ramp included
+    half = BYTES_PER_QUERY * P // 2 // 4
+    c_src, c_dst = torch.empty(half, dtype=torch.float32, device="cuda"), torch.empty(half, dtype=torch.float32, device="cuda")
+    cgraph = capture_graph(torch, lambda: c_dst.copy_(c_src), kg_n)
+    cgraph.replay()
+    torch.cuda.synchronize()
+    copy_ms = graph_ms_per_launch(torch, cgraph, kg_n, reps=3)
+    del cgraph, c_src, c_dst
     e_mean, e_med, e_min = time_eager_kernel(torch, np, step, 200)
     # the drop-in call itself -- what a user of the reference writes: val, grad = sdf(points) (sdf.py:535-591), outputs allocated
     d_call, d_sync = time_calls(torch, np, lambda: cached(pts), reps=400)
@@ -906,6 +916,8 @@ def main():
                                          "ms_per_call": d_call, "queries_per_s": P / (d_call * 1e-3),
                                          "ms_per_call_synchronized_each": d_sync,
                                          "timing": "400 calls back to back + one synchronize; median of 200 synchronized calls"},
+                         "copy_same_bytes_us": copy_ms * 1e3, "copy_same_bytes_frac": algo / (copy_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                         "copy_is": "torch d2d copy of half the bytes (same traffic), same hipGraph timing",
                          "frac_of_wall_ms_per_step": algo / (elapsed / args.steps) / 1e9 / HBM_PEAK_GBS},
             "valu_model": valu_model(),
         }

@@ -128,6 +128,10 @@ extern "C" int pvamd_grid_finalize(pvamd_grid_t* g) {
         g->err32[d] = (float)((2.0 * 5.97e-8 / res * (1.0 + 2.0 * amin)) * (pmax + 1.0) +
                               2.5e-7 * (double)(g->shape[d] + (reach > 0.0 ? 1 : 0)));
     }
+    // one bound for all three axes (the largest): lets the kernels test the three estimates with one compare (grid_lookup.h
+    // estimate_unsure); a larger bound only sends a few more points to the exact statements
+    const float worst = std::fmax(g->err32[0], std::fmax(g->err32[1], g->err32[2]));
+    for (int d = 0; d < 3; ++d) g->err32[d] = worst;
     g->finalized = 1;
     return 0;
 }

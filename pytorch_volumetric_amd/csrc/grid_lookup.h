@@ -105,7 +105,16 @@ PVAMD_DEV bool in_range(const pvamd_grid_t& g, float x, float y, float z) {
 // The same test as a 64-bit LANE MASK, for the instruction-bound composed kernels: the ballot of ONE compare is that
 // compare's own SGPR result, and the six masks are combined with scalar ANDs -- whereas the ballot of an AND of compares
 // makes the backend materialise the bool (v_cndmask 0 / 1) and compare it with 0 again, two vector instructions per visit.
+// Round 5: per axis ONE v_med3_f32 + ONE compare -- x in [lo, hi] <=> med3(x, lo, hi) == x (a NaN fails the ==; -0 == +0 as
+// with <=) -- the same six vector instructions as six compares, but three lane masks to AND instead of six (the scalar unit is
+// as busy as the vector ones in these kernels): per-lane kernel 0.896 -> 0.866 ms on C4's workload, C3 0.0897 -> 0.0886 ms,
+// README slice 0.0572 -> 0.0561 ms; wave-tile kernel within noise (profiles/r05_composed_variants.txt).
 PVAMD_DEV uint64_t in_range_mask(const pvamd_grid_t& g, float x, float y, float z) {
+#ifndef PVAMD_RANGE_SIX_COMPARES
+    return __builtin_amdgcn_ballot_w64(__builtin_amdgcn_fmed3f(x, g.vlo[0], g.vhi[0]) == x) &
+           __builtin_amdgcn_ballot_w64(__builtin_amdgcn_fmed3f(y, g.vlo[1], g.vhi[1]) == y) &
+           __builtin_amdgcn_ballot_w64(__builtin_amdgcn_fmed3f(z, g.vlo[2], g.vhi[2]) == z);
+#endif
     return __builtin_amdgcn_ballot_w64(g.vlo[0] <= x) & __builtin_amdgcn_ballot_w64(x <= g.vhi[0]) &
            __builtin_amdgcn_ballot_w64(g.vlo[1] <= y) & __builtin_amdgcn_ballot_w64(y <= g.vhi[1]) &
            __builtin_amdgcn_ballot_w64(g.vlo[2] <= z) & __builtin_amdgcn_ballot_w64(z <= g.vhi[2]);
@@ -129,6 +138,20 @@ PVAMD_DEV int voxel_index_fast(const pvamd_grid_t& g, int d, float p) {
 PVAMD_DEV bool wave_all(bool p) { return __builtin_amdgcn_ballot_w64(p) == __builtin_amdgcn_ballot_w64(true); }
 PVAMD_DEV bool wave_any(bool p) { return __builtin_amdgcn_ballot_w64(p) != 0; }
 
+// Whether some coordinate's estimate t sits within its rounding bound of a half-integer (off[d] = t - rint(t)): the estimate
+// and the reference's quotient could then round differently.  pvamd_grid_finalize() stores ONE bound (the largest of the three
+// axes') in every err32[d], so the three tests "0.5 - |off_d| > err" are one: 0.5 - max_d |off_d| > err (the subtraction is
+// monotone) -- v_max3_f32 with |.| modifiers, a subtract and a compare instead of three of each.  A NaN offset is ignored by
+// the max: it only arises from a non-finite coordinate, which is never in range, and whose index nobody uses.
+PVAMD_DEV bool estimate_unsure(const pvamd_grid_t& g, const float off[3]) {
+#ifdef PVAMD_UNSURE_PER_AXIS
+    return !(sub_rn(0.5f, fabsf(off[0])) > g.err32[0]) | !(sub_rn(0.5f, fabsf(off[1])) > g.err32[1]) | !(sub_rn(0.5f, fabsf(off[2])) > g.err32[2]);
+#else
+    const float worst = __builtin_fmaxf(__builtin_fmaxf(fabsf(off[0]), fabsf(off[1])), fabsf(off[2]));
+    return !(sub_rn(0.5f, worst) > g.err32[0]);
+#endif
+}
+
 // Index estimate only (no exact fallback inline): returns the flat index of the estimate and sets `unsure` when some
 // coordinate sits within its rounding bound of a half-integer -- the caller then redoes that POINT with the exact
 // statements (voxel_flat<F64>) outside its hot loop, which keeps the float64 division sequence (and its registers) out
@@ -137,13 +160,15 @@ PVAMD_DEV bool wave_any(bool p) { return __builtin_amdgcn_ballot_w64(p) != 0; }
 PVAMD_DEV int voxel_flat_estimate(const pvamd_grid_t& g, float x, float y, float z, bool& unsure) {
     const float p[3] = {x, y, z};
     int k[3];
+    float off[3];
 #pragma unroll
     for (int d = 0; d < 3; ++d) {
         const float t = mul_rn(sub_rn(p[d], g.fmin[d]), g.inv32[d]);
         const float kc = __builtin_rintf(t);
-        unsure |= !(sub_rn(0.5f, fabsf(sub_rn(t, kc))) > g.err32[d]);  // NaN-safe: NaN is "unsure"
+        off[d] = sub_rn(t, kc);
         k[d] = (int)kc;
     }
+    unsure |= estimate_unsure(g, off);
     const unsigned flat = (unsigned)((k[0] * g.shape[1] + k[1]) * g.shape[2] + k[2]);
     const unsigned last = (unsigned)(g.shape[0] * g.shape[1] * g.shape[2] - 1);
     return (int)(flat < last ? flat : last);
@@ -156,14 +181,15 @@ PVAMD_DEV int voxel_flat_estimate(const pvamd_grid_t& g, float x, float y, float
 PVAMD_DEV int voxel_flat_in_range_fused(const pvamd_grid_t& g, float x, float y, float z) {
     const float p[3] = {x, y, z};
     int k[3];
-    bool unsure = false;
+    float off[3];
 #pragma unroll
     for (int d = 0; d < 3; ++d) {
         const float t = mul_rn(sub_rn(p[d], g.fmin[d]), g.inv32[d]);
         const float kc = __builtin_rintf(t);
-        unsure |= !(sub_rn(0.5f, fabsf(sub_rn(t, kc))) > g.err32[d]);  // NaN-safe: NaN takes the exact path
+        off[d] = sub_rn(t, kc);
         k[d] = (int)kc;
     }
+    const bool unsure = estimate_unsure(g, off);
     if (__builtin_expect(wave_any(unsure), 0)) {
         if (unsure) {
 #pragma unroll 1

@@ -2,10 +2,10 @@
 # The driver-shaped bench line + the rocprofv3 kernel trace of the SAME command + PMC traffic passes -> gpurun_out/$1/
 export TMPDIR=/tmp
 O=gpurun_out/$1; mkdir -p $O
-[ -z "$ONLY_KT" ] && python bench.py --gpus 1 --steps 20 --warmup 5 > $O/bench_k20.json 2> $O/bench_k20.err
-rocprofv3 --kernel-trace --stats -d $O/kt -o bench --output-format csv -- python bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline > $O/kt.log 2>&1
-[ -z "$ONLY_KT" ] && rocprofv3 --pmc FETCH_SIZE -d $O/fetch -o bench --output-format csv -- python bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline --no-large --no-legs > $O/fetch.log 2>&1
-[ -z "$ONLY_KT" ] && rocprofv3 --pmc WRITE_SIZE -d $O/write -o bench --output-format csv -- python bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline --no-large --no-legs > $O/write.log 2>&1
+[ -z "$ONLY_KT" ] && python bench.py --gpus 1 --steps 20 --warmup 5 --detail $O/bench_detail_k20.json > $O/bench_k20.json 2> $O/bench_k20.err
+rocprofv3 --kernel-trace --stats -d $O/kt -o bench --output-format csv -- python bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline --detail $O/bench_detail_kt.json > $O/kt.log 2>&1
+[ -z "$ONLY_KT" ] && rocprofv3 --pmc FETCH_SIZE -d $O/fetch -o bench --output-format csv -- python bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline --no-large --no-legs --detail /tmp/d1.json > $O/fetch.log 2>&1
+[ -z "$ONLY_KT" ] && rocprofv3 --pmc WRITE_SIZE -d $O/write -o bench --output-format csv -- python bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline --no-large --no-legs --detail /tmp/d2.json > $O/write.log 2>&1
 python - <<PY > $O/kernel_stats.md
 # per (kernel, launch geometry): the same template instantiation serves the 1M-point steps and the 8M / 64M-point legs
 import csv, glob, collections
@@ -17,7 +17,8 @@ for f in glob.glob("$O/kt/**/*kernel_trace.csv", recursive=True):
         d = (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3
         name = r["Kernel_Name"][:96]
         if "cached_query_wave<true, false, false, true>" in name:  # same capped grid for every size: split by duration
-            name += " [1,048,576-point launches]" if d < 20 else " [8M-point launches of the mid_batch leg]"
+            name += (" [1,048,576-point launches]" if d < 20 else " [8M-point launches of the mid_batch leg]" if d < 100 else
+                     " [64M-point launches of the large_batch leg]" if d < 420 else " [1e8-point launches of the p1e8_batch leg]")
         rows[(name, grid, wg)].append(d)
 total = sum(sum(v) for v in rows.values())
 print("| kernel | grid (threads) x workgroup | calls | total us | avg us | min us | max us | % |")

@@ -1,4 +1,4 @@
-"""One BASELINE workload CALLS times, for a rocprofv3 pass (tools/valu_session.sh): c1 | c3 | c4 | c5."""
+"""One BASELINE workload CALLS times, for a rocprofv3 pass (tools/valu_session.sh): c1 | c3 | c4 | c5 | bd1 | bd2 | bw (cache builds)."""
 import os, sys
 sys.path.insert(0, os.getcwd())
 import torch
@@ -24,6 +24,13 @@ elif which == "c4":
     pts = Wk.c4_points(P)
     val = torch.empty((A, P), dtype=torch.float32, device="cuda"); grad = torch.empty((A, P, 3), dtype=torch.float32, device="cuda")
     fn = lambda: robot.query_into(pts, val, grad)
+elif which in ("bd1", "bd2", "bw"):  # bench.py CACHE_BUILDS: one CachedSDF construction per call
+    mesh_name, res, pad = {"bd1": ("ycb_power_drill.npz", 0.01, 0.1), "bd2": ("ycb_power_drill.npz", 0.002, 0.01),
+                           "bw": ("offset_wrench_nogrip.obj", 0.001, 0.05)}[which]
+    obj = pv.MeshObjectFactory(Wk.mesh_path(mesh_name))
+    gt = pv.MeshSDF(obj)
+    gt(torch.zeros(64, 3).cuda())
+    fn = lambda: pv.CachedSDF(which, res, obj.bounding_box(padding=pad), gt, device="cuda", cache_path=None)
 else:
     mesh = Wk.build_c5_mesh()
     pts = Wk.c5_points(1 << 21)

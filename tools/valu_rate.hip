@@ -23,10 +23,11 @@ constexpr int ITERS = 2048;
     __global__ __launch_bounds__(256) void NAME(float* out, long long* cyc) {                                        \
         float a[8], b = out[threadIdx.x & 7], c = out[8 + (threadIdx.x & 7)];                                        \
         for (int i = 0; i < 8; ++i) a[i] = out[16 + i] + threadIdx.x;                                                \
+        asm volatile("s_mov_b32 s22, 0x55555555\n s_mov_b32 s23, 0x55555555" ::: "s22", "s23");                      \
         const long long t0 = __builtin_readcyclecounter();                                                           \
         for (int it = 0; it < ITERS; ++it) {                                                                         \
             _Pragma("unroll") for (int r = 0; r < 4; ++r) {                                                          \
-                _Pragma("unroll") for (int i = 0; i < 8; ++i) asm volatile(ASM : "+v"(a[i]) : "v"(b), "v"(c) : "vcc", "s20", "s21");     \
+                _Pragma("unroll") for (int i = 0; i < 8; ++i) asm volatile(ASM : "+v"(a[i]) : "v"(b), "v"(c) : "vcc", "s20", "s21", "s22", "s23");     \
             }                                                                                                        \
         }                                                                                                            \
         const long long t1 = __builtin_readcyclecounter();                                                           \
@@ -77,8 +78,18 @@ KERNEL_F32(k_max_f32, "v_max_f32 %0, %1, %0")
 KERNEL_F32(k_mov_b32, "v_mov_b32 %0, %1")
 KERNEL_F32(k_cmp_lt_f32, "v_cmp_lt_f32 vcc, %1, %0")
 KERNEL_F32(k_cmp_e64, "v_cmp_lt_f32 s[20:21], %1, %0")
-KERNEL_F32(k_cndmask, "v_cndmask_b32 %0, %1, %2, vcc")
-KERNEL_F32(k_cndmask_rw, "v_cndmask_b32 %0, %0, %1, vcc")
+// v_cndmask_b32 with its select mask in an SGPR pair that nothing in the loop rewrites -- the form the composed / mesh kernels
+// issue (inverse_ballot of a lane mask).  Round 4's rows used the implicit VCC and read 9.5 ns at every occupancy: that is a VCC
+// read-after-(clobber) chain of the harness, not an issue rate -- the shipped composed loop issues a v_cndmask every few
+// instructions at 1.35 ns per instruction overall.  Those rows are gone.
+KERNEL_F32(k_cndmask_sgpr, "v_cndmask_b32_e64 %0, %1, %2, s[22:23]")
+KERNEL_F32(k_cndmask_sgpr_rw, "v_cndmask_b32_e64 %0, %0, %1, s[22:23]")
+KERNEL_F32(k_med3_f32, "v_med3_f32 %0, %1, %2, %0")
+KERNEL_F32(k_min3_f32, "v_min3_f32 %0, %1, %2, %0")
+// the composed loop's pattern: a compare that writes an SGPR pair next to arithmetic, and compare -> select -> fma
+KERNEL_F32(k_cmp_fma, "v_cmp_lt_f32 s[20:21], %1, %0\n v_fma_f32 %0, %1, %2, %0")                                                   // 2 / slot
+KERNEL_F32(k_cmp_cnd_fma, "v_cmp_lt_f32 s[20:21], %1, %0\n v_cndmask_b32_e64 %0, %0, %2, s[20:21]\n v_fma_f32 %0, %1, %2, %0")      // 3 / slot
+KERNEL_F32(k_cmp_med3_fma, "v_cmp_le_f32 s[20:21], %1, %0\n v_med3_f32 %0, %1, %2, %0\n v_fma_f32 %0, %1, %2, %0")                  // 3 / slot
 KERNEL_F32(k_rndne_f32, "v_rndne_f32 %0, %0")
 KERNEL_F32(k_cvt_i32_f32, "v_cvt_i32_f32 %0, %0")
 KERNEL_F32(k_sqrt_f32, "v_sqrt_f32 %0, %0")
@@ -120,7 +131,10 @@ int main() {
     std::vector<Entry> es = {
         {"v_fma_f32", k_fma_f32, 1}, {"v_add_f32", k_add_f32, 1}, {"v_mul_f32", k_mul_f32, 1}, {"v_max_f32", k_max_f32, 1},
         {"v_mov_b32", k_mov_b32, 1}, {"v_cmp_lt_f32 (vcc)", k_cmp_lt_f32, 1}, {"v_cmp_lt_f32 (sgpr pair)", k_cmp_e64, 1},
-        {"v_cndmask_b32", k_cndmask, 1}, {"v_cndmask_b32 (dst=src0)", k_cndmask_rw, 1}, {"v_rndne_f32", k_rndne_f32, 1}, {"v_cvt_i32_f32", k_cvt_i32_f32, 1},
+        {"v_cndmask_b32 (sgpr-pair mask)", k_cndmask_sgpr, 1}, {"v_cndmask_b32 (sgpr mask, dst=src0)", k_cndmask_sgpr_rw, 1},
+        {"v_med3_f32", k_med3_f32, 1}, {"v_min3_f32", k_min3_f32, 1}, {"v_cmp(sgpr)+v_fma (2/slot)", k_cmp_fma, 2},
+        {"v_cmp+v_cndmask+v_fma (3/slot)", k_cmp_cnd_fma, 3}, {"v_cmp+v_med3+v_fma (3/slot)", k_cmp_med3_fma, 3},
+        {"v_rndne_f32", k_rndne_f32, 1}, {"v_cvt_i32_f32", k_cvt_i32_f32, 1},
         {"v_sqrt_f32", k_sqrt_f32, 1}, {"v_rcp_f32", k_rcp_f32, 1}, {"v_mul_lo_u32", k_mul_lo_u32, 1},
         {"v_mad_u32_u24", k_mad_u32_u24, 1}, {"v_add_u32", k_add_u32, 1}, {"v_lshl_add_u32", k_lshl_add_u32, 1},
         {"v_max_i32", k_max_i32, 1}, {"v_div_scale_f32", k_div_scale_f32, 1}, {"v_div_fmas_f32", k_div_fmas_f32, 1},
@@ -136,12 +150,12 @@ int main() {
     printf("per opcode and W resident waves per SIMD: ns = wall-clock (HIP events) per wave64 instruction per SIMD; own = s_memtime ticks\n"
            "between two instructions of ONE wave (median); conc = sum of per-wave busy ticks / (span x SIMDs) = waves actually co-resident per SIMD;\n"
            "GHz = s_memtime ticks per wall ns\n");
-    printf("%-30s |", "opcode");
+    printf("%-36s |", "opcode");
     for (int W : {1, 2, 4, 6, 8}) printf("  W=%d: ns    own  conc   GHz |", W);
     printf("\n");
     std::vector<long long> h(2 * maxWaves);
     for (auto& e : es) {
-        printf("%-30s |", e.name);
+        printf("%-36s |", e.name);
         for (int W : {1, 2, 4, 6, 8}) {
             const int blocks = cus * W;  // 256-thread blocks: 4 waves = one per SIMD; W blocks per CU
             float ms = 0;

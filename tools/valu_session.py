@@ -1,4 +1,4 @@
-"""Aggregate ONE profiling session (tools/valu_session.sh) into profiles/r04_valu_session.json: per workload the VALU
+"""Aggregate ONE profiling session (tools/valu_session.sh) into profiles/rNN_valu_session.json: per workload the VALU
 instruction counters, the dynamic opcode-class counters, the kernels' time (kernel trace of the same commands, same box,
 same minutes) and the issue rates tools/valu_rate.bin measured -- everything bench.py's VALU rooflines are built from.
 usage: valu_session.py <session dir> <out.json>"""
@@ -7,10 +7,14 @@ import csv, glob, json, os, re, sys, collections
 # also: valu_session.py --rerate <valu_rate.txt> <existing.json>: recompute the issue rates of a committed session from its table
 sess, out_path = sys.argv[1], sys.argv[2]
 WORK = {  # key -> (run_valu.py name, calls, kernel regex, description)
-    "c1_mesh_query": ("c1", 6, r"mesh_|hand_over|order_|aabb_|morton|invert_face", "C1: MeshSDF(drill), 10,000 grid points, one call = point sort + list / parts / finish launches"),
+    "c1_mesh_query": ("c1", 6, r"mesh_|hand_over|order_|radix_|aabb_|morton|invert_face", "C1: MeshSDF(drill), 10,000 grid points, one call = point sort + list / parts / finish launches"),
     "c3_composed_query": ("c3", 6, r"composed_query", "C3: ComposedSDF of 8 drills, 4,194,304 random points, one launch"),
     "c4_composed_query_wave": ("c4", 4, r"composed_query", "C4: RobotSDF 8 links (100 KB grids), 200 configurations x 262,144 random points, one launch"),
-    "c5_chamfer_mesh": ("c5", 3, r"mesh_|chamfer|hand_over|order_|aabb_|morton|invert_face", "C5: chamfer, 2,097,152 points -> 99,500-triangle sphere, one call = point sort + main launch + heavy-group launches"),
+    "c5_chamfer_mesh": ("c5", 3, r"mesh_|chamfer|hand_over|order_|radix_|aabb_|morton|invert_face", "C5: chamfer, 2,097,152 points -> 99,500-triangle sphere, one call = point sort + main launch + heavy-group launches"),
+    # cache construction: CachedSDF(...) over a MeshSDF = point sort + mesh query over every voxel centre + pack
+    "build_drill_0.01": ("bd1", 6, r"mesh_|hand_over|order_|radix_|aabb_|morton|invert_face|pack_grid", "cache build: drill, res 0.01 pad 0.1, 37x33x40 = 48,840 voxel centres"),
+    "build_drill_0.002": ("bd2", 4, r"mesh_|hand_over|order_|radix_|aabb_|morton|invert_face|pack_grid", "cache build: drill, res 0.002 pad 0.01, 92x73x105 = 705,180 voxel centres"),
+    "build_wrench_0.001": ("bw", 3, r"mesh_|hand_over|order_|radix_|aabb_|morton|invert_face|pack_grid", "cache build: offset_wrench_nogrip, res 0.001 pad 0.05, 218x126x111 = 3,048,948 voxel centres"),
 }
 
 
@@ -27,14 +31,15 @@ def rates(path):
             continue
         table[cells[0]] = min(ns)
     fast = [table[k] for k in ("v_fma_f32", "v_add_f32", "v_mul_f32") if k in table]
-    slow = [table[k] for k in ("v_cmp_lt_f32 (vcc)", "v_max_f32", "v_cvt_i32_f32", "v_rndne_f32", "v_mul_lo_u32") if k in table]
+    slow = [table[k] for k in ("v_cmp_lt_f32 (vcc)", "v_cmp_lt_f32 (sgpr pair)", "v_max_f32", "v_med3_f32", "v_cndmask_b32 (sgpr-pair mask)",
+                               "v_cvt_i32_f32", "v_rndne_f32", "v_mul_lo_u32") if k in table]
     return {"fast": sum(fast) / len(fast), "slow": sum(slow) / len(slow), "trans": table.get("v_sqrt_f32"),
             "best_any": min(table.values()), "best_any_row": min(table, key=table.get),
             "per_opcode_best_ns": table,
             "note": "best over 1..8 resident waves per SIMD of tools/valu_rate.bin, this session; fast = mean of v_fma/add/mul_f32, "
-                    "slow = mean of v_cmp / v_max / v_cvt / v_rndne / v_mul_lo_u32; best_any = the fastest row of the whole table "
-                    "(a stream that alternates one fast-group and one slow-group opcode: the two groups issue side by side, so a "
-                    "mix is NOT bounded by the weighted sum of the two rates)"}
+                    "slow = mean of v_cmp (vcc / sgpr pair) / v_max / v_med3 / v_cndmask (sgpr mask) / v_cvt / v_rndne / v_mul_lo_u32; "
+                    "best_any = the fastest row of the whole table (a stream that alternates fast-group and slow-group opcodes: the two "
+                    "groups issue side by side, so a mix is NOT bounded by the weighted sum of the two rates)"}
 
 
 def counters(pattern_dir, regex):

@@ -7,7 +7,7 @@ O=gpurun_out/$1; S=/tmp/valu_sess; rm -rf $S; mkdir -p $O $S
 P1="SQ_INSTS_VALU SQ_THREAD_CYCLES_VALU SQ_ACTIVE_INST_VALU SQ_INSTS_SALU SQ_BUSY_CYCLES SQ_WAVES SQ_WAVE_CYCLES SQ_ACTIVE_INST_ANY"
 P2="SQ_INSTS_VALU_ADD_F32 SQ_INSTS_VALU_MUL_F32 SQ_INSTS_VALU_FMA_F32 SQ_INSTS_VALU_TRANS_F32 SQ_INSTS_VALU_INT32 SQ_INSTS_VALU_CVT"
 P3="SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_MUL_F64 SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_INT64 SQ_WAIT_ANY SQ_WAIT_INST_ANY"
-for w in "c1 6" "c3 6" "c4 4" "c5 3"; do
+for w in "c1 6" "c3 6" "c4 4" "c5 3" "bd1 6" "bd2 4" "bw 3"; do
   set -- $w
   for i in 1 2 3; do
     eval "CNT=\$P$i"
