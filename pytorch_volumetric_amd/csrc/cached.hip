@@ -106,7 +106,13 @@ __global__ __launch_bounds__(kWavesPerBlock * 64, PVAMD_CQ_MINWAVES) void cached
             float4 r[4];
             bool valid[4];
 #pragma unroll
-            for (int k = 0; k < 4; ++k) r[k] = cached_lookup<F64>(g, px[k], py[k], pz[k], valid[k]);
+            for (int k = 0; k < 4; ++k) {
+#if defined(PVAMD_CQ_ABLATE) && (PVAMD_CQ_ABLATE == 1)  // timing experiment (WRONG results; profiles/r05_cq_geometry.txt): load -> LDS -> store only
+                r[k] = make_float4(px[k], py[k], pz[k], px[k]); valid[k] = true;
+#else
+                r[k] = cached_lookup<F64>(g, px[k], py[k], pz[k], valid[k]);
+#endif
+            }
             sp[3 * lane] = f32x4{r[0].y, r[0].z, r[0].w, r[1].y};
             sp[3 * lane + 1] = f32x4{r[1].z, r[1].w, r[2].y, r[2].z};
             sp[3 * lane + 2] = f32x4{r[2].w, r[3].y, r[3].z, r[3].w};
