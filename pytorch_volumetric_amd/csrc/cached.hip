@@ -110,7 +110,7 @@ __global__ __launch_bounds__(kWavesPerBlock * 64, PVAMD_CQ_MINWAVES) void cached
 #if defined(PVAMD_CQ_ABLATE) && (PVAMD_CQ_ABLATE == 1)  // timing experiment (WRONG results; profiles/r05_cq_geometry.txt): load -> LDS -> store only
                 r[k] = make_float4(px[k], py[k], pz[k], px[k]); valid[k] = true;
 #else
-                r[k] = cached_lookup<F64>(g, px[k], py[k], pz[k], valid[k]);
+                r[k] = cached_lookup<F64, LD_NT>(g, px[k], py[k], pz[k], valid[k]);  // LD_NT = the streaming launch (> 8M points)
 #endif
             }
             sp[3 * lane] = f32x4{r[0].y, r[0].z, r[0].w, r[1].y};
@@ -126,7 +126,7 @@ __global__ __launch_bounds__(kWavesPerBlock * 64, PVAMD_CQ_MINWAVES) void cached
             for (int k = 0; k < 4; ++k) {
                 const int p = lane + 64 * k;
                 bool valid;
-                const float4 r = cached_lookup<F64>(g, px[k], py[k], pz[k], valid);
+                const float4 r = cached_lookup<F64, LD_NT>(g, px[k], py[k], pz[k], valid);
                 svf[p] = r.x;
                 spf[3 * p] = r.y;
                 spf[3 * p + 1] = r.z;

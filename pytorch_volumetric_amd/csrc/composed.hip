@@ -32,21 +32,6 @@ struct Best {
                           // as the vector units in this kernel.)
 };
 
-// Correctly rounded sqrt of a sum of squares (n2 >= 0 or NaN).  v_sqrt_f32 is within 1 ulp; the neighbour whose
-// residual says so replaces it (the same two-sided test the compiler's expansion of sqrtf uses).  That test needs
-// n2 >= 2^-96 to keep its residuals normal -- the compiler pre-scales smaller inputs; here they (rare: a distance below
-// 3.5e-15) take the generic path through one wave-uniform branch.  0, inf and NaN fall through the test unchanged.
-PVAMD_DEV float sqrt_rn_sumsq(float n2) {
-    const bool tiny = (unsigned)(__float_as_int(n2) - 1) < (unsigned)(0x0F800000 - 1);  // 0 < n2 < 2^-96
-    if (__builtin_expect(wave_any(tiny), 0)) return sqrt_rn(n2);
-    float s = __builtin_amdgcn_sqrtf(n2);
-    const float s_dn = __int_as_float(__float_as_int(s) - 1), s_up = __int_as_float(__float_as_int(s) + 1);
-    const float r_dn = fmaf(-s_dn, s, n2), r_up = fmaf(-s_up, s, n2);
-    s = (r_dn <= 0.f) ? s_dn : s;
-    s = (r_up > 0.f) ? s_up : s;
-    return s;
-}
-
 // How a visit obtains its voxel index (all three give the reference's index, bit for bit):
 //   kEstimate    the fp32 estimate; `unsure` is raised where it cannot be trusted and the CALLER redoes those points with
 //                kExact after its leaf loop -- keeps the division sequence and its registers out of the hot loop; right

@@ -138,6 +138,21 @@ PVAMD_DEV int voxel_index_fast(const pvamd_grid_t& g, int d, float p) {
 PVAMD_DEV bool wave_all(bool p) { return __builtin_amdgcn_ballot_w64(p) == __builtin_amdgcn_ballot_w64(true); }
 PVAMD_DEV bool wave_any(bool p) { return __builtin_amdgcn_ballot_w64(p) != 0; }
 
+// Correctly rounded sqrt of a sum of squares (n2 >= 0 or NaN).  v_sqrt_f32 is within 1 ulp; the neighbour whose
+// residual says so replaces it (the same two-sided test the compiler's expansion of sqrtf uses).  That test needs
+// n2 >= 2^-96 to keep its residuals normal -- the compiler pre-scales smaller inputs; here they (rare: a distance below
+// 3.5e-15) take the generic path through one wave-uniform branch.  0, inf and NaN fall through the test unchanged.
+PVAMD_DEV float sqrt_rn_sumsq(float n2) {
+    const bool tiny = (unsigned)(__float_as_int(n2) - 1) < (unsigned)(0x0F800000 - 1);  // 0 < n2 < 2^-96
+    if (__builtin_expect(wave_any(tiny), 0)) return sqrt_rn(n2);
+    float s = __builtin_amdgcn_sqrtf(n2);
+    const float s_dn = __int_as_float(__float_as_int(s) - 1), s_up = __int_as_float(__float_as_int(s) + 1);
+    const float r_dn = fmaf(-s_dn, s, n2), r_up = fmaf(-s_up, s, n2);
+    s = (r_dn <= 0.f) ? s_dn : s;
+    s = (r_up > 0.f) ? s_up : s;
+    return s;
+}
+
 // Whether some coordinate's estimate t sits within its rounding bound of a half-integer (off[d] = t - rint(t)): the estimate
 // and the reference's quotient could then round differently.  pvamd_grid_finalize() stores ONE bound (the largest of the three
 // axes') in every err32[d], so the three tests "0.5 - |off_d| > err" are one: 0.5 - max_d |off_d| > err (the subtraction is
@@ -241,8 +256,22 @@ PVAMD_DEV float4 bounding_box_sdf(const pvamd_grid_t& g, float x, float y, float
 }
 
 // (val, gx, gy, gz) for one point in the leaf frame; `valid` reports the range test.
-template <bool F64>
+// Round 5: the statements the composed kernels had already been brought down to -- range test as three med3 + compare, ONE
+// rare branch for the exact index statements of all three axes (voxel_flat_in_range_fused), the bounding-box vector as one
+// v_med3_f32 per component (equal to sdf.py:559-567's max / add / negate for every input incl. NaN and infinities: negation and
+// adding 0 are exact), its norm by v_sqrt_f32 + the two-sided residual test.  The 1M-point C2 launch is as much
+// instruction-bound as memory-bound (profiles/r05_cq_geometry.txt): ~110 -> ~75 vector instructions per mixed point.
+// STREAMING = the statements of rounds 1-4, kept for launches far beyond the Infinity Cache (> 8M points), which are bound by
+// the L1 -> L2 request path and run SLOWER with the shorter look-up (64M points 332 -> 353 us, every point gathering 406 -> 532:
+// the gathers of a tile crowd the TCP's pending-request slots sooner; profiles/r05_cq_geometry.txt).
+template <bool F64, bool STREAMING = false>
 PVAMD_DEV float4 cached_lookup(const pvamd_grid_t& g, float x, float y, float z, bool& valid) {
+#ifdef PVAMD_CQ_OLD_LOOKUP
+    constexpr bool kOld = true;
+#else
+    constexpr bool kOld = STREAMING;
+#endif
+    if constexpr (kOld) {
     valid = in_range(g, x, y, z);
     if (valid) {
         // (g is a kernarg here: the compiler already knows vox is global, and routing it through load_record's integer cast
@@ -253,6 +282,19 @@ PVAMD_DEV float4 cached_lookup(const pvamd_grid_t& g, float x, float y, float z,
         return bounding_box_sdf(g, x, y, z);
     }
     return make_float4(0.f, 0.f, 0.f, 0.f);  // LOOKUP_GT_SDF: zeros (sdf.py:546-547), caller fills in
+    } else {
+    valid = (__builtin_amdgcn_fmed3f(x, g.vlo[0], g.vhi[0]) == x) & (__builtin_amdgcn_fmed3f(y, g.vlo[1], g.vhi[1]) == y) &
+            (__builtin_amdgcn_fmed3f(z, g.vlo[2], g.vhi[2]) == z);
+    if (valid) return reinterpret_cast<const float4*>(g.vox)[voxel_flat_in_range_fused(g, x, y, z)];
+    if (g.oob_mode == PVAMD_OOB_BOUNDING_BOX) {
+        const float ta = __builtin_amdgcn_fmed3f(sub_rn(x, g.bb_min[0]), sub_rn(x, g.bb_max[0]), 0.f);
+        const float tb = __builtin_amdgcn_fmed3f(sub_rn(y, g.bb_min[1]), sub_rn(y, g.bb_max[1]), 0.f);
+        const float tc = __builtin_amdgcn_fmed3f(sub_rn(z, g.bb_min[2]), sub_rn(z, g.bb_max[2]), 0.f);
+        const float n = sqrt_rn_sumsq(fmaf(tc, tc, fmaf(tb, tb, mul_rn(ta, ta))));  // sdf.py:568
+        return make_float4(n, div_rn(ta, n), div_rn(tb, n), div_rn(tc, n));          // sdf.py:570
+    }
+    return make_float4(0.f, 0.f, 0.f, 0.f);  // LOOKUP_GT_SDF: zeros (sdf.py:546-547), caller fills in
+    }
 }
 
 // ---- float64 query points (sdf.py:545-547: output dtype = query dtype; torch promotion makes the index arithmetic,
