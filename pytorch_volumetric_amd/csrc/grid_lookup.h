@@ -285,21 +285,6 @@ PVAMD_DEV float4 cached_lookup(const pvamd_grid_t& g, float x, float y, float z,
     } else {
     valid = (__builtin_amdgcn_fmed3f(x, g.vlo[0], g.vhi[0]) == x) & (__builtin_amdgcn_fmed3f(y, g.vlo[1], g.vhi[1]) == y) &
             (__builtin_amdgcn_fmed3f(z, g.vlo[2], g.vhi[2]) == z);
-#ifdef PVAMD_CQ_OOB_FIRST
-    float4 r = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (!valid) {
-        if (g.oob_mode == PVAMD_OOB_BOUNDING_BOX) {
-            const float ta = __builtin_amdgcn_fmed3f(sub_rn(x, g.bb_min[0]), sub_rn(x, g.bb_max[0]), 0.f);
-            const float tb = __builtin_amdgcn_fmed3f(sub_rn(y, g.bb_min[1]), sub_rn(y, g.bb_max[1]), 0.f);
-            const float tc = __builtin_amdgcn_fmed3f(sub_rn(z, g.bb_min[2]), sub_rn(z, g.bb_max[2]), 0.f);
-            const float n = sqrt_rn_sumsq(fmaf(tc, tc, fmaf(tb, tb, mul_rn(ta, ta))));
-            r = make_float4(n, div_rn(ta, n), div_rn(tb, n), div_rn(tc, n));
-        }
-    } else {
-        r = reinterpret_cast<const float4*>(g.vox)[voxel_flat_in_range_fused(g, x, y, z)];
-    }
-    return r;
-#endif
     if (valid) return reinterpret_cast<const float4*>(g.vox)[voxel_flat_in_range_fused(g, x, y, z)];
     if (g.oob_mode == PVAMD_OOB_BOUNDING_BOX) {
         const float ta = __builtin_amdgcn_fmed3f(sub_rn(x, g.bb_min[0]), sub_rn(x, g.bb_max[0]), 0.f);
