@@ -153,7 +153,7 @@ class RobotSDF(sdf.ObjectFrameSDF):
         rc = lib.pvamd_configure_chain(joints.data_ptr(), F, q.data_ptr(), A, M, offset_inv.data_ptr(), S,
                                        None if sincos is None else sincos.data_ptr(), hit[1].data_ptr(), None,
                                        stack.data_ptr(), stream)
-        if rc == _lib.E_SHAPE and S > 20 and not one_launch_only:
+        if rc == _lib.E_SHAPE and not one_launch_only:  # (a shape the three-launch path rejects as well is reported there)
             sin_q, cos_q = torch.sin(q), torch.cos(q)
             if sincos is not None:
                 sincos.copy_(torch.stack((sin_q, cos_q), dim=-1))
