@@ -322,7 +322,10 @@ def compact_line(d, detail_name):
     for key in ("all_in_range_batch", "mid_batch", "large_batch", "p1e8_batch"):
         if key in d:
             b = d[key]
-            line[key] = {"ms": b.get("ms_per_launch", b.get("kernel_ms_median")), "frac_of_8TBs": b["frac_of_8TBs"]}
+            line[key] = {"ms": b.get("ms_per_launch", b.get("kernel_ms_median")), "frac_of_8TBs": b["frac_of_8TBs"],
+                         **pick(b, "x_torch_copy")}
+    if "torch_copy" in d:
+        line["torch_copy_GBs"] = d["torch_copy"]["GBs"]
     if "latency" in d and "cached(points)" in d["latency"]:
         line["latency_us"] = {"cached_p50": d["latency"]["cached(points)"]["p50_us"], "cached_p99": d["latency"]["cached(points)"]["p99_us"]}
     if "legs_aborted" in d:
@@ -336,7 +339,7 @@ def compact_text(d, detail_name):
     a run (many failing legs with long messages) should ever push it over."""
     line = sig(compact_line(d, detail_name))
     text = json.dumps(line, separators=(",", ":"))
-    for drop in ("latency_us", "all_in_range_batch", "mid_batch", "p1e8_batch", "large_batch", "legs", "parity"):
+    for drop in ("latency_us", "torch_copy_GBs", "all_in_range_batch", "mid_batch", "p1e8_batch", "large_batch", "legs", "parity"):
         if len(text) < COMPACT_LIMIT:
             break
         line.pop(drop, None)
@@ -628,6 +631,20 @@ def main():
                               "achieved_GBs": BYTES_PER_QUERY * PL / (m * 1e-3) / 1e9,
                               "frac_of_8TBs": BYTES_PER_QUERY * PL / (m * 1e-3) / 1e9 / HBM_PEAK_GBS}
         del big, bval, bgrad
+        # yardstick for the streaming regime ("against both datasheet peak and measured-copy peak"): torch's
+        # device-to-device copy moving the same 1.88 GB (940 MB read + 940 MB written), timed the same way
+        cbytes = BYTES_PER_QUERY * PL // 2
+        csrc = torch.empty(cbytes // 4, dtype=torch.float32, device="cuda")
+        cdst = torch.empty(cbytes // 4, dtype=torch.float32, device="cuda")
+        for _ in range(20):
+            cdst.copy_(csrc)
+        _, cm, _ = time_eager_kernel(torch, np, lambda: cdst.copy_(csrc), 20)
+        copy_gbs = 2 * cbytes / (cm * 1e-3) / 1e9
+        out["torch_copy"] = {"bytes_moved": 2 * cbytes, "ms_median": cm, "GBs": copy_gbs, "frac_of_8TBs": copy_gbs / HBM_PEAK_GBS,
+                                "what": "torch d2d copy of 940 MB, events per launch, median of 20; a yardstick, not a ceiling (tools/membw: 6.5 TB/s)"}
+        out["large_batch"]["x_torch_copy"] = out["large_batch"]["achieved_GBs"] / copy_gbs
+        del csrc, cdst
+        torch.cuda.empty_cache()
         # secondary: the P = 1e8 launch SURVEY.md 8(d) asks for (2.8 GB of algorithmic traffic)
         PH = 100_000_000
         huge = Wk.c2_points(cached, PH, seed=100)
@@ -638,7 +655,8 @@ def main():
         _, m, mn = time_eager_kernel(torch, np, lambda: cached.query_into(huge, hval, hgrad), 30)
         out["p1e8_batch"] = {"points": PH, "kernel_ms_median": m, "kernel_ms_min": mn, "queries_per_s": PH / (m * 1e-3),
                              "achieved_GBs": BYTES_PER_QUERY * PH / (m * 1e-3) / 1e9,
-                             "frac_of_8TBs": BYTES_PER_QUERY * PH / (m * 1e-3) / 1e9 / HBM_PEAK_GBS}
+                             "frac_of_8TBs": BYTES_PER_QUERY * PH / (m * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                             "x_torch_copy": BYTES_PER_QUERY * PH / (m * 1e-3) / 1e9 / copy_gbs}
         del huge, hval, hgrad
         torch.cuda.empty_cache()
 
