@@ -322,3 +322,31 @@ def test_planar_cache_with_a_cell_count_that_three_does_not_divide_and_its_pickl
     v2, g2 = again(pts)
     assert torch.equal(v1, v2) and torch.equal(g1.nan_to_num(7.0), g2.nan_to_num(7.0)) and g1.shape == (4000, 2)
     assert inside.any() and (~inside).any()
+
+
+@pytest.mark.parametrize("f64", [True, False])
+def test_streaming_launch_equals_the_chunked_calls_and_the_oracle(f64):
+    """More than 8M points take the STREAMING instantiation of the wave-tile kernel (non-temporal loads, one tile per wave on an
+    uncapped grid, and -- since round 5 -- the round 1-4 look-up statements, where smaller launches use the composed kernels'
+    shorter ones: csrc/grid_lookup.h cached_lookup<F64, STREAMING>).  Both must return the same bits for the same points: the
+    big call against the same points in chunks below the threshold, and against the oracle on three runs of 20,000 points."""
+    c = make_cached(f64=f64)
+    P = (8 << 20) + 12_345  # a ragged end on top
+    lo = np.array([r[0] for r in c.ranges]) - 0.05
+    hi = np.array([r[1] for r in c.ranges]) + 0.05
+    import workloads
+    pts = workloads.uniform_points_device(P, lo, hi, seed=11)
+    pts[123] = float("nan")
+    pts[P - 7, 1] = float("inf")
+    val, grad = c(pts)  # one streaming launch
+    assert val.shape == (P,) and grad.shape == (P, 3)
+    step = 3_000_000
+    for a in range(0, P, step):  # the same points through the non-streaming instantiation
+        v, g = c(pts[a:a + step].contiguous())
+        assert torch.equal(v.nan_to_num(7.0), val[a:a + step].nan_to_num(7.0))
+        assert torch.equal(g.nan_to_num(7.0), grad[a:a + step].nan_to_num(7.0))
+    og = H.oracle_grid_from_cached(c)
+    for a in (0, P // 2, P - 20_000):
+        ov, ogr, _ = oracle.cached_query(og, pts[a:a + 20_000].cpu().numpy())
+        assert np.array_equal(val[a:a + 20_000].cpu().numpy(), ov, equal_nan=True)
+        assert np.array_equal(grad[a:a + 20_000].cpu().numpy(), ogr, equal_nan=True)
