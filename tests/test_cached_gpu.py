@@ -350,3 +350,13 @@ def test_streaming_launch_equals_the_chunked_calls_and_the_oracle(f64):
         ov, ogr, _ = oracle.cached_query(og, pts[a:a + 20_000].cpu().numpy())
         assert np.array_equal(val[a:a + 20_000].cpu().numpy(), ov, equal_nan=True)
         assert np.array_equal(grad[a:a + 20_000].cpu().numpy(), ogr, equal_nan=True)
+    # ... and the instantiation that also writes the out-of-range mask (what LOOKUP_GT_SDF asks for), through the C entry
+    import ctypes
+    lib = pv._lib.load()
+    v2, g2 = torch.empty_like(val), torch.empty_like(grad)
+    oob = torch.empty((P,), dtype=torch.uint8, device="cuda")
+    desc = c._grid_desc()
+    pv._lib.check(lib.pvamd_cached_query(ctypes.byref(desc), pv._lib.ptr(pts), P, pv._lib.ptr(v2), pv._lib.ptr(g2), pv._lib.ptr(oob),
+                                         pv._lib.stream_ptr()), "pvamd_cached_query")
+    assert torch.equal(v2.nan_to_num(7.0), val.nan_to_num(7.0)) and torch.equal(g2.nan_to_num(7.0), grad.nan_to_num(7.0))
+    assert torch.equal(oob.bool(), ~c.voxels.get_valid_values(pts))
