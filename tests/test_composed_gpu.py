@@ -362,3 +362,26 @@ def test_bucketed_and_packed_paths_take_more_than_65535_configurations():
                                            tfm.reshape(S, A, 4, 4)[:, pick].reshape(-1, 4, 4).numpy(), len(pick), pts.cpu().numpy())
     assert np.array_equal(val[pick].cpu().numpy(), oval, equal_nan=True)
     assert np.array_equal(grad[pick].cpu().numpy(), ograd, equal_nan=True)
+
+
+def test_a_single_configuration_over_more_points_than_the_grid_has_lanes():
+    """One configuration (the per-lane kernel) over 20 M points: its grid is capped at 65,535 workgroups of 256 lanes, so every
+    lane takes a second round of the grid-stride loop -- the launch must equal the same points in chunks small enough for one
+    round each, and the oracle on three runs."""
+    import workloads
+    leaves = [make_leaf(f64=(s % 2 == 0)) for s in range(3)]
+    tfm = H.random_rigid(3, seed=77)
+    comp = pv.ComposedSDF(leaves, pv.Transform3d(matrix=tfm))
+    P = 20_000_003
+    pts = workloads.uniform_points_device(P, [-0.5] * 3, [0.5] * 3, seed=5)
+    val, grad = comp(pts)
+    assert val.shape == (P,) and grad.shape == (P, 3)
+    step = 4_000_000
+    for a in range(0, P, step):
+        v, g = comp(pts[a:a + step].contiguous())
+        assert torch.equal(v, val[a:a + step]) and torch.equal(g.nan_to_num(7.0), grad[a:a + step].nan_to_num(7.0))
+    ogrids = [H.oracle_grid_from_cached(l) for l in leaves]
+    for a in (0, P // 2, P - 10_000):
+        ov, og, _ = oracle.composed_query(ogrids, tfm.numpy(), 1, pts[a:a + 10_000].cpu().numpy())
+        assert np.array_equal(val[a:a + 10_000].cpu().numpy(), ov[0], equal_nan=True)
+        assert np.array_equal(grad[a:a + 10_000].cpu().numpy(), og[0], equal_nan=True)
