@@ -11,7 +11,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("PVAMD_LIB") or os.path.join(_HERE, "csrc", "libpvamd.so")  # PVAMD_LIB: A/B builds (tools/)
 
-ABI_VERSION = 10
+ABI_VERSION = 11
 OOB_LOOKUP_GT_SDF = 0
 OOB_BOUNDING_BOX = 1
 COMPOSED_INLINE_EXACT = 1
@@ -134,6 +134,12 @@ SIGNATURES = {
                                                      ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_int64,
                                                      ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int32,
                                                      ctypes.c_void_p]),
+    "pvamd_group_chunk_points": (ctypes.c_int64, []),
+    "pvamd_group_scratch_bytes": (ctypes.c_int64, [ctypes.c_int64]),
+    "pvamd_group_points": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p]),
+    "pvamd_composed_query_grouped": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int32, ctypes.c_void_p, ctypes.c_int32,
+                                                    ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p,
+                                                    ctypes.c_void_p, ctypes.c_int32, ctypes.c_void_p]),
     "pvamd_transform_points": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int32, ctypes.c_void_p, ctypes.c_int64,
                                               ctypes.c_void_p, ctypes.c_void_p]),
     "pvamd_compose_merge": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int32, ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p,
@@ -310,6 +316,26 @@ def as_query_points(points, device=None, keep_f64=False):
 
 ORDER_RADIX_SORT_FROM = int(os.environ.get("PVAMD_RADIX_FROM", 3 << 18))  # PVAMD_ORDER_RADIX_SORT_FROM (the env: A/B builds only)
 
+
+
+_group_chunk = None
+
+
+def group_chunk_points():
+    """Points per chunk of the chunk-grouped composed query (a build constant of the library)."""
+    global _group_chunk
+    if _group_chunk is None:
+        _group_chunk = int(load().pvamd_group_chunk_points())
+    return _group_chunk
+
+
+def group_points(flat):
+    """pvamd_group_points over contiguous fp32 (P, 3) GPU points: the scratch (uint8 tensor) pvamd_composed_query_grouped reads."""
+    lib = load()
+    P = flat.shape[0]
+    scratch = torch.empty((int(lib.pvamd_group_scratch_bytes(P)),), dtype=torch.uint8, device=flat.device)
+    check(lib.pvamd_group_points(ptr(flat), P, ptr(scratch), stream_ptr()), "pvamd_group_points")
+    return scratch
 
 def morton_order_scratch_words(P):
     """PVAMD_MORTON_ORDER_SCRATCH_BYTES(P) / 4"""

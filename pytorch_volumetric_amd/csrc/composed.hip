@@ -20,6 +20,7 @@
 #include "common.h"
 #include "grid_lookup.h"
 #include "wave_ops.h"
+#include "morton.h"
 
 namespace pvamd {
 
@@ -174,6 +175,27 @@ PVAMD_DEV void build_cull_spheres(const pvamd_grid_t* __restrict__ grids, int S,
     }
 }
 
+// The leaves a set of points inside the sphere (ct, rt) may need (all coordinates at most `mag` in magnitude); lane = leaf.
+PVAMD_DEV uint64_t leaf_mask_of_sphere(const float (*cull)[8], int S, int lane, const float ct[3], float rt, float mag,
+                                       float& lower) {
+    bool near = false;
+    float upper = __builtin_inff();
+    lower = -__builtin_inff();
+    if (lane < S) {
+        const float* c = cull[lane];  // S <= 64 rows of 8 floats: lanes read distinct rows
+        const float dx = ct[0] - c[0], dy = ct[1] - c[1], dz = ct[2] - c[2];
+        const float d = fast_sqrt(dx * dx + dy * dy + dz * dz);
+        const float slack = 1e-5f * (d + mag) + 1e-30f;
+        near = !(d * 0.9999f - slack > rt + c[3]);           // some point may be inside the leaf's range
+        // when far: every point's value for this leaf is >= lower and <= upper
+        lower = near ? -__builtin_inff() : d * 0.9999f - slack - rt - c[4];
+        upper = near ? __builtin_inff() : d * 1.0001f + slack + rt + c[5];
+    }
+    const float ub = wave_min(upper);
+    const bool visit = !(lower > ub);
+    return __builtin_amdgcn_ballot_w64(visit && lane < S) | (S > 64 ? ~0ull : 0ull);
+}
+
 // Leaves (bit s of the result) that some point of the wave's 256-point tile may need.  lane = leaf.  `lower` (lane s)
 // = a lower bound of leaf s's value over the whole tile when the tile is entirely outside the leaf's range, -inf
 // otherwise: what the leaf loop re-tests against its running minimum (see composed_query_wave).
@@ -209,21 +231,7 @@ PVAMD_DEV uint64_t tile_leaf_mask(const float (*cull)[8], int S, int lane, const
         mag = fmaxf(mag, fmaxf(fabsf(l), fabsf(h)));
     }
     const float rt = fast_sqrt(rt2) * 1.0001f + 1e-5f * mag;  // 1-ulp sqrt: the bounds carry 1e-4 of slack
-    bool near = false;
-    float upper = __builtin_inff();
-    if (lane < S) {
-        const float* c = cull[lane];  // S <= 64 rows of 8 floats: lanes read distinct rows
-        const float dx = ct[0] - c[0], dy = ct[1] - c[1], dz = ct[2] - c[2];
-        const float d = fast_sqrt(dx * dx + dy * dy + dz * dz);
-        const float slack = 1e-5f * (d + mag) + 1e-30f;
-        near = !(d * 0.9999f - slack > rt + c[3]);           // some point may be inside the leaf's range
-        // when far: every point's value for this leaf is >= lower and <= upper
-        lower = near ? -__builtin_inff() : d * 0.9999f - slack - rt - c[4];
-        upper = near ? __builtin_inff() : d * 1.0001f + slack + rt + c[5];
-    }
-    const float ub = wave_min(upper);
-    const bool visit = !(lower > ub);
-    return __builtin_amdgcn_ballot_w64(visit && lane < S) | (S > 64 ? ~0ull : 0ull);
+    return leaf_mask_of_sphere(cull, S, lane, ct, rt, mag, lower);
 }
 
 // One wave = 256 consecutive points of one configuration per pass; all global traffic in contiguous 1 KB pieces
@@ -385,10 +393,21 @@ struct BestIn {
     int leaf, flat;
 };
 
-template <int PPP, bool PACKED, bool MASKED>
+// GROUPED (round 6, composed_query_grouped below): the wave's 256 points are a spatially compact run of its workgroup's
+// chunk, read from the chunk-sorted copy in memory (`pts`: lane stride 12 B, contiguous over the wave); a result goes to
+// the LDS slot of the CALLER-order position `perm` names (tile = idx >> 8, point = idx & 255 of the block's `res` slices,
+// the layout the coalesced stores read), so the un-permutation costs four LDS writes per point and no memory pass.
+struct GroupIO {
+    const float* __restrict__ pts;      // the wave's 256 sorted points
+    const uint16_t* __restrict__ perm;  // their positions inside the chunk, caller order
+    float* res;                         // the block's result slices, [tile][1024]
+    int64_t chunk_first;                // caller index of the chunk's first point
+};
+
+template <int PPP, bool PACKED, bool MASKED, bool GROUPED = false>
 PVAMD_DEV void tile_passes_split(const pvamd_grid_t* __restrict__ grids, int S, const float* __restrict__ tf, int A, int a,
                                  int64_t first, int64_t P, float* __restrict__ val, int* __restrict__ leaf, float* spf,
-                                 int lane, uint64_t todo, float lower) {
+                                 int lane, uint64_t todo, float lower, const GroupIO gio = GroupIO{}) {
     float* svf = spf + 768;
     const int first_leaf = todo ? __builtin_ctzll(todo) : 0;
     const bool refine = MASKED && S <= 64 && todo != ((S >= 64) ? ~0ull : ((1ull << S) - 1ull));
@@ -402,9 +421,15 @@ PVAMD_DEV void tile_passes_split(const pvamd_grid_t* __restrict__ grids, int S, 
 #pragma unroll
         for (int k = 0; k < PPP; ++k) {
             const int p = lane + 64 * (h + k);
-            px[k] = spf[3 * p];
-            py[k] = spf[3 * p + 1];
-            pz[k] = spf[3 * p + 2];
+            if constexpr (GROUPED) {
+                px[k] = gio.pts[3 * p];
+                py[k] = gio.pts[3 * p + 1];
+                pz[k] = gio.pts[3 * p + 2];
+            } else {
+                px[k] = spf[3 * p];
+                py[k] = spf[3 * p + 1];
+                pz[k] = spf[3 * p + 2];
+            }
             best[k] = BestOut{__builtin_inff(), __builtin_nanf(""), __builtin_nanf(""), __builtin_nanf(""), kNoLeaf};
             bin[k] = BestIn{__builtin_inff(), kNoLeaf, 0};
             unsure[k] = 0;
@@ -526,6 +551,17 @@ PVAMD_DEV void tile_passes_split(const pvamd_grid_t* __restrict__ grids, int S, 
             const float* M = tf + 16 * ((int64_t)s_win * A + a);
             float gx, gy, gz;
             rotate_back(M, fin[k], gx, gy, gz);
+            if constexpr (GROUPED) {
+                const int idx = gio.perm[p];
+                float* slot = gio.res + (idx >> 8) * 1024;
+                const int q = idx & 255;
+                slot[768 + q] = fin[k].v;
+                slot[3 * q] = gx;
+                slot[3 * q + 1] = gy;
+                slot[3 * q + 2] = gz;
+                if (leaf) leaf[(int64_t)a * P + gio.chunk_first + idx] = s_win;
+                continue;
+            }
             if constexpr (PACKED) {
                 reinterpret_cast<f32x4*>(val)[(int64_t)a * P + first + p] = f32x4{fin[k].v, gx, gy, gz};
             } else {
@@ -894,6 +930,222 @@ __global__ __launch_bounds__(kUnpermuteWaves * 64) void composed_unpermute_kerne
     }
 }
 
+
+// ---- round 6: chunk-grouped points ----
+// On random query points nearly every wave pays BOTH halves of nearly every leaf visit: a leaf's range covers 1.5 % (C4) / 5 %
+// (C3) of the query box, so some of a wave's 64 scattered lanes are inside it 62-96 % of the time, and the look-up half then
+// runs for a handful of lanes.  A global spatial sort fixes that (0.53 ms against 0.68 on C4) but its un-permute pass over the
+// 839 MB of outputs costs more than it saves.  Regrouping the points INSIDE chunks of consecutive caller points keeps nearly
+// all of the gain (tools/chunk_sort_probe.py: chunks of 4096 run the kernel 30 % faster, as fast as the global sort) and a
+// workgroup can undo it through LDS: a chunk's outputs are one contiguous piece of every output row.
+//
+// group_points_kernel (once per call, shared by the A configurations): one workgroup per chunk of kGroupWaves x 256
+// consecutive points sorts them along a Hilbert curve over the chunk's own box (16^3 cells, counting sort in LDS) and writes
+// the sorted copy, `perm[j]` = position inside the chunk of sorted point j, and per run of 256 sorted points (one wave's
+// tile) the bounding sphere the leaf mask wants.  composed_query_grouped: a wave takes one such run, every result lands in
+// the LDS slot of its caller-order position, and after a barrier each wave stores one caller-order tile as 1 + 3 contiguous KB.
+// The order inside a Hilbert cell is whatever the LDS atomics gave: no result depends on it (a point's statements do not
+// know its lane).
+#ifndef PVAMD_GROUP_WAVES
+#define PVAMD_GROUP_WAVES 16
+#endif
+constexpr int kGroupWaves = PVAMD_GROUP_WAVES;
+constexpr int kGroupChunk = kGroupWaves * kTilePoints;
+static_assert(kGroupChunk <= 65536 && 4096 % (kGroupWaves * 64) == 0, "perm is uint16; the scan splits 4096 bins evenly");
+
+template <int NW>
+__global__ __launch_bounds__(NW * 64) void group_points_kernel(const float* __restrict__ pts, int64_t P,
+                                                               float* __restrict__ sorted, float* __restrict__ bounds,
+                                                               uint16_t* __restrict__ perm) {
+    constexpr int N = NW * kTilePoints, kBins = 4096, kPerThread = kBins / (NW * 64);
+    __shared__ __attribute__((aligned(16))) float lds[NW][768];
+    __shared__ unsigned hist[kBins];
+    __shared__ uint16_t sperm[N];
+    __shared__ unsigned box[6];
+    __shared__ unsigned wsum[NW];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t chunk = blockIdx.x;
+    const int64_t cfirst = chunk * N <= P - N ? chunk * N : P - N;  // the last chunk is moved back to end at the last point
+    f32x4_alias* sp = reinterpret_cast<f32x4_alias*>(lds[wave]);
+    {
+        const f32x4_u* src = reinterpret_cast<const f32x4_u*>(pts + 3 * (cfirst + wave * kTilePoints));
+        sp[lane] = src[lane];
+        sp[lane + 64] = src[lane + 64];
+        sp[lane + 128] = src[lane + 128];
+    }
+    for (int i = threadIdx.x; i < kBins; i += NW * 64) hist[i] = 0u;
+    if (threadIdx.x < 3) {
+        box[threadIdx.x] = 0xffffffffu;
+        box[3 + threadIdx.x] = 0u;
+    }
+    PVAMD_WAVE_SYNC();
+    const f32x4 q0 = sp[3 * lane], q1 = sp[3 * lane + 1], q2 = sp[3 * lane + 2];
+    const float px[4] = {q0.x, q0.w, q1.z, q2.y}, py[4] = {q0.y, q1.x, q1.w, q2.z}, pz[4] = {q0.z, q1.y, q2.x, q2.w};
+    // the chunk's box over its finite coordinates
+    float lo[3], hi[3];
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+        lo[d] = __builtin_inff();
+        hi[d] = -__builtin_inff();
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const float c[3] = {px[k], py[k], pz[k]};
+#pragma unroll
+        for (int d = 0; d < 3; ++d) {
+            const bool fin = fabsf(c[d]) < __builtin_inff();
+            lo[d] = fin ? fminf(lo[d], c[d]) : lo[d];
+            hi[d] = fin ? fmaxf(hi[d], c[d]) : hi[d];
+        }
+    }
+    __syncthreads();  // box[] initialised, every tile in LDS
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+        const float l = wave_min(lo[d]), h = wave_max(hi[d]);
+        if (lane == 0) {
+            atomicMin(&box[d], order_code(l));
+            atomicMax(&box[3 + d], order_code(h));
+        }
+    }
+    __syncthreads();
+    float blo[3], scale[3];
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+        blo[d] = order_decode(box[d]);
+        scale[d] = 15.999f / fmaxf(order_decode(box[3 + d]) - blo[d], 1e-30f);
+    }
+    unsigned key[4], rank[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        key[k] = hilbert_cell16(px[k], py[k], pz[k], blo, scale);  // NaN / infinite coordinates land in some cell: harmless
+        rank[k] = atomicAdd(&hist[key[k]], 1u);
+    }
+    __syncthreads();
+    // exclusive scan of the 4096 counts: kPerThread consecutive bins per thread, a wave scan, the wave totals
+    unsigned local[kPerThread], sum = 0u;
+#pragma unroll
+    for (int i = 0; i < kPerThread; ++i) {
+        local[i] = hist[threadIdx.x * kPerThread + i];
+        sum += local[i];
+    }
+    unsigned inc = sum;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const unsigned t = __shfl_up(inc, off);
+        inc += lane >= off ? t : 0u;
+    }
+    if (lane == 63) wsum[wave] = inc;
+    __syncthreads();
+    unsigned base = inc - sum;
+    for (int w = 0; w < wave; ++w) base += wsum[w];
+#pragma unroll
+    for (int i = 0; i < kPerThread; ++i) {
+        hist[threadIdx.x * kPerThread + i] = base;
+        base += local[i];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 4; ++k) sperm[hist[key[k]] + rank[k]] = (uint16_t)(wave * kTilePoints + 4 * lane + k);
+    __syncthreads();
+    // wave w writes sorted run w and its bounding sphere (the statements of tile_leaf_mask)
+    float tlo[3], thi[3];
+    bool odd = false;
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+        tlo[d] = __builtin_inff();
+        thi[d] = -__builtin_inff();
+    }
+    const int64_t out0 = chunk * N + wave * kTilePoints;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int j = lane + 64 * k;
+        const int idx = sperm[wave * kTilePoints + j];
+        const float* q = &lds[idx >> 8][3 * (idx & 255)];
+        perm[out0 + j] = (uint16_t)idx;
+#pragma unroll
+        for (int d = 0; d < 3; ++d) {
+            const float x = q[d];
+            sorted[3 * (out0 + j) + d] = x;
+            tlo[d] = fminf(tlo[d], x);
+            thi[d] = fmaxf(thi[d], x);
+            odd |= !(fabsf(x) < __builtin_inff());
+        }
+    }
+    float ct[3], rt2 = 0.f, mag = 0.f;
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+        const float l = wave_min(tlo[d]), h = wave_max(thi[d]);
+        ct[d] = 0.5f * (l + h);
+        const float half = 0.5f * (h - l);
+        rt2 += half * half;
+        mag = fmaxf(mag, fmaxf(fabsf(l), fabsf(h)));
+    }
+    float rt = fast_sqrt(rt2) * 1.0001f + 1e-5f * mag;
+    if (wave_any(odd)) rt = __builtin_inff();  // a NaN / infinite coordinate: no bounds, every leaf is visited
+    if (lane < 8) {
+        const float rec[8] = {ct[0], ct[1], ct[2], rt, mag, 0.f, 0.f, 0.f};
+        float v = rec[0];
+#pragma unroll
+        for (int i = 1; i < 8; ++i) v = lane == i ? rec[i] : v;
+        bounds[8 * (chunk * NW + wave) + lane] = v;
+    }
+}
+
+// how large a run's sphere may be against the scene (the radius about leaf 0's centre that holds every leaf's range) for a leaf
+// mask to be worth its ~60 instructions
+#ifndef PVAMD_GROUP_MASK_SPAN
+#define PVAMD_GROUP_MASK_SPAN 0.5f
+#endif
+#ifndef PVAMD_GROUP_MINWAVES
+#define PVAMD_GROUP_MINWAVES 8
+#endif
+template <int NW, int PPP>
+__global__ __launch_bounds__(NW * 64, PVAMD_GROUP_MINWAVES) void composed_query_grouped(
+    const pvamd_grid_t* __restrict__ grids, int S, const float* __restrict__ tf, int A, const float* __restrict__ sorted,
+    const float* __restrict__ bounds, const uint16_t* __restrict__ perm, int64_t nchunks, int64_t P, float* __restrict__ val,
+    float* __restrict__ grad, int* __restrict__ leaf, int a0) {
+    constexpr int N = NW * kTilePoints;
+    __shared__ __attribute__((aligned(16))) float res[NW][1024];
+    __shared__ float cull[kMaxCullLeaves][8];
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int a = a0 + blockIdx.x;  // configuration fastest, as composed_query_wave
+    build_cull_spheres(grids, S, tf, A, a, cull);
+    __syncthreads();
+    float scene = __builtin_inff();
+    if (S <= kMaxCullLeaves) {
+        float reach = -__builtin_inff();
+        if (lane < S) {
+            const float dx = cull[lane][0] - cull[0][0], dy = cull[lane][1] - cull[0][1], dz = cull[lane][2] - cull[0][2];
+            reach = fast_sqrt(dx * dx + dy * dy + dz * dz) + cull[lane][3];
+        }
+        scene = wave_max(reach);
+    }
+    const float span = PVAMD_GROUP_MASK_SPAN * scene;
+    for (int64_t chunk = blockIdx.y; chunk < nchunks; chunk += gridDim.y) {
+        const int64_t cfirst = chunk * N <= P - N ? chunk * N : P - N;
+        const int64_t run = chunk * N + wave * kTilePoints;
+        const float* tb = bounds + 8 * (chunk * NW + wave);  // wave-uniform: scalar loads
+        const float ct[3] = {tb[0], tb[1], tb[2]};
+        const float rt = tb[3], mag = tb[4];
+        float lower = -__builtin_inff();
+        uint64_t todo = S >= 64 ? ~0ull : ((1ull << S) - 1ull);
+        const bool masked = 2.f * rt <= span;  // false for the "no bounds" marker (+inf)
+        if (masked) todo = leaf_mask_of_sphere(cull, S, lane, ct, rt, mag, lower);
+        const GroupIO gio{sorted + 3 * run, perm + run, &res[0][0], cfirst};
+        if (masked) tile_passes_split<PPP, false, true, true>(grids, S, tf, A, a, 0, P, val, leaf, nullptr, lane, todo, lower, gio);
+        else tile_passes_split<PPP, false, false, true>(grids, S, tf, A, a, 0, P, val, leaf, nullptr, lane, todo, lower, gio);
+        __syncthreads();  // every result of the chunk is in its caller-order slot
+        const f32x4_alias* sp = reinterpret_cast<const f32x4_alias*>(res[wave]);
+        const int64_t o = (int64_t)a * P + cfirst + wave * kTilePoints;
+        __builtin_nontemporal_store(sp[192 + lane], reinterpret_cast<f32x4_u*>(val + o) + lane);
+        f32x4_u* dst = reinterpret_cast<f32x4_u*>(grad + 3 * o);
+        __builtin_nontemporal_store(sp[lane], dst + lane);
+        __builtin_nontemporal_store(sp[lane + 64], dst + lane + 64);
+        __builtin_nontemporal_store(sp[lane + 128], dst + lane + 128);
+        __syncthreads();  // the slices are free for the next chunk
+    }
+}
+
 }  // namespace pvamd
 
 using namespace pvamd;
@@ -1019,6 +1271,49 @@ extern "C" int pvamd_composed_query(const pvamd_grid_t* grids, int32_t S, const 
                                    (int64_t)0, P, out_val, out_grad, out_leaf, a0, cf);
         }
     }
+    return (int)hipGetLastError();
+}
+
+// ---- chunk-grouped query (round 6): scratch layout = sorted points | run bounds | perm ----
+static inline int64_t group_chunks(int64_t P) { return (P + kGroupChunk - 1) / kGroupChunk; }
+static inline int64_t group_bounds_offset(int64_t P) { return group_chunks(P) * kGroupChunk * 12; }
+static inline int64_t group_perm_offset(int64_t P) { return group_bounds_offset(P) + group_chunks(P) * kGroupWaves * 32; }
+
+extern "C" int64_t pvamd_group_chunk_points(void) { return kGroupChunk; }
+
+extern "C" int64_t pvamd_group_scratch_bytes(int64_t P) {
+    if (P < kGroupChunk) return 0;
+    return group_perm_offset(P) + group_chunks(P) * kGroupChunk * 2;
+}
+
+extern "C" int pvamd_group_points(const float* points, int64_t P, void* scratch, void* stream) {
+    if (P < kGroupChunk) return PVAMD_E_SHAPE;
+    if (!points || !scratch) return PVAMD_E_NULL;
+    if (!aligned_to(points, 4) || !aligned_to(scratch, 16)) return PVAMD_E_ALIGN;
+    char* base = static_cast<char*>(scratch);
+    hipLaunchKernelGGL((group_points_kernel<kGroupWaves>), dim3((unsigned)group_chunks(P)), dim3(kGroupWaves * 64), 0, (hipStream_t)stream,
+                       points, P, reinterpret_cast<float*>(base), reinterpret_cast<float*>(base + group_bounds_offset(P)),
+                       reinterpret_cast<uint16_t*>(base + group_perm_offset(P)));
+    return (int)hipGetLastError();
+}
+
+extern "C" int pvamd_composed_query_grouped(const pvamd_grid_t* grids, int32_t S, const float* tf, int32_t A, const void* scratch,
+                                            int64_t P, float* out_val, float* out_grad, int32_t* out_leaf, int32_t flags,
+                                            void* stream) {
+    if (S < 1 || A < 1 || P < kGroupChunk || S >= kNoLeaf) return PVAMD_E_SHAPE;
+    if (flags & (PVAMD_COMPOSED_INLINE_EXACT | PVAMD_COMPOSED_LEGACY_LEAF_LOOP)) return PVAMD_E_MODE;
+    if (!grids || !tf || !out_val || !out_grad || !scratch) return PVAMD_E_NULL;
+    if (!aligned_to(grids, 8) || !aligned_to(tf, 4) || !aligned_to(scratch, 16) || !aligned_to(out_val, 4) || !aligned_to(out_grad, 4))
+        return PVAMD_E_ALIGN;
+    const char* base = static_cast<const char*>(scratch);
+    const int64_t nchunks = group_chunks(P);
+    // configuration = blockIdx.x (any count), chunks = blockIdx.y (grid-strided beyond 65535)
+    int64_t cap = ((int64_t)65536 + A - 1) / A;
+    if (cap > 65535) cap = 65535;
+    const unsigned gy = (unsigned)(nchunks < cap ? nchunks : (cap < 1 ? 1 : cap));
+    hipLaunchKernelGGL((composed_query_grouped<kGroupWaves, PVAMD_COMPOSED_PPP>), dim3(A, gy), dim3(kGroupWaves * 64), 0, (hipStream_t)stream,
+                       grids, S, tf, A, reinterpret_cast<const float*>(base), reinterpret_cast<const float*>(base + group_bounds_offset(P)),
+                       reinterpret_cast<const uint16_t*>(base + group_perm_offset(P)), nchunks, P, out_val, out_grad, out_leaf, 0);
     return (int)hipGetLastError();
 }
 

@@ -1,0 +1,182 @@
+"""-m gpu: the chunk-grouped composed query (round 6: pvamd_group_points + pvamd_composed_query_grouped) -- points regrouped
+spatially inside chunks of consecutive caller points, results restored to the caller's order through LDS -- against the CPU
+oracle and against the ungrouped kernels, bit for bit (sdf.py:392-433 of the reference)."""
+import ctypes
+
+import numpy as np
+import pytest
+import torch
+
+import pytorch_volumetric_amd as pv
+from oracle import oracle
+from pytorch_volumetric_amd import _lib
+from tests import helpers as H
+
+pytestmark = pytest.mark.gpu
+
+
+def make_leaf(f64=True, res=0.01, padding=0.1):
+    gt = H.drill_like_gt()
+    return pv.CachedSDF("drill_like", res, H.padded_range(H.DRILL_BB, padding, as_numpy=f64), gt, device="cuda",
+                        cache_path=None)
+
+
+def scene_points(n, seed, extent=0.5):
+    return H.uniform_points(n, [-extent] * 3, [extent] * 3, seed)
+
+
+def composed(S, A, seed, trans=0.3):
+    leaves = [make_leaf(f64=(s % 2 == 0)) for s in range(S)]
+    tfm = H.random_rigid(S * A, seed=seed, trans=trans)
+    comp = pv.ComposedSDF(leaves, None)
+    comp.set_transforms(pv.Transform3d(matrix=tfm), batch_dim=(A,))
+    return comp, leaves, tfm
+
+
+def same_bits(a, b):
+    return np.array_equal(a.view(np.int32), b.view(np.int32))
+
+
+@pytest.mark.parametrize("S,A,P", [(8, 3, 4096), (8, 2, 4097), (8, 5, 12_345), (3, 7, 8191), (1, 2, 4096), (20, 2, 5000)])
+def test_grouped_matches_the_oracle_and_the_ungrouped_kernels_bitwise(S, A, P):
+    """Any P >= one chunk (a ragged end: the last chunk is moved back and overlaps its neighbour), mixed float64 / float32 index
+    arithmetic per leaf, odd row starts of the (A, P) outputs."""
+    chunk = _lib.group_chunk_points()
+    assert P >= chunk
+    comp, leaves, tfm = composed(S, A, seed=S * 100 + A)
+    pts = scene_points(P, seed=P, extent=0.6).cuda()
+    comp.group_points = True
+    val, grad = comp(pts)
+    comp.group_points = False
+    val0, grad0 = comp(pts)
+    assert val.shape == (A, P) and grad.shape == (A, P, 3)
+    assert same_bits(val.cpu().numpy(), val0.cpu().numpy()) and same_bits(grad.cpu().numpy(), grad0.cpu().numpy())
+    oval, ograd, _ = oracle.composed_query([H.oracle_grid_from_cached(l) for l in leaves], tfm.numpy(), A, pts.cpu().numpy())
+    assert np.array_equal(val.cpu().numpy(), oval, equal_nan=True)
+    assert np.array_equal(grad.cpu().numpy(), ograd, equal_nan=True)
+
+
+def test_grouped_leaf_ids_and_a_single_configuration_through_the_c_abi():
+    """out_leaf (the arg-min leaf of every point, written to the caller's order from inside the leaf loop) and A = 1, straight
+    through the two entry points."""
+    S, A, P = 8, 1, 9000
+    comp, leaves, tfm = composed(S, A, seed=5)
+    pts = scene_points(P, seed=3, extent=0.6).cuda()
+    lib = _lib.load()
+    dev = pts.device
+    grids = comp._leaf_grids(dev)
+    scratch = _lib.group_points(pts)
+    val = torch.empty((A, P), device=dev)
+    grad = torch.empty((A, P, 3), device=dev)
+    leaf = torch.full((A, P), -1, dtype=torch.int32, device=dev)
+    _lib.check(lib.pvamd_composed_query_grouped(_lib.ptr(grids), S, _lib.ptr(comp._tf_device(dev)), A, _lib.ptr(scratch), P,
+                                                _lib.ptr(val), _lib.ptr(grad), _lib.ptr(leaf), 0, _lib.stream_ptr()), "grouped")
+    oval, ograd, oleaf = oracle.composed_query([H.oracle_grid_from_cached(l) for l in leaves], tfm.numpy(), A, pts.cpu().numpy())
+    assert np.array_equal(val.cpu().numpy(), oval, equal_nan=True)
+    assert np.array_equal(grad.cpu().numpy(), ograd, equal_nan=True)
+    assert np.array_equal(leaf.cpu().numpy(), oleaf)
+
+
+def test_grouped_refuses_what_it_does_not_cover():
+    lib = _lib.load()
+    chunk = _lib.group_chunk_points()
+    assert lib.pvamd_group_scratch_bytes(chunk - 1) == 0
+    assert lib.pvamd_group_scratch_bytes(chunk) > chunk * 14
+    comp, _, _ = composed(2, 2, seed=1)
+    pts = scene_points(chunk, seed=1).cuda()
+    scratch = _lib.group_points(pts)
+    grids = comp._leaf_grids(pts.device)
+    val = torch.empty((2, chunk), device="cuda")
+    grad = torch.empty((2, chunk, 3), device="cuda")
+    args = (_lib.ptr(grids), 2, _lib.ptr(comp._tf_device(pts.device)), 2, _lib.ptr(scratch))
+    assert lib.pvamd_composed_query_grouped(*args, chunk - 1, _lib.ptr(val), _lib.ptr(grad), None, 0, _lib.stream_ptr()) == _lib.E_SHAPE
+    assert lib.pvamd_composed_query_grouped(*args, chunk, _lib.ptr(val), _lib.ptr(grad), None, _lib.COMPOSED_INLINE_EXACT,
+                                            _lib.stream_ptr()) == -4
+    assert lib.pvamd_group_points(_lib.ptr(pts), chunk - 1, _lib.ptr(scratch), _lib.stream_ptr()) == _lib.E_SHAPE
+    assert lib.pvamd_group_points(None, chunk, _lib.ptr(scratch), _lib.stream_ptr()) == -1
+    torch.cuda.synchronize()
+
+
+def test_grouped_with_nan_infinite_and_coincident_points():
+    """Non-finite coordinates take part in no bound (the run they are in visits every leaf) and land in some Hilbert cell; a
+    chunk of identical points has a zero-size box.  Results as the oracle's, NaN for NaN."""
+    S, A = 6, 3
+    chunk = _lib.group_chunk_points()
+    P = 3 * chunk
+    comp, leaves, tfm = composed(S, A, seed=9)
+    pts = scene_points(P, seed=11, extent=0.6)
+    pts[5] = float("nan")
+    pts[17, 1] = float("inf")
+    pts[chunk + 3, 2] = -float("inf")
+    pts[chunk + 100, 0] = float("nan")
+    pts[2 * chunk:] = pts[2 * chunk]  # the third chunk: one point, repeated
+    pts = pts.cuda()
+    comp.group_points = True
+    val, grad = comp(pts)
+    oval, ograd, _ = oracle.composed_query([H.oracle_grid_from_cached(l) for l in leaves], tfm.numpy(), A, pts.cpu().numpy())
+    assert np.array_equal(val.cpu().numpy(), oval, equal_nan=True)
+    assert np.array_equal(grad.cpu().numpy(), ograd, equal_nan=True)
+
+
+def test_grouped_on_compact_points_uses_the_leaf_mask_and_stays_exact():
+    """Points inside a small region (every run's sphere is far smaller than the scene: the masked leaf loop with its
+    refinement runs) and leaves spread far apart, so that whole leaves are dropped per run."""
+    S, A = 8, 4
+    chunk = _lib.group_chunk_points()
+    P = 2 * chunk + 77
+    comp, leaves, tfm = composed(S, A, seed=21, trans=1.5)
+    pts = (scene_points(P, seed=2, extent=0.08) + torch.tensor([0.3, -0.2, 0.1])).cuda()
+    comp.group_points = True
+    val, grad = comp(pts)
+    oval, ograd, _ = oracle.composed_query([H.oracle_grid_from_cached(l) for l in leaves], tfm.numpy(), A, pts.cpu().numpy())
+    assert np.array_equal(val.cpu().numpy(), oval, equal_nan=True)
+    assert np.array_equal(grad.cpu().numpy(), ograd, equal_nan=True)
+
+
+def test_query_into_grouped_at_odd_addresses_and_replayed_from_a_graph():
+    """query_into picks the grouped kernel on its own for a batch in the wave-tile regime; buffers that are only dword
+    aligned; the two launches captured in a hipGraph and replayed after the transforms changed in place."""
+    S, A = 8, 40
+    P = 2 * _lib.group_chunk_points() + 257 * 4 + 1  # A * tiles >= 32768 needs P >= 209,716 at A = 40 ... not here: force it
+    comp, leaves, tfm = composed(S, A, seed=4)
+    comp.group_points = True
+    pts = scene_points(P, seed=8, extent=0.6)
+    pbuf = torch.zeros(3 * P + 8, device="cuda")
+    pbuf[1:1 + 3 * P] = pts.reshape(-1).cuda()
+    pview = pbuf[1:1 + 3 * P].view(P, 3)
+    vbuf = torch.full((A * P + 8,), -7.0, device="cuda")
+    gbuf = torch.full((3 * A * P + 8,), -7.0, device="cuda")
+    vview, gview = vbuf[3:3 + A * P].view(A, P), gbuf[1:1 + 3 * A * P].view(A, P, 3)
+    comp.query_into(pview, vview, gview)
+    ogrids = [H.oracle_grid_from_cached(l) for l in leaves]
+    oval, ograd, _ = oracle.composed_query(ogrids, tfm.numpy(), A, pts.numpy())
+    assert np.array_equal(vview.cpu().numpy(), oval, equal_nan=True)
+    assert np.array_equal(gview.cpu().numpy(), ograd, equal_nan=True)
+    assert (vbuf[:3] == -7).all() and (vbuf[3 + A * P:] == -7).all() and (gbuf[:1] == -7).all() and (gbuf[1 + 3 * A * P:] == -7).all()
+    # graph replay with new transforms written in place
+    tf_dev = comp._tf_device(pview.device)
+    g = torch.cuda.CUDAGraph()
+    s = torch.cuda.Stream()
+    with torch.cuda.stream(s):
+        comp.query_into(pview, vview, gview)
+        with torch.cuda.graph(g, stream=s):
+            comp.query_into(pview, vview, gview)
+    tfm2 = H.random_rigid(S * A, seed=44, trans=0.3)
+    tf_dev.copy_(tfm2.cuda())
+    vbuf.fill_(-7.0)
+    g.replay()
+    torch.cuda.synchronize()
+    oval, ograd, _ = oracle.composed_query(ogrids, tfm2.numpy(), A, pts.numpy())
+    assert np.array_equal(vview.cpu().numpy(), oval, equal_nan=True)
+    assert np.array_equal(gview.cpu().numpy(), ograd, equal_nan=True)
+
+
+def test_auto_takes_the_grouped_kernel_only_in_its_regime():
+    comp, _, _ = composed(2, 2, seed=1)
+    chunk = _lib.group_chunk_points()
+    assert comp.group_points == "auto"
+    assert not comp._grouping_pays(1, 1 << 22, 0)            # a single configuration cannot amortise the sort pass
+    assert not comp._grouping_pays(200, chunk - 1, 0)        # less than a chunk
+    assert not comp._grouping_pays(200, 15_251, 0)           # too few tiles to fill the chip: the per-lane kernel's regime
+    assert comp._grouping_pays(200, 1 << 18, 0)              # C4
+    assert not comp._grouping_pays(200, 1 << 18, _lib.COMPOSED_INLINE_EXACT)  # gather-bound grids: the bucketed path's regime
