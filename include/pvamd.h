@@ -90,6 +90,12 @@ typedef struct pvamd_grid {
     /* ---- float64 query points (the *_f64 entry points) ---- */
     double       dbb_min[3]; /* surface bounding box in float64: sdf.py:556-557 casts self.bb to the query dtype   */
     double       dbb_max[3];
+    /* ---- derived by pvamd_grid_finalize() (ABI 11) ---- */
+    float        range_n2;   /* the largest squared bounding-box distance fma(tz,tz,fma(ty,ty,tx*tx)) (sdf.py:559-568, float32)
+                                any VALID p can have: the statements are monotone, so it is their value at the corner of
+                                [vlo, vhi] farthest from the box.  n2 > range_n2 proves "out of range" with one compare.
+                                +inf when the descriptor has no box (NaN bounds).                                   */
+    float        reserved0;
 } pvamd_grid_t;
 
 /*

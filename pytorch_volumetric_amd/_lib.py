@@ -75,6 +75,8 @@ class GridDesc(ctypes.Structure):
         ("rule", ctypes.c_int32),
         ("dbb_min", ctypes.c_double * 3),
         ("dbb_max", ctypes.c_double * 3),
+        ("range_n2", ctypes.c_float),
+        ("reserved0", ctypes.c_float),
     ]
 
 

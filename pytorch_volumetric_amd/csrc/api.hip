@@ -132,6 +132,24 @@ extern "C" int pvamd_grid_finalize(pvamd_grid_t* g) {
     // estimate_unsure); a larger bound only sends a few more points to the exact statements
     const float worst = std::fmax(g->err32[0], std::fmax(g->err32[1], g->err32[2]));
     for (int d = 0; d < 3; ++d) g->err32[d] = worst;
+    // range_n2: the kernels' own statements (grid_lookup.h / composed.hip: t = med3(p - bb_min, p - bb_max, 0) per axis, n2 =
+    // fma(tz, tz, fma(ty, ty, tx * tx)), every operation a correctly rounded float32 one) are monotone in p on either side of
+    // the box, so over the valid interval |t| is largest at vlo or vhi and n2 at the corner that takes the larger one per axis
+    float pad[3];
+    for (int d = 0; d < 3; ++d) {
+        float worst_t = 0.f;
+        const float ends[2] = {g->vlo[d], g->vhi[d]};
+        for (float p : ends) {
+            const float d1 = p - g->bb_min[d], d2 = p - g->bb_max[d];  // d1 >= d2
+            float t = d1 < 0.f ? d1 : (d2 > 0.f ? d2 : 0.f);           // median of (d1, d2, 0)
+            if (d1 != d1 || d2 != d2) t = NAN;
+            worst_t = (t != t || worst_t != worst_t) ? NAN : std::fmax(worst_t, std::fabs(t));
+        }
+        pad[d] = worst_t;
+    }
+    const float n2 = std::fmaf(pad[2], pad[2], std::fmaf(pad[1], pad[1], pad[0] * pad[0]));
+    g->range_n2 = (n2 != n2) ? INFINITY : n2;
+    g->reserved0 = 0.f;
     g->finalized = 1;
     return 0;
 }

@@ -441,18 +441,22 @@ PVAMD_DEV void tile_passes_split(const pvamd_grid_t* __restrict__ grids, int S, 
             const pvamd_grid_t& g = grids[s];
 #pragma unroll
             for (int k = 0; k < PPP; ++k) {
-#if defined(PVAMD_ABLATE) && (PVAMD_ABLATE & 4)  // timing experiment only: the leaf-frame coordinates for one add each (what an
-                // affine computed elsewhere -- on the matrix pipe, say -- could save at the very most)
-                const float x = px[k] + M[3], y = py[k] + M[7], z = pz[k] + M[11];
-#else
                 const float x = affine_row(M[0], M[1], M[2], M[3], px[k], py[k], pz[k]);
                 const float y = affine_row(M[4], M[5], M[6], M[7], px[k], py[k], pz[k]);
                 const float z = affine_row(M[8], M[9], M[10], M[11], px[k], py[k], pz[k]);
-#endif
-                uint64_t vm = in_range_mask(g, x, y, z);
-#if defined(PVAMD_ABLATE) && (PVAMD_ABLATE & 1)  // timing experiment only (tools/r4_ablate.sh): no in-range look-ups
-                vm = 0;
-#endif
+                // sdf.py:559-568 for every lane, squared (no exec masking; in-range lanes are masked out of the take)
+                const float ta = __builtin_amdgcn_fmed3f(sub_rn(x, g.bb_min[0]), sub_rn(x, g.bb_max[0]), 0.f);
+                const float tb = __builtin_amdgcn_fmed3f(sub_rn(y, g.bb_min[1]), sub_rn(y, g.bb_max[1]), 0.f);
+                const float tc = __builtin_amdgcn_fmed3f(sub_rn(z, g.bb_min[2]), sub_rn(z, g.bb_max[2]), 0.f);
+                const float n2 = fmaf(tc, tc, fmaf(tb, tb, mul_rn(ta, ta)));
+                // Round 6: ONE compare stands in front of the range test.  Every statement from x to n2 is monotone in how far
+                // x lies outside the box, so over the valid interval [vlo, vhi] n2 is largest at an end point:
+                // pvamd_grid_finalize() evaluates these same statements there (range_n2), and n2 > range_n2 PROVES the
+                // point out of range -- exactly, no tolerance.  With neighbouring points per wave (the grouped kernel) most
+                // visits end here: 9 vector instructions and the vlo / vhi scalar loads become one compare.  A NaN n2 (NaN
+                // point, or a descriptor without a box) proves nothing and takes the range test.
+                uint64_t vm = 0;
+                if (__builtin_amdgcn_ballot_w64(!(n2 > g.range_n2)) != 0) vm = in_range_mask(g, x, y, z);
                 if (vm != 0) {
                     // the lanes in range look their value up (index estimate; shaky ones are redone exactly below)
                     const bool valid = __builtin_amdgcn_inverse_ballot_w64(vm);
@@ -469,20 +473,14 @@ PVAMD_DEV void tile_passes_split(const pvamd_grid_t* __restrict__ grids, int S, 
                     bin[k].flat = t ? flat : bin[k].flat;
                     if (vm == everyone) continue;
                 }
-#if defined(PVAMD_ABLATE) && (PVAMD_ABLATE & 2)  // timing experiment only: no out-of-range candidates
-                best[k].n2 = __builtin_fminf(best[k].n2, x + y + z);  // keeps the affine alive
-                continue;
-#endif
-                // sdf.py:559-568 for every lane, squared (no exec masking; in-range lanes are masked out of the take)
-                const float ta = __builtin_amdgcn_fmed3f(sub_rn(x, g.bb_min[0]), sub_rn(x, g.bb_max[0]), 0.f);
-                const float tb = __builtin_amdgcn_fmed3f(sub_rn(y, g.bb_min[1]), sub_rn(y, g.bb_max[1]), 0.f);
-                const float tc = __builtin_amdgcn_fmed3f(sub_rn(z, g.bb_min[2]), sub_rn(z, g.bb_max[2]), 0.f);
-                const float n2 = fmaf(tc, tc, fmaf(tb, tb, mul_rn(ta, ta)));
                 // first minimum, NaN counts as minimum (keep_first_minimum), on the squared norms
                 uint64_t take = __builtin_amdgcn_ballot_w64(!(n2 >= best[k].n2)) &
                                 __builtin_amdgcn_ballot_w64(best[k].n2 == best[k].n2) & ~vm;
-                const uint64_t near = take & __builtin_amdgcn_ballot_w64(n2 >= mul_rn(best[k].n2, kNearTie));
                 BAND_STAT(0, 1);
+                // nobody improves (neighbouring points agree on which leaves are far): the near-tie test and the five
+                // selects are skipped for the wave
+                if (take == 0) continue;
+                const uint64_t near = take & __builtin_amdgcn_ballot_w64(n2 >= mul_rn(best[k].n2, kNearTie));
                 if (__builtin_expect(near != 0, 0)) {
                     // the two roots may round to the same float32, in which case the incumbent stays: decide exactly
                     const float ra = sqrt_rn_sumsq(best[k].n2), rb = sqrt_rn_sumsq(n2);
