@@ -125,15 +125,17 @@ class Timer:
         # (profiles/r04_stall.txt): one such pass inside a 20-call timed region reads as 1 ms per call.  Not in the timed span.
         was_enabled = gc.isenabled()
         gc.disable()
-        t0 = time.perf_counter()
-        fn()
-        done.record()
-        while not done.query():
-            pass
-        torch.cuda.synchronize()
-        elapsed = time.perf_counter() - t0
-        if was_enabled:
-            gc.enable()
+        try:
+            t0 = time.perf_counter()
+            fn()
+            done.record()
+            while not done.query():
+                pass
+            torch.cuda.synchronize()
+            elapsed = time.perf_counter() - t0
+        finally:  # a leg that raises inside the timed span must not leave the collector off for the legs after it
+            if was_enabled:
+                gc.enable()
         self.barrier()
         if self.world > 1:
             t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")

@@ -217,6 +217,15 @@ def load():
         fn.argtypes = argtypes
     if lib.pvamd_abi_version() != ABI_VERSION:
         raise PvamdError(f"libpvamd ABI {lib.pvamd_abi_version()} != binding ABI {ABI_VERSION}; rebuild")
+    # an A/B build (tools/build_variant.sh: one translation unit compiled with tuning / counter knobs) names itself; the product
+    # path and the tests never load one by accident
+    if hasattr(lib, "pvamd_variant"):
+        lib.pvamd_variant.restype = ctypes.c_char_p
+        what = lib.pvamd_variant().decode()
+        if os.environ.get("PVAMD_ALLOW_VARIANT") != "1":
+            raise PvamdError(f"{LIB_PATH} is an A/B build ({what}); set PVAMD_ALLOW_VARIANT=1 to time it, or unset PVAMD_LIB")
+        import sys
+        print(f"[pvamd] A/B build loaded: {what} ({LIB_PATH})", file=sys.stderr)
     _lib = lib
     return lib
 
@@ -316,7 +325,7 @@ def as_query_points(points, device=None, keep_f64=False):
     return flat, lead, points.dtype if points.dtype.is_floating_point else torch.float32, points.device
 
 
-ORDER_RADIX_SORT_FROM = int(os.environ.get("PVAMD_RADIX_FROM", 3 << 18))  # PVAMD_ORDER_RADIX_SORT_FROM (the env: A/B builds only)
+ORDER_RADIX_SORT_FROM = 3 << 18  # PVAMD_ORDER_RADIX_SORT_FROM of the product build; morton_order_scratch_words() sizes for EITHER sort
 
 
 
@@ -341,9 +350,12 @@ def group_points(flat):
 
 def morton_order_scratch_words(P):
     """PVAMD_MORTON_ORDER_SCRATCH_BYTES(P) / 4"""
-    if P >= ORDER_RADIX_SORT_FROM:  # the radix sort: supergroup totals + tile histograms (<= 512 words per 4096-pair tile), 2 key + 2 index arrays
-        return 8 + 4 * P + 512 * ((P + 4095) // 4096)
-    return 8 + (1 << (21 if P >= (1 << 20) else (18 if P >= (1 << 16) else 15))) + P + 2048
+    # The library picks the sort by a compile-time threshold the binding cannot see in an A/B build (ADVICE r5: an env override
+    # here let Python size the counting sort's scratch while the C side ran the radix sort past it): size for whichever needs
+    # more.  Radix: supergroup totals + tile histograms (<= 512 words per 4096-pair tile), 2 key + 2 index arrays.
+    radix = 8 + 4 * P + 512 * ((P + 4095) // 4096)
+    counting = 8 + (1 << (21 if P >= (1 << 20) else (18 if P >= (1 << 16) else 15))) + P + 2048
+    return max(radix, counting)
 
 
 def morton_order(points, min_points=2048, want_inverse=False, want_sorted=False):

@@ -20,7 +20,7 @@ namespace pvamd {
 // Any point count >= 256 and any 4-byte aligned buffers: the 16-byte accesses take dword addresses (common.h f32x4_u); a
 // ragged end is covered by moving the last tile back so that it ends at the last point.
 // Waves per workgroup.  Round 4: 16 (1024 threads, 64 KB of LDS, two workgroups per CU) instead of 8 -- found while A/B-ing
-// LDS-DMA point loads (slower at every depth: profiles/r04_cq_variants.txt): the 64M-point launch 382 -> 346 us (5.43 TB/s =
+// LDS-DMA point loads (slower at every depth: profiles/r04_cq_variants.txt; the experiment's source is tools/patches/cq_ablate_and_dma.patch): the 64M-point launch 382 -> 346 us (5.43 TB/s =
 // 0.68 of 8 TB/s; 336 us = 0.70 on another box), with EVERY point gathering 568 -> 419 us -- round 3's "gather ceiling that no
 // launch geometry moves" (0.55-0.59 ms) was the 8-wave geometry's; 1M and 8M points unchanged (5.84 / 39.9 us).
 #ifndef PVAMD_CQ_WAVES
@@ -107,11 +107,7 @@ __global__ __launch_bounds__(kWavesPerBlock * 64, PVAMD_CQ_MINWAVES) void cached
             bool valid[4];
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
-#if defined(PVAMD_CQ_ABLATE) && (PVAMD_CQ_ABLATE == 1)  // timing experiment (WRONG results; profiles/r05_cq_geometry.txt): load -> LDS -> store only
-                r[k] = make_float4(px[k], py[k], pz[k], px[k]); valid[k] = true;
-#else
                 r[k] = cached_lookup<F64, LD_NT>(g, px[k], py[k], pz[k], valid[k]);  // LD_NT = the streaming launch (> 8M points)
-#endif
             }
             sp[3 * lane] = f32x4{r[0].y, r[0].z, r[0].w, r[1].y};
             sp[3 * lane + 1] = f32x4{r[1].z, r[1].w, r[2].y, r[2].z};
@@ -152,88 +148,6 @@ __global__ __launch_bounds__(kWavesPerBlock * 64, PVAMD_CQ_MINWAVES) void cached
         PVAMD_WAVE_SYNC();
     }
 }
-
-#ifdef PVAMD_CQ_DMA
-// ---- experiment (round 4, tools/r4_cq_dma.sh): the point stream through LDS-DMA, PVAMD_CQ_DMA tiles in flight per wave ----
-// global_load_lds_dwordx4 lands a contiguous KB (wave-uniform LDS base + lane x 16) straight in the tile's LDS slot: no
-// staging VGPRs, no ds_write pass, and a wave can have several tiles' loads in flight at no register cost.  A wave takes
-// PVAMD_CQ_DMA consecutive tiles: all their loads are issued first, then tile t is processed once at most 3 x (tiles after
-// t) vector-memory operations are still outstanding (the stores of earlier tiles count too: the wait is conservative).
-constexpr int kDmaTiles = PVAMD_CQ_DMA;
-PVAMD_DEV void wait_vmcnt(int n) {  // s_waitcnt vmcnt(n) only (gfx9 encoding: vmcnt[3:0] | expcnt 7 << 4 | lgkmcnt 15 << 8 | vmcnt[5:4] << 14)
-    switch (n) {
-        case 0: __builtin_amdgcn_s_waitcnt(0x0F70); break;
-        case 3: __builtin_amdgcn_s_waitcnt(0x0F73); break;
-        case 6: __builtin_amdgcn_s_waitcnt(0x0F76); break;
-        case 9: __builtin_amdgcn_s_waitcnt(0x0F79); break;
-        case 12: __builtin_amdgcn_s_waitcnt(0x0F7C); break;
-        default: __builtin_amdgcn_s_waitcnt(0x0F70); break;
-    }
-}
-template <bool F64, bool ST_NT>
-__global__ __launch_bounds__(kWavesPerBlock * 64) void cached_query_dma(const pvamd_grid_t g, const float* __restrict__ pts, int64_t P,
-                                                                         float* __restrict__ val, float* __restrict__ grad) {
-    __shared__ __attribute__((aligned(16))) float lds[kWavesPerBlock][kDmaTiles][768];
-    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int64_t ntiles = (P + kTilePoints - 1) / kTilePoints;
-    const int64_t t0 = ((int64_t)blockIdx.x * kWavesPerBlock + wave) * kDmaTiles;
-    auto first_point = [&](int64_t t) { return t * kTilePoints <= P - kTilePoints ? t * kTilePoints : P - kTilePoints; };
-    typedef const __attribute__((address_space(1))) void* gptr_t;
-    typedef __attribute__((address_space(3))) void* lptr_t;
-#pragma unroll
-    for (int t = 0; t < kDmaTiles; ++t) {
-        const int64_t tile = t0 + t < ntiles ? t0 + t : ntiles - 1;  // past the end: reload the last tile (never written out)
-        const float* src = pts + 3 * first_point(tile);
-#pragma unroll
-        for (int j = 0; j < 3; ++j)
-            __builtin_amdgcn_global_load_lds((gptr_t)(src + 4 * (lane + 64 * j)), (lptr_t)(&lds[wave][t][256 * j]), 16, 0, 0);
-    }
-    // stores of tile t - 1 are issued AFTER the wait for tile t's loads, so that that wait counts loads only (with PVAMD_CQ_DMA
-    // = 2 it is exact; deeper, the stores of tile t - 2 are still in the count and the wait is conservative)
-    f32x4 v4_prev = {0.f, 0.f, 0.f, 0.f};
-    auto store_tile = [&](int t, f32x4 v4) {
-        const f32x4_alias* sp = reinterpret_cast<const f32x4_alias*>(lds[wave][t]);
-        const int64_t o = first_point(t0 + t);
-        f32x4_u* vdst = reinterpret_cast<f32x4_u*>(val + o);
-        f32x4_u* dst = reinterpret_cast<f32x4_u*>(grad + 3 * o);
-        if (ST_NT) {
-            __builtin_nontemporal_store(v4, vdst + lane);
-            __builtin_nontemporal_store(sp[lane], dst + lane);
-            __builtin_nontemporal_store(sp[lane + 64], dst + lane + 64);
-            __builtin_nontemporal_store(sp[lane + 128], dst + lane + 128);
-        } else {
-            vdst[lane] = v4;
-            dst[lane] = sp[lane];
-            dst[lane + 64] = sp[lane + 64];
-            dst[lane + 128] = sp[lane + 128];
-        }
-    };
-    int done = 0;
-#pragma unroll
-    for (int t = 0; t < kDmaTiles; ++t) {
-        if (t0 + t >= ntiles) break;
-        wait_vmcnt(3 * (kDmaTiles - 1 - t));
-        PVAMD_WAVE_SYNC();
-        if (t > 0) store_tile(t - 1, v4_prev);
-        float* spf = lds[wave][t];
-        f32x4_alias* sp = reinterpret_cast<f32x4_alias*>(spf);
-        const f32x4 q0 = sp[3 * lane], q1 = sp[3 * lane + 1], q2 = sp[3 * lane + 2];
-        const float px[4] = {q0.x, q0.w, q1.z, q2.y}, py[4] = {q0.y, q1.x, q1.w, q2.z}, pz[4] = {q0.z, q1.y, q2.x, q2.w};
-        PVAMD_WAVE_SYNC();
-        float4 r[4];
-        bool valid[4];
-#pragma unroll
-        for (int k = 0; k < 4; ++k) r[k] = cached_lookup<F64>(g, px[k], py[k], pz[k], valid[k]);
-        sp[3 * lane] = f32x4{r[0].y, r[0].z, r[0].w, r[1].y};
-        sp[3 * lane + 1] = f32x4{r[1].z, r[1].w, r[2].y, r[2].z};
-        sp[3 * lane + 2] = f32x4{r[2].w, r[3].y, r[3].z, r[3].w};
-        v4_prev = f32x4{r[0].x, r[1].x, r[2].x, r[3].x};
-        PVAMD_WAVE_SYNC();
-        done = t + 1;
-    }
-    if (done > 0) store_tile(done - 1, v4_prev);
-}
-#endif
 
 // ---- one point per lane: small batches (more waves than 256-point tiles would give) ----
 template <bool F64>
@@ -389,18 +303,6 @@ extern "C" int pvamd_cached_query(const pvamd_grid_t* grid, const float* points,
         const bool big = P > ((int64_t)8 << 20);  // > 8M points (96 MB of xyz): streaming regime
         const int64_t cap = big ? PVAMD_CQ_BIG_BLOCKS : PVAMD_CQ_BLOCKS;  // 0: one tile per wave, no grid-stride loop
         const dim3 grid_dim((unsigned)((cap > 0 && need > cap) ? cap : need)), block(kWavesPerBlock * 64);
-#ifdef PVAMD_CQ_DMA
-#ifndef PVAMD_CQ_DMA_ALL
-#define PVAMD_CQ_DMA_ALL 0
-#endif
-        if ((big || PVAMD_CQ_DMA_ALL) && !out_oob) {  // the experiment: LDS-DMA point stream, kDmaTiles tiles per wave
-            const int64_t per_block = (int64_t)kWavesPerBlock * kDmaTiles;
-            const dim3 dgrid((unsigned)((ntiles + per_block - 1) / per_block));
-            if (f64) hipLaunchKernelGGL((cached_query_dma<true, PVAMD_CQ_BIG_ST_NT>), dgrid, block, 0, s, *grid, points, P, out_val, out_grad);
-            else hipLaunchKernelGGL((cached_query_dma<false, PVAMD_CQ_BIG_ST_NT>), dgrid, block, 0, s, *grid, points, P, out_val, out_grad);
-            return (int)hipGetLastError();
-        }
-#endif
 #define PVAMD_LAUNCH_CQ(F64_, OOB_)                                                                                      \
     do {                                                                                                                \
         if (big) hipLaunchKernelGGL((cached_query_wave<F64_, OOB_, PVAMD_CQ_BIG_LD_NT, PVAMD_CQ_BIG_ST_NT>), grid_dim, block, 0, s, *grid, points, P, out_val, out_grad, out_oob); \

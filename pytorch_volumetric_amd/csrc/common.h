@@ -4,6 +4,13 @@
 #include <stdint.h>
 #include "../../include/pvamd.h"
 
+// A/B builds (tools/build_variant.sh compiles ONE translation unit with extra -D knobs and -DPVAMD_VARIANT="name: flags") carry
+// their name in the library: _lib.load() refuses a library that exports pvamd_variant unless PVAMD_ALLOW_VARIANT=1 is set, so a
+// tuning build cannot be picked up by the product path or the tests by accident.  The product build never defines it.
+#ifdef PVAMD_VARIANT
+extern "C" __attribute__((visibility("default"), weak)) const char* pvamd_variant(void) { return PVAMD_VARIANT; }
+#endif
+
 namespace pvamd {
 
 // native clang vectors: the non-temporal builtins and 16-B global_load/store_dwordx4 want these, not HIP's structs

@@ -227,7 +227,7 @@ extern "C" int pvamd_configure_chain(const pvamd_joint_t* joints, int32_t F, con
     if (M > 0 && !q) return PVAMD_E_NULL;
     const size_t lds = (size_t)S * 12 * 64 * sizeof(float) + (size_t)F * sizeof(pvamd_joint_t) + (size_t)64 * M * 2 * sizeof(float);
     if (lds > 150 * 1024) return PVAMD_E_SHAPE;  // ~50 SDF-carrying links: use pvamd_chain_fk + pvamd_transform_stack
-    if (lds > 64 * 1024) {  // more dynamic LDS than a launch gets by default (21+ SDF-carrying links): opt in, per call (no state kept)
+    if (lds > 64 * 1024) {  // more dynamic LDS than a launch gets by default (21+ SDF-carrying links): opt in (hipFuncSetAttribute leaves a per-function attribute behind: harmless, a later call only ever raises it)
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(configure_chain_kernel),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return (int)e;

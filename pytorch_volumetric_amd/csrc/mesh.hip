@@ -867,10 +867,6 @@ PVAMD_DEV bool scan_mesh(const MeshArgs& m, MeshShared<SLICES, WITH_RAY>& sh, Wa
             greedy_reach(m, sh.g, wv, first);
 #endif
             TOC(20, t_seed);
-#ifdef PVAMD_MESH_ONLY_SEED  // timing experiment (WRONG results; profiles/r05_mesh_experiments.txt): begin + seed + greedy alone
-            __syncthreads();
-            return false;
-#endif
             visit_tile<WITH_RAY>(m, sh.g, sh.w[wave], wv, first);
             drain_closest(m, sh.g, sh.w[wave], wv, true);  // publish what the nearest tile gave before looking further
         }

@@ -2,6 +2,7 @@
 (reference model_to_sdf.py:12-133).  One leaf per mesh visual; forward kinematics gives world_T_link per
 configuration; `pvamd_transform_stack` (f32 MFMA) contracts them with the visual offsets into the leaf-major
 object->leaf stack that the fused ComposedSDF kernel consumes."""
+import ctypes
 import logging
 import math
 import typing
@@ -163,8 +164,11 @@ class RobotSDF(sdf.ObjectFrameSDF):
             _lib.check(lib.pvamd_transform_stack(offset_inv.data_ptr(), link_world.data_ptr(), S, A, stack.data_ptr(), stream),
                        "pvamd_transform_stack")
         elif rc == _lib.E_SHAPE and one_launch_only:
-            raise ValueError(f"configure_and_query_into: {S} SDF-carrying links do not fit the one-launch configure kernel "
-                             "(about 50 at most); call set_joint_configuration(q) and query_into(...) instead")
+            lds = S * 12 * 64 * 4 + F * ctypes.sizeof(_lib.JointDesc) + 64 * M * 2 * 4
+            raise ValueError(f"configure_and_query_into: pvamd_configure_chain refused the shape (frames F={F}, joints M={M}, "
+                             f"SDF-carrying links S={S}, configurations A={A}); its one launch needs F, A, S >= 1 and "
+                             f"{lds} bytes of LDS (limit 153600: about 50 SDF-carrying links); otherwise call "
+                             "set_joint_configuration(q) and query_into(...) instead")
         elif rc != 0:
             _lib.check(rc, "pvamd_configure_chain")
         return stack

@@ -577,10 +577,9 @@ class CachedSDF(ObjectFrameSDF):
         if out_val.shape != (P,) or out_grad.shape != (P, 3) or out_val.dtype != torch.float32 or \
                 out_grad.dtype != torch.float32 or not (out_val.is_contiguous() and out_grad.is_contiguous()):
             raise ValueError("query_into needs contiguous fp32 outputs of shape (P,) and (P,3)")
-        if getattr(self, "_desc_cache", None) is None:
-            self._desc_cache = self._grid_desc()
+        desc = self._grid_desc()  # cached per mode and cache pointer, dropped by __setattr__ when `bb` / the cache change
         with _lib.on_device(points.device):
-            _lib.check(_lib.load().pvamd_cached_query(ctypes.byref(self._desc_cache), _lib.ptr(points), P,
+            _lib.check(_lib.load().pvamd_cached_query(ctypes.byref(desc), _lib.ptr(points), P,
                                                       _lib.ptr(out_val), _lib.ptr(out_grad), None, _lib.stream_ptr()),
                        "pvamd_cached_query")
 
@@ -953,7 +952,9 @@ class ComposedSDF(ObjectFrameSDF):
     def query_prepared(self, prepared: "PreparedPoints", order="caller"):
         """The fused query over a prepare_points() handle under the CURRENT transforms (set_transforms /
         RobotSDF.set_joint_configuration between calls as usual).
-        order="caller": exactly what __call__(points) returns -- same shapes, same bits -- without the per-call sort.
+        order="caller": exactly what __call__(points) returns -- same shapes, same bits -- without the per-call sort (for float32
+            and lower-precision points; float64 points were rounded to float32 by prepare_points, whereas __call__ answers
+            them with float64 index arithmetic, sdf.py:545: prepare float32 points if the two must agree).
         order="sorted": (A..., P) / (A..., P, 3) with column j the result of caller point `prepared.order[j]` (flattened
         index): no sort and no un-permute pass -- the kernel's own output order.  Same bits, permuted."""
         if order not in ("caller", "sorted"):

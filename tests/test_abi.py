@@ -114,3 +114,19 @@ def test_product_never_touches_the_oracle():
                     assert '#include "../../oracle' not in text and "oracle/" not in text.replace("oracle/pvamd_oracle.c", ""), f
     deps = subprocess.run(["ldd", _lib.LIB_PATH], capture_output=True).stdout.decode()
     assert "oracle" not in deps
+
+
+def test_no_wrong_result_experiments_in_the_product_sources_and_variants_are_refused():
+    """timing experiments that return WRONG results are patches under tools/patches now, not #ifdefs in
+    csrc/; an A/B build (tools/build_variant.sh) names itself through `pvamd_variant` and _lib.load() refuses it unless
+    PVAMD_ALLOW_VARIANT=1.  The product library exports no such symbol."""
+    import glob
+    csrc = os.path.join(ROOT, "pytorch_volumetric_amd", "csrc")
+    for path in glob.glob(os.path.join(csrc, "*.hip")) + glob.glob(os.path.join(csrc, "*.h")):
+        text = open(path).read()
+        for word in ("ABLATE", "ONLY_SEED", "WRONG results"):
+            assert word not in text, f"{word} in {os.path.basename(path)}"
+    out = subprocess.run(["nm", "-D", _lib.LIB_PATH], capture_output=True, text=True, check=True).stdout
+    assert "pvamd_variant" not in out and "pvamd_debug" not in out
+    assert "pvamd_variant" in open(os.path.join(csrc, "common.h")).read()
+    assert "PVAMD_ALLOW_VARIANT" in open(os.path.join(ROOT, "pytorch_volumetric_amd", "_lib.py")).read()

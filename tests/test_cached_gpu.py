@@ -360,3 +360,52 @@ def test_streaming_launch_equals_the_chunked_calls_and_the_oracle(f64):
                                          pv._lib.stream_ptr()), "pvamd_cached_query")
     assert torch.equal(v2.nan_to_num(7.0), val.nan_to_num(7.0)) and torch.equal(g2.nan_to_num(7.0), grad.nan_to_num(7.0))
     assert torch.equal(oob.bool(), ~c.voxels.get_valid_values(pts))
+
+
+def test_query_into_follows_a_reassigned_bounding_box_and_a_repacked_cache():
+    """query_into kept the first descriptor it saw; `c.bb = ...` (and a re-packed cache) changed what
+    __call__ answered but not what query_into did.  Both now read the descriptor cache that __setattr__ invalidates."""
+    c = make_cached()
+    pts = query_points(c, 20_000, seed=3).cuda()
+    val, grad = torch.empty(20_000, device="cuda"), torch.empty(20_000, 3, device="cuda")
+    c.query_into(pts, val, grad)
+    v0, g0 = c(pts)
+    assert torch.equal(val, v0) and torch.equal(grad.view(torch.int32), g0.view(torch.int32))
+    c.bb = c.bb + 0.01
+    c.query_into(pts, val, grad)
+    v1, g1 = c(pts)
+    assert not torch.equal(v1, v0)  # the out-of-range half of the points sees the moved box
+    assert torch.equal(val, v1) and torch.equal(grad.view(torch.int32), g1.view(torch.int32))
+    oval, ograd, _ = oracle.cached_query(H.oracle_grid_from_cached(c), pts.cpu().numpy())
+    assert np.array_equal(val.cpu().numpy(), oval, equal_nan=True) and np.array_equal(grad.cpu().numpy(), ograd, equal_nan=True)
+    c._packed = c._packed.clone() * 2.0  # a re-packed cache at another address
+    c.query_into(pts, val, grad)
+    v2, g2 = c(pts)
+    assert torch.equal(val, v2) and torch.equal(grad.view(torch.int32), g2.view(torch.int32)) and not torch.equal(v2, v1)
+
+
+@pytest.mark.parametrize("oob", [pv.OutOfBoundsStrategy.BOUNDING_BOX, pv.OutOfBoundsStrategy.LOOKUP_GT_SDF])
+@pytest.mark.parametrize("f64", [True, False])
+def test_nan_and_inf_points_through_the_wave_tile_kernel_in_both_oob_modes(oob, f64):
+    """the med3 range test and the NaN-ignoring max of the index-estimate check (grid_lookup.h cached_lookup, the
+    statements of launches up to 8M points) had NaN / +-inf coverage only through the composed kernels.  40,000 points take the
+    wave-tile kernel; non-finite coordinates sit in every lane position of a tile, alone and together."""
+    c = make_cached(f64=f64, oob=oob)
+    n = 40_000
+    pts = query_points(c, n, seed=21)
+    bad = [float("nan"), float("inf"), -float("inf")]
+    for i in range(0, 1024):
+        pts[7 * i % n, i % 3] = bad[i % 3]
+    pts[20_001] = float("nan")
+    pts[20_002] = float("inf")
+    pts[20_003, 0], pts[20_003, 1] = float("nan"), -float("inf")
+    val, grad = c(pts.cuda())
+    og = H.oracle_grid_from_cached(c)
+    oval, ograd, ooob = oracle.cached_query(og, pts.numpy())
+    assert ooob[20_001] and ooob[20_002] and ooob[20_003]
+    if oob == pv.OutOfBoundsStrategy.LOOKUP_GT_SDF:  # sdf.py:552-554: the ground truth answers the out-of-range subset
+        idx = np.nonzero(ooob)[0]
+        v_gt, g_gt = c.gt_sdf(pts[idx].cuda())  # on the device, as CachedSDF.__call__ asks it
+        oval[idx], ograd[idx] = v_gt.cpu().numpy(), g_gt.cpu().numpy()
+    assert np.array_equal(val.cpu().numpy(), oval, equal_nan=True)
+    assert np.array_equal(grad.cpu().numpy(), ograd, equal_nan=True)

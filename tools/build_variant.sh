@@ -10,7 +10,7 @@ mkdir -p tools/variants
 C=pytorch_volumetric_amd/csrc
 which=$(basename "$src" .hip); which=${which%%_*}
 extra=""; { [ "$which" = composed ] || [ "$which" = mesh ]; } && extra="-fno-slp-vectorize"   # as csrc/Makefile (FLAGS_*)
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -fno-fast-math -ffp-contract=off -Wno-unused-value -I$C -Iinclude $extra "$@" -c "$src" -o tools/variants/${which}_$name.o
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -fno-fast-math -ffp-contract=off -Wno-unused-value -I$C -Iinclude $extra "-DPVAMD_VARIANT=\"$name: $*\"" "$@" -c "$src" -o tools/variants/${which}_$name.o
 objs=""
 for o in api cached composed mesh chamfer_grid xform fk voxelgrid sample sort; do
   if [ $o = $which ]; then objs="$objs tools/variants/${which}_$name.o"; else objs="$objs $C/$o.o"; fi
