@@ -322,9 +322,11 @@ int pvamd_morton_keys(const float* points, int64_t P, const float* box, int32_t*
 #ifndef PVAMD_ORDER_RADIX_SORT_FROM
 #define PVAMD_ORDER_RADIX_SORT_FROM (3 << 18)  /* 786,432: counting sort 0.078 ms at 512 k, 0.166 at 1 M; radix 0.097 / 0.105 (profiles/r05_sort.txt) */
 #endif
-#define PVAMD_MORTON_ORDER_SCRATCH_BYTES(P) ((P) >= PVAMD_ORDER_RADIX_SORT_FROM \
-    ? 4 * (8 + 4 * (int64_t)(P) + 512 * (((int64_t)(P) + 4095) / 4096)) \
-    : 4 * (8 + (1 << PVAMD_MORTON_ORDER_BITS(P)) + (int64_t)(P) + 2048))
+/* enough for EITHER sort, so that the size does not depend on the threshold a library was built with */
+#define PVAMD_MORTON_RADIX_SCRATCH_BYTES(P) (4 * (8 + 4 * (int64_t)(P) + 512 * (((int64_t)(P) + 4095) / 4096)))
+#define PVAMD_MORTON_COUNTING_SCRATCH_BYTES(P) (4 * (8 + (1 << PVAMD_MORTON_ORDER_BITS(P)) + (int64_t)(P) + 2048))
+#define PVAMD_MORTON_ORDER_SCRATCH_BYTES(P) (PVAMD_MORTON_RADIX_SCRATCH_BYTES(P) > PVAMD_MORTON_COUNTING_SCRATCH_BYTES(P) \
+    ? PVAMD_MORTON_RADIX_SCRATCH_BYTES(P) : PVAMD_MORTON_COUNTING_SCRATCH_BYTES(P))
 int pvamd_morton_order(const float* points, int64_t P, int32_t* order_out, int32_t* inv_out, float* sorted_points_out,
                        void* scratch, void* stream);
 
