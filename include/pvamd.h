@@ -216,6 +216,7 @@ int pvamd_voxel_scatter_u8(const pvamd_grid_t* grid, uint8_t* storage, const flo
 #define PVAMD_COMPOSED_FORCE_PER_LANE 2   /* testing / tuning: take the one-point-per-lane kernel whatever the size */
 #define PVAMD_COMPOSED_FORCE_WAVE_TILE 4  /* testing / tuning: take the wave-tile kernel whatever the size                 */
 #define PVAMD_COMPOSED_POINTS_FASTEST 8   /* tuning: per-lane kernel with blocks ordered points-fastest (default: configuration-fastest) */
+#define PVAMD_COMPOSED_OUT_PACKED 32  /* pvamd_composed_query_grouped only: out_val takes [A][P] (val, gx, gy, gz) records (16-byte aligned), out_grad NULL */
 #define PVAMD_COMPOSED_LEGACY_LEAF_LOOP 16 /* testing / tuning: wave-tile kernel with the round-3 leaf loop (lookups and exact roots inside the leaf loop) */
 int pvamd_composed_query(const pvamd_grid_t* grids, int32_t S, const float* tf, int32_t A,
                          const float* points, int64_t P,
@@ -263,8 +264,10 @@ int pvamd_composed_query_bucketed(const pvamd_grid_t* grids, int32_t S, const fl
  * pvamd_group_points: sort every chunk of `points` (device [P][3], P >= pvamd_group_chunk_points()) once; the A
  *   configurations of a call -- and later calls on the same points -- share it.  scratch: device,
  *   pvamd_group_scratch_bytes(P) bytes, 16-byte aligned (sorted copy | bounding sphere per run of 256 | uint16 positions).
- * pvamd_composed_query_grouped: the query over that scratch.  flags: 0 (the INLINE_EXACT / LEGACY hints: PVAMD_E_MODE --
- *   gather-bound grids gain nothing from it).  Any A >= 1, any P >= pvamd_group_chunk_points(), any 4-byte aligned outputs. */
+ * pvamd_composed_query_grouped: the query over that scratch.  flags: 0, or PVAMD_COMPOSED_OUT_PACKED (the records of
+ *   pvamd_composed_query_packed, for any P: out_val = [A][P][4], out_grad = NULL); the INLINE_EXACT / LEGACY hints:
+ *   PVAMD_E_MODE -- gather-bound grids gain nothing from it.  Any A >= 1, any P >= pvamd_group_chunk_points(), any 4-byte
+ *   aligned outputs. */
 int64_t pvamd_group_chunk_points(void);
 int64_t pvamd_group_scratch_bytes(int64_t P);
 int pvamd_group_points(const float* points, int64_t P, void* scratch, void* stream);

@@ -1097,7 +1097,7 @@ __global__ __launch_bounds__(NW * 64) void group_points_kernel(const float* __re
 #ifndef PVAMD_GROUP_MINWAVES
 #define PVAMD_GROUP_MINWAVES 8
 #endif
-template <int NW, int PPP>
+template <int NW, int PPP, bool PACKED>
 __global__ __launch_bounds__(NW * 64, PVAMD_GROUP_MINWAVES) void composed_query_grouped(
     const pvamd_grid_t* __restrict__ grids, int S, const float* __restrict__ tf, int A, const float* __restrict__ sorted,
     const float* __restrict__ bounds, const uint16_t* __restrict__ perm, int64_t nchunks, int64_t P, float* __restrict__ val,
@@ -1135,11 +1135,23 @@ __global__ __launch_bounds__(NW * 64, PVAMD_GROUP_MINWAVES) void composed_query_
         __syncthreads();  // every result of the chunk is in its caller-order slot
         const f32x4_alias* sp = reinterpret_cast<const f32x4_alias*>(res[wave]);
         const int64_t o = (int64_t)a * P + cfirst + wave * kTilePoints;
-        __builtin_nontemporal_store(sp[192 + lane], reinterpret_cast<f32x4_u*>(val + o) + lane);
-        f32x4_u* dst = reinterpret_cast<f32x4_u*>(grad + 3 * o);
-        __builtin_nontemporal_store(sp[lane], dst + lane);
-        __builtin_nontemporal_store(sp[lane + 64], dst + lane + 64);
-        __builtin_nontemporal_store(sp[lane + 128], dst + lane + 128);
+        if constexpr (PACKED) {
+            // one (val, gx, gy, gz) record per point (what a query sharded over GPUs gathers): the wave's caller-order tile is
+            // 4 KB of consecutive records; plain stores -- the all-gather / unpack reads them next
+            const float* rf = res[wave];
+            f32x4* rec = reinterpret_cast<f32x4*>(val) + o;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int p = lane + 64 * k;
+                rec[p] = f32x4{rf[768 + p], rf[3 * p], rf[3 * p + 1], rf[3 * p + 2]};
+            }
+        } else {
+            __builtin_nontemporal_store(sp[192 + lane], reinterpret_cast<f32x4_u*>(val + o) + lane);
+            f32x4_u* dst = reinterpret_cast<f32x4_u*>(grad + 3 * o);
+            __builtin_nontemporal_store(sp[lane], dst + lane);
+            __builtin_nontemporal_store(sp[lane + 64], dst + lane + 64);
+            __builtin_nontemporal_store(sp[lane + 128], dst + lane + 128);
+        }
         __syncthreads();  // the slices are free for the next chunk
     }
 }
@@ -1300,8 +1312,11 @@ extern "C" int pvamd_composed_query_grouped(const pvamd_grid_t* grids, int32_t S
                                             void* stream) {
     if (S < 1 || A < 1 || P < kGroupChunk || S >= kNoLeaf) return PVAMD_E_SHAPE;
     if (flags & (PVAMD_COMPOSED_INLINE_EXACT | PVAMD_COMPOSED_LEGACY_LEAF_LOOP)) return PVAMD_E_MODE;
-    if (!grids || !tf || !out_val || !out_grad || !scratch) return PVAMD_E_NULL;
-    if (!aligned_to(grids, 8) || !aligned_to(tf, 4) || !aligned_to(scratch, 16) || !aligned_to(out_val, 4) || !aligned_to(out_grad, 4))
+    const bool packed = (flags & PVAMD_COMPOSED_OUT_PACKED) != 0;
+    if (!grids || !tf || !out_val || (!packed && !out_grad) || !scratch) return PVAMD_E_NULL;
+    if (packed && out_grad) return PVAMD_E_MODE;  // records go to out_val alone
+    if (!aligned_to(grids, 8) || !aligned_to(tf, 4) || !aligned_to(scratch, 16) || !aligned_to(out_val, packed ? 16 : 4) ||
+        !aligned_to(out_grad, 4))
         return PVAMD_E_ALIGN;
     const char* base = static_cast<const char*>(scratch);
     const int64_t nchunks = group_chunks(P);
@@ -1309,9 +1324,15 @@ extern "C" int pvamd_composed_query_grouped(const pvamd_grid_t* grids, int32_t S
     int64_t cap = ((int64_t)65536 + A - 1) / A;
     if (cap > 65535) cap = 65535;
     const unsigned gy = (unsigned)(nchunks < cap ? nchunks : (cap < 1 ? 1 : cap));
-    hipLaunchKernelGGL((composed_query_grouped<kGroupWaves, PVAMD_COMPOSED_PPP>), dim3(A, gy), dim3(kGroupWaves * 64), 0, (hipStream_t)stream,
-                       grids, S, tf, A, reinterpret_cast<const float*>(base), reinterpret_cast<const float*>(base + group_bounds_offset(P)),
-                       reinterpret_cast<const uint16_t*>(base + group_perm_offset(P)), nchunks, P, out_val, out_grad, out_leaf, 0);
+    const float* sorted = reinterpret_cast<const float*>(base);
+    const float* bounds = reinterpret_cast<const float*>(base + group_bounds_offset(P));
+    const uint16_t* perm = reinterpret_cast<const uint16_t*>(base + group_perm_offset(P));
+    if (packed)
+        hipLaunchKernelGGL((composed_query_grouped<kGroupWaves, PVAMD_COMPOSED_PPP, true>), dim3(A, gy), dim3(kGroupWaves * 64), 0,
+                           (hipStream_t)stream, grids, S, tf, A, sorted, bounds, perm, nchunks, P, out_val, out_grad, out_leaf, 0);
+    else
+        hipLaunchKernelGGL((composed_query_grouped<kGroupWaves, PVAMD_COMPOSED_PPP, false>), dim3(A, gy), dim3(kGroupWaves * 64), 0,
+                           (hipStream_t)stream, grids, S, tf, A, sorted, bounds, perm, nchunks, P, out_val, out_grad, out_leaf, 0);
     return (int)hipGetLastError();
 }
 

@@ -166,7 +166,7 @@ class RobotSDF(sdf.ObjectFrameSDF):
         elif rc == _lib.E_SHAPE and one_launch_only:
             lds = S * 12 * 64 * 4 + F * ctypes.sizeof(_lib.JointDesc) + 64 * M * 2 * 4
             raise ValueError(f"configure_and_query_into: pvamd_configure_chain refused the shape (frames F={F}, joints M={M}, "
-                             f"SDF-carrying links S={S}, configurations A={A}); its one launch needs F, A, S >= 1 and "
+                             f"SDF-carrying links S={S}, configurations A={A}); the one-launch configure kernel needs F, A, S >= 1 and "
                              f"{lds} bytes of LDS (limit 153600: about 50 SDF-carrying links); otherwise call "
                              "set_joint_configuration(q) and query_into(...) instead")
         elif rc != 0:

@@ -1035,6 +1035,13 @@ class ComposedSDF(ObjectFrameSDF):
             out = torch.empty((A, P, 4), dtype=torch.float32, device=dev)
         with _lib.on_device(dev):
             grids = self._leaf_grids(dev)
+            if self._grouping_pays(A, P, self._query_flags):
+                scratch = _lib.group_points(points)
+                _lib.check(_lib.load().pvamd_composed_query_grouped(_lib.ptr(grids), len(self.sdfs), _lib.ptr(self._tf_device(dev)), A,
+                                                                    _lib.ptr(scratch), P, _lib.ptr(out), None, None,
+                                                                    self._query_flags | _lib.COMPOSED_OUT_PACKED, _lib.stream_ptr()),
+                           "pvamd_composed_query_grouped")
+                return out
             _lib.check(_lib.load().pvamd_composed_query_packed(_lib.ptr(grids), len(self.sdfs), _lib.ptr(self._tf_device(dev)),
                                                                A, _lib.ptr(points), P, _lib.ptr(out), self._query_flags,
                                                                _lib.stream_ptr()), "pvamd_composed_query_packed")

@@ -180,3 +180,34 @@ def test_auto_takes_the_grouped_kernel_only_in_its_regime():
     assert not comp._grouping_pays(200, 15_251, 0)           # too few tiles to fill the chip: the per-lane kernel's regime
     assert comp._grouping_pays(200, 1 << 18, 0)              # C4
     assert not comp._grouping_pays(200, 1 << 18, _lib.COMPOSED_INLINE_EXACT)  # gather-bound grids: the bucketed path's regime
+
+
+@pytest.mark.parametrize("P,A,world", [(262_144 // 4, 24, 8), (40_001, 10, 8), (5000, 3, 3)])
+def test_eight_shards_computed_one_by_one_unpack_to_the_unsharded_call(P, A, world):
+    """the packed one-collective path of dist.ShardedSDF, with the all-gather's result assembled
+    by hand -- every rank's slab of packed records computed separately on this one GPU (rank r's slice of the points, padded
+    to whole tiles as ShardedSDF._packed_call pads it; the chunk-grouped packed kernel where the slice is large enough, the
+    wave-tile packed kernel otherwise), laid out (world, A, Pp, 4) as all_gather_into_tensor leaves it -- through
+    dist.packed_index + pvamd_unpack_records: equal, bit for bit, to the unsharded call.  No process group."""
+    from pytorch_volumetric_amd import dist as pvdist
+    S = 8
+    comp, leaves, tfm = composed(S, A, seed=31)
+    pts = scene_points(P, seed=12, extent=0.6).cuda()
+    comp.group_points = True  # (refused by itself below one chunk: _grouping_pays)
+    dv, dg = comp(pts)
+    _, _, chunk = pvdist.shard_range(P, world, 0)
+    Pp = -(-chunk // 256) * 256
+    gathered = torch.empty((world, A, Pp, 4), device="cuda")
+    used_grouped = False
+    for r in range(world):
+        start, stop, _ = pvdist.shard_range(P, world, r)
+        mine = pts[start:stop]
+        if mine.shape[0] < Pp:
+            mine = torch.cat((mine, pts[:1].expand(Pp - mine.shape[0], 3)), dim=0)
+        used_grouped |= comp._grouping_pays(A, Pp, 0)
+        gathered[r] = comp.query_packed(mine.contiguous())
+    assert used_grouped == (Pp >= _lib.group_chunk_points())
+    index = pvdist.packed_index(P, chunk, A, Pp, pts.device)
+    sh = pvdist.ShardedSDF(comp)
+    val, grad = sh._unpack_records(gathered, index, P, Pp, A, pts.device)
+    assert same_bits(val.cpu().numpy(), dv.cpu().numpy()) and same_bits(grad.cpu().numpy(), dg.cpu().numpy())
