@@ -10,6 +10,8 @@ BYTES_PER_QUERY = 28   # 12 B point read + 4 B value + 12 B gradient written (SU
 BYTES_PER_PAIR_C4 = 16  # C4: 4 B value + 12 B gradient written per (configuration, point); points are re-read from L2
 XGMI_LINK_GBS = 153.0   # per direction per peer link (7 links per GPU on an 8-GPU node; the task's hardware notes)
 N_SIMD = 1024
+FP32_PEAK_TFLOPS = 157.3   # MI355X vector fp32
+FLOP_PER_EXACT_PAIR = 80.0  # one point-triangle closest-point (or ray) test, nominal
 README_PUBLISHED_MS = {20: 37.688577, 200: 128.645445}  # /root/reference README.md:196-200, RTX 2080 Ti, KUKA iiwa (8 links)
 
 
@@ -73,7 +75,7 @@ def time_calls(torch, np, fn, reps=400):
     return back_to_back * 1e3, float(np.median(each)) * 1e3
 
 
-PROFILE_ROUNDS = ("r05", "r04")  # committed profile files are looked up newest round first
+PROFILE_ROUNDS = ("r06", "r05", "r04")  # committed profile files are looked up newest round first
 
 
 def profile_path(suffix):
@@ -141,9 +143,30 @@ def valu_roofline(kernel_key, ms, launches_per_step=1):
     sess_ms = entry["kernel_ms_same_session"] * launches_per_step
     achieved = inst / (sess_ms * 1e-3)
     return {"bound": "valu", "achieved": achieved / 1e9, "peak": peak / 1e9, "unit": "G wave64 VALU inst/s",
-            "frac": achieved / peak, "frac_this_run": inst / (ms * 1e-3) / peak, "kernel_ms_same_session": sess_ms,
+            "frac": achieved / peak, "frac_this_run": inst / (ms * 1e-3) / peak, "util_valu": inst / (ms * 1e-3) / peak,
+            "util_valu_is": "issued VALU instructions (committed session) / this run's time / own-mix issue ceiling: a utilisation",
+            "kernel_ms_same_session": sess_ms,
             "valu_inst_per_step": inst, "active_lanes_per_inst": entry.get("active_lanes"), "slow_fraction": f_slow,
             "session": f"profiles/{name}[workloads][{kernel_key}]"}
+
+
+
+def exact_pairs_of(torch, obj, fn):
+    """Exact point-triangle tests (closest-point + ray) ONE untimed run of `fn` executes over mesh object `obj`: counted live by
+    the product kernels (pvamd_mesh_t.pair_counters), detached again before anything is timed."""
+    counters = obj.count_exact_pairs(True)
+    try:
+        fn()
+        torch.cuda.synchronize()
+        closest, rays = (int(x) for x in counters.tolist())
+    finally:
+        obj.count_exact_pairs(False)
+    return closest, rays
+
+
+def frac_8d_pairs(pairs, ms):
+    """SURVEY.md 8(d), mesh configs: exact tests executed x 80 flop / time / 157.3 TFLOP/s (vector fp32 peak)."""
+    return pairs * FLOP_PER_EXACT_PAIR / (ms * 1e-3) / (FP32_PEAK_TFLOPS * 1e12)
 
 
 class LegSkipped(Exception):
@@ -211,7 +234,12 @@ def leg_c4(torch, dist, Wk, pv, timer, gate, robots, rank, world, steps, padding
                    else "robot.query_into(points, val, grad): fused kernel, caller's buffers",
            "sharded": {"gather": False, "value": pairs / t, "ms_per_step": t / steps * 1e3,
                        "hbm_write_GBs": BYTES_PER_PAIR_C4 * pairs / t / 1e9,
-                       "frac_of_hbm_peak": BYTES_PER_PAIR_C4 * pairs / t / 1e9 / (HBM_PEAK_GBS * world)}}
+                       "frac_of_hbm_peak": BYTES_PER_PAIR_C4 * pairs / t / 1e9 / (HBM_PEAK_GBS * world),
+                       # 16 B written per (configuration, point) pair against 8 TB/s per GPU -- this run's time only
+                       "frac_8d": BYTES_PER_PAIR_C4 * pairs / t / 1e9 / (HBM_PEAK_GBS * world),
+                       "frac_8d_is": "16 B x A x P / ms_per_step / (8 TB/s x n_gpus)",
+                       "kernel": "group_points_kernel + composed_query_grouped" if robot.sdf._grouping_pays(A, n, robot.sdf._query_flags)
+                                 else "composed_query_wave / composed_query_scalar"}}
     if not bucketed and not small and world == 1:
         out["sharded"]["roofline"] = valu_roofline("c4_composed_query_wave", t / steps * 1e3)
     if bucketed:
@@ -347,6 +375,7 @@ def leg_c3(torch, Wk, pv, timer, gate, cached, rank, world, steps, small=False):
     return {"config": f"C3: ComposedSDF of 8 transformed drills (37x33x40 cache each), {P} points, points sharded x{world}",
             "scaling": "strong", "n_gpus": world, "steps": steps, "unit": "queries/s", "value": P * steps / t,
             "ms_per_step": t / steps * 1e3, "call": "comp.query_into(points, val, grad): fused kernel, caller's buffers",
+            "frac_8d": gbs / (HBM_PEAK_GBS * world), "frac_8d_is": "28 B x P / ms_per_step / (8 TB/s x n_gpus)  (SURVEY.md 8(d))",
             "roofline": dict(valu_roofline("c3_composed_query", t / steps * 1e3) if (world == 1 and not small) else {"bound": "valu"},
                              hbm_algorithmic_GBs=gbs, frac_of_hbm_peak=gbs / (HBM_PEAK_GBS * world))}
 
@@ -361,11 +390,16 @@ def leg_c1(torch, np, Wk, pv, gate, world):
     _, grid_pts = pv.get_coordinates_and_points_in_grid(0.002, drill.bounding_box(0.01))
     pts = grid_pts[torch.randperm(len(grid_pts), generator=torch.Generator().manual_seed(0))[:10_000]].cuda()
     sdf(pts)
+    closest, rays = exact_pairs_of(torch, drill, lambda: sdf(pts))
     gate()
     call_ms, synced_ms = time_calls(torch, np, lambda: sdf(pts), reps=100)
     return {"config": f"C1: MeshSDF on YcbPowerDrill ({drill.num_faces} triangles), 10,000 grid points, one call",
             "scaling": "replicas", "n_gpus": world, "unit": "points/s", "value": 10_000 / (call_ms * 1e-3),
             "ms_per_step": call_ms, "ms_per_call": call_ms, "ms_per_call_synchronized_each": synced_ms,
+            "exact_pairs_per_step": closest + rays, "exact_closest_tests": closest, "exact_ray_tests": rays,
+            "frac_8d": frac_8d_pairs(closest + rays, call_ms),
+            "frac_8d_is": "exact point-triangle tests executed (counted live) x 80 flop / ms_per_step / 157.3 TFLOP/s",
+            "brute_force_equivalent_pairs_per_s": 10_000 * drill.num_faces / (call_ms * 1e-3),
             "roofline": valu_roofline("c1_mesh_query", call_ms)}
 
 
@@ -389,6 +423,7 @@ def leg_c5(torch, dist, Wk, pv, timer, gate, rank, world, steps, small=False, us
                 err = pv.batch_chamfer_dist(W, pts, obj_factory=mesh, scale=1000.0)
 
     mesh._mesh_desc()  # upload + prepare the mesh: set-up, before the gate
+    closest, rays = exact_pairs_of(torch, mesh, lambda: pv.batch_chamfer_dist(W, pts, obj_factory=mesh, scale=1000.0))
     gate()
     # (with ranks the warm-up count must be the same on every rank: `run` holds a collective)
     settle(torch, run, seconds=0.0 if (world > 1 or use_pg) else 0.3, at_least=2 if (world > 1 or use_pg) else 1)
@@ -398,6 +433,9 @@ def leg_c5(torch, dist, Wk, pv, timer, gate, rank, world, steps, small=False, us
     return {"config": f"C5: chamfer, {N} points -> {F}-triangle sphere mesh, points sharded x{world}, B=1",
             "scaling": "strong", "n_gpus": world, "steps": steps, "unit": "points/s", "value": N * steps / t,
             "ms_per_step": t / steps * 1e3, "brute_force_equivalent_pairs_per_s": N * F * steps / t,
+            "exact_pairs_per_step": closest + rays, "exact_closest_tests": closest, "exact_ray_tests": rays,
+            "frac_8d": frac_8d_pairs(closest + rays, t / steps * 1e3) / world,
+            "frac_8d_is": "exact tests executed over all N points (counted live) x 80 flop / ms_per_step / (157.3 TF x n_gpus)",
             "roofline": valu_roofline("c5_chamfer_mesh", t / steps * 1e3) if (world == 1 and not small) else None,
             "collective": None if (world == 1 and not use_pg) else f"all_reduce of B=1 float64 sums + count ({dist.get_backend()})",
             "chamfer_mm2": float(err[0]), "analytic_sphere_mm2": analytic,
@@ -420,21 +458,34 @@ def leg_cache_build(torch, np, Wk, pv, gate, world, small=False):
         obj = pv.MeshObjectFactory(Wk.mesh_path(mesh_name))
         gt = pv.MeshSDF(obj)
         gt(torch.zeros(64, 3).cuda())  # mesh upload + preparation: not part of a cache build's repeatable cost
-        times = []
-        for i in range(4):
+        def build():
+            return pv.CachedSDF(key, res, obj.bounding_box(padding=pad), gt, device="cuda", cache_path=None)
+
+        closest, rays = exact_pairs_of(torch, obj, build)
+        times, gpu_times = [], []
+        for i in range(6):
             torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             t0 = time.perf_counter()
-            c = pv.CachedSDF(key, res, obj.bounding_box(padding=pad), gt, device="cuda", cache_path=None)
+            e0.record()
+            c = build()
+            e1.record()
             torch.cuda.synchronize()
             if i:
                 times.append(time.perf_counter() - t0)
+                gpu_times.append(e0.elapsed_time(e1))
         shape = tuple(int(x) for x in c._view.shape)
         n = int(np.prod(shape))
-        ms = float(np.median(times)) * 1e3
+        ms, gpu_ms = float(np.median(times)) * 1e3, float(np.median(gpu_times))
         entry = {"mesh": mesh_name, "triangles": obj.num_faces, "resolution": res, "padding": pad, "grid": list(shape),
-                 "grid_is_the_reference_size": shape == want_shape, "voxels": n, "ms": ms, "value": n / (ms * 1e-3)}
+                 "grid_is_the_reference_size": shape == want_shape, "voxels": n, "ms": ms, "value": n / (ms * 1e-3),
+                 "ms_is": "wall time of CachedSDF(...) incl. the final synchronize, median of 5",
+                 "gpu_ms": gpu_ms, "gpu_ms_is": "HIP events around the same call: first launch to last kernel done",
+                 "exact_pairs": closest + rays, "exact_closest_tests": closest, "exact_ray_tests": rays,
+                 "frac_8d": frac_8d_pairs(closest + rays, gpu_ms),
+                 "frac_8d_is": "exact point-triangle tests executed (counted live) x 80 flop / gpu_ms / 157.3 TFLOP/s"}
         if world == 1 and not small:
-            roof = valu_roofline(f"build_{key}", ms)
+            roof = valu_roofline(f"build_{key}", gpu_ms)
             if roof.get("frac") is not None:
                 entry["roofline"] = roof
         out["builds"][key] = entry

@@ -126,6 +126,8 @@ typedef struct pvamd_mesh {
     int32_t      F;
     int32_t      reserved;
     double       ray_dir[3];
+    uint64_t*    pair_counters; /* device, NULL (the default) or two counters the mesh kernels add to: exact closest-point tests
+                                   and exact ray tests executed (measurement only: what the broad phase left to do)            */
 } pvamd_mesh_t;
 
 /* One frame of a kinematic tree (URDF link + the joint that attaches it to its parent), frames sorted parents-first. */

@@ -91,6 +91,7 @@ class MeshDesc(ctypes.Structure):
         ("F", ctypes.c_int32),
         ("reserved", ctypes.c_int32),
         ("ray_dir", ctypes.c_double * 3),
+        ("pair_counters", ctypes.c_void_p),
     ]
 
 

@@ -53,7 +53,17 @@ struct MeshArgs {
     const int* rec_of_face;
     int F;
     double ray_dir[3];
+    unsigned long long* pairs;  // NULL, or two counters: exact closest-point tests | exact ray tests executed (pvamd_mesh_t::pair_counters)
 };
+// one global atomic per batch of exact tests, behind a wave-uniform test of a kernel argument: nothing when the caller did
+// not ask (the benchmark asks in ONE untimed call, to price the work actually done against the fp32 peak: SURVEY.md 8(d))
+#define PVAMD_COUNT_PAIRS(m, which, n)                                                                                  \
+    do {                                                                                                                \
+        if ((m).pairs) {                                                                                                \
+            const unsigned long long count_ = (unsigned long long)(n); /* wave-uniform; evaluated by every active lane */ \
+            if ((int)(threadIdx.x & 63) == __builtin_ctzll(__ballot(true))) atomicAdd((m).pairs + (which), count_);     \
+        }                                                                                                               \
+    } while (0)
 
 // ---------------------------------------------------------------------------------------------------------------
 // prepare (double precision throughout; every stored bound is rounded outwards)
@@ -413,6 +423,7 @@ PVAMD_DEV void drain_closest(const MeshArgs& m, GroupShared<WITH_RAY>& g, WaveLo
     const int lane = threadIdx.x & 63;
     TIC(t_drain);
     drain(wl.qc, wv.nc, everything, [&](int count, const unsigned* q) {
+        PVAMD_COUNT_PAIRS(m, 0, count);
         const unsigned e = lane < count ? q[lane] : 0u;
         const int owner = e & 63;
         const V3 p = v3(__shfl(wv.s.p.x, owner, 64), __shfl(wv.s.p.y, owner, 64), __shfl(wv.s.p.z, owner, 64));
@@ -433,6 +444,7 @@ PVAMD_DEV void drain_rays(const MeshArgs& m, GroupShared<WITH_RAY>& g, WaveLocal
     if (wv.nr == 0) return;
     const int lane = threadIdx.x & 63;
     drain(wl.qr, wv.nr, everything, [&](int count, const unsigned* q) {
+        PVAMD_COUNT_PAIRS(m, 1, count);
         const unsigned e = lane < count ? q[lane] : 0u;
         const int owner = e & 63;
         const V3 p = v3(__shfl(wv.s.p.x, owner, 64), __shfl(wv.s.p.y, owner, 64), __shfl(wv.s.p.z, owner, 64));
@@ -623,6 +635,7 @@ PVAMD_DEV void greedy_reach(const MeshArgs& m, GroupShared<WITH_RAY>& g, Wave<WI
     // ... and the exact distance to that record's triangle, all 64 lanes at once (what a drain does for 64 queued pairs):
     // the bound drops from "the far side of the nearest record's sphere" to a real distance before anything is queued
     // against it, and the pair is a candidate like any other (same operations as in the drain: same bits).
+    PVAMD_COUNT_PAIRS(m, 0, __popcll(__ballot(jn >= 0 && wv.live)));
     if (jn >= 0 && wv.live) {
         const f32x4 A = record_plane(m.rec, jn, kPlaneA), B = record_plane(m.rec, jn, kPlaneB), C = record_plane(m.rec, jn, kPlaneC);
         const V3 qp = sub(closest_point_triangle(p, xyz(A), xyz(B), xyz(C)), p);
@@ -1076,6 +1089,7 @@ PVAMD_DEV float greedy_bound(const MeshArgs& m, V3 p, unsigned long long& found)
     }
     bound = fminf(bound, nearest);
 #ifndef PVAMD_MESH_NO_GREEDY_EXACT
+    PVAMD_COUNT_PAIRS(m, 0, __popcll(__ballot(jn >= 0 && fabsf(p.x) < INFINITY && fabsf(p.y) < INFINITY && fabsf(p.z) < INFINITY)));
     if (jn >= 0 && fabsf(p.x) < INFINITY && fabsf(p.y) < INFINITY && fabsf(p.z) < INFINITY) {
         const f32x4 A = record_plane(m.rec, jn, kPlaneA), B = record_plane(m.rec, jn, kPlaneB), C = record_plane(m.rec, jn, kPlaneC);
         const V3 qp = sub(closest_point_triangle(p, xyz(A), xyz(B), xyz(C)), p);
@@ -1399,6 +1413,7 @@ static MeshArgs mesh_args(const pvamd_mesh_t& mesh) {
     m.rec_of_face = mesh.rec_of_face;
     m.F = mesh.F;
     for (int d = 0; d < 3; ++d) m.ray_dir[d] = mesh.ray_dir[d];
+    m.pairs = reinterpret_cast<unsigned long long*>(mesh.pair_counters);
     return m;
 }
 

@@ -153,6 +153,19 @@ class ObjectFactory(abc.ABC):
         self._mesh_desc_cache = desc
         return desc
 
+    def count_exact_pairs(self, enable=True):
+        """Measurement hook (pvamd_mesh_t.pair_counters): while enabled, every mesh query / chamfer / cache build over this
+        object adds the exact point-triangle tests it executes to a device tensor of two int64 counters (closest-point tests,
+        ray tests), which is returned (zeroed).  `enable=False` detaches it.  Results are unaffected."""
+        desc = self._mesh_desc()
+        if not enable:
+            desc.pair_counters = None
+            self._pair_counters = None
+            return None
+        self._pair_counters = torch.zeros((2,), dtype=torch.int64, device=self._rec_dev.device)
+        desc.pair_counters = self._pair_counters.data_ptr()
+        return self._pair_counters
+
     def sample_surface(self, n, seed):
         """n area-uniform surface points (float64, on the GPU), the index of the prepared triangle each came from and a
         random key per sample; the draw of sample_mesh_points (sdf.py:643-650)."""

@@ -66,19 +66,21 @@ def test_under_torchrun_the_given_world_is_used():
 def fat_record(world=8):
     """A long record with every optional block present and 17-digit floats everywhere (no GPU needed)."""
     x = 0.123456789012345678
-    roof = {"bound": "valu", "achieved": 556.59 + x, "peak": 977.33 + x, "unit": "G wave64 VALU inst/s", "frac": x, "frac_this_run": x}
+    roof = {"bound": "valu", "achieved": 556.59 + x, "peak": 977.33 + x, "unit": "G wave64 VALU inst/s", "frac": x, "frac_this_run": x,
+            "util_valu": x}
     check = {"ranks": world, "ranks_expected": world, "backend": "nccl", "bytes_received_per_rank_expected": 734003200,
              "bytes_match": True, "kernel_only_ms": x, "gathered_ms": 10 * x, "ok": True}
     gathered = {"gather": True, "value": 1e10 + x, "ms_per_step": x, "self_check": check, "bytes_received_per_rank": 734003200,
                 "equals_unsharded_call": True, "collective": "packed (val, grad) records, all_gather_into_tensor x1 (nccl), unpack kernel"}
-    c4 = {"scaling": "strong", "sharded": {"gather": False, "value": 7.7e10 + x, "ms_per_step": x, "roofline": roof,
+    c4 = {"scaling": "strong", "sharded": {"gather": False, "value": 7.7e10 + x, "ms_per_step": x, "roofline": roof, "frac_8d": x,
                                            "prepared_sorted_ms": x, "prepared_caller_ms": x},
           "gathered": gathered, "gathered_by_configs": {"ms_per_step": x}}
-    legs = {"c3": {"value": 4.9e10 + x, "ms_per_step": x, "roofline": roof}, "c4": c4, "c4_readme_grid": c4,
-            "c5": {"value": 7e8 + x, "ms_per_step": x, "roofline": roof, "rel_err_vs_analytic": x * 1e-3,
-                   "collective": "all_reduce of B=1 float64 sums + count (nccl)"},
-            "cache_build": {"builds": {k: {"ms": x, "value": 1e9 + x, "roofline": roof} for k in ("drill_0.01", "drill_0.002", "wrench_0.001")}},
-            "c1": {"value": 1.2e8 + x, "ms_per_step": x, "roofline": roof},
+    legs = {"c3": {"value": 4.9e10 + x, "ms_per_step": x, "roofline": roof, "frac_8d": x}, "c4": c4, "c4_readme_grid": c4,
+            "c5": {"value": 7e8 + x, "ms_per_step": x, "roofline": roof, "rel_err_vs_analytic": x * 1e-3, "frac_8d": x,
+                   "exact_pairs_per_step": 25165824, "collective": "all_reduce of B=1 float64 sums + count (nccl)"},
+            "cache_build": {"builds": {k: {"ms": x, "gpu_ms": x, "value": 1e9 + x, "roofline": roof, "frac_8d": x, "exact_pairs": 36587376}
+                                       for k in ("drill_0.01", "drill_0.002", "wrench_0.001")}},
+            "c1": {"value": 1.2e8 + x, "ms_per_step": x, "roofline": roof, "frac_8d": x, "exact_pairs_per_step": 250000},
             "readme_a20": {"ms_per_call": x, "configure_plus_query_graph_ms": x, "published_ms": 37.688577},
             "readme_a200": {"error": "RuntimeError(" + "y" * 500 + ")", "ranks_without_a_result": 3}}
     batch = {"ms_per_launch": x, "kernel_ms_median": x, "frac_of_8TBs": x}
@@ -90,8 +92,8 @@ def fat_record(world=8):
                        "launch": "one hipGraph of the K steps"},
             "roofline": {"bound": "hbm", "achieved": 4690.0 + x, "peak": 8000.0, "unit": "GB/s", "frac": x, "traffic": 35736551.39 + x,
                          "algorithmic_bytes_per_launch": 29360128, "kernel": "pvamd::cached_query_wave", "launch_us": 6 + x,
-                         "launch_source": "profiles/r05_kernel_stats.json", "frac_rocprof": x, "frac_events": x, "launch_us_events": x,
-                         "frac_of_wall_ms_per_step": x, "events": "z" * 110},
+                         "launch_source": "hip events (this run)", "frac_rocprof": x, "frac_events": x, "launch_us_events": x,
+                         "frac_wall": x, "events": "z" * 110},
             "cpu_baseline": {"value": 8.5e6 + x, "unit": "queries/s", "cores": 128, "kind": "port", "host_cpus": 256,
                              "sample": "median of 3 samples of whole passes over the same 1048576 points, 1.9 s wall",
                              "baseline_opforop": 8.5e6 + x, "baseline_fused": 3.1e8 + x, "fused_port": {"value": 3.1e8 + x, "cores": 128}},
@@ -115,7 +117,12 @@ def test_contract_line_stays_under_the_drivers_tail():
     assert line["roofline"]["frac"] == 0.12346 and "events" not in line["roofline"]
     assert line["legs"]["c4"]["gathered"] == {"ranks": 8, "backend": "nccl", "bytes_received_per_rank": 734003200,
                                               "kernel_only_ms": 0.12346, "gathered_ms": 1.2346, "equals_unsharded_call": True, "ok": True}
-    assert len(line["legs"]["readme_a200"]["error"]) <= 80 and line["legs"]["cache_build"]["wrench_0.001"]["roofline_frac"] == 0.12346
+    assert len(line["legs"]["readme_a200"]["error"]) <= 80 and line["legs"]["cache_build"]["wrench_0.001"]["frac_8d"] == 0.12346
+    # every leg carries the SURVEY 8(d) fraction of THIS run next to the utilisation figure; nothing in the line names a profiles/ file
+    for leg in ("c1", "c3", "c5"):
+        assert line["legs"][leg]["frac_8d"] == 0.12346 and line["legs"][leg]["util_valu"] == 0.12346
+    assert line["legs"]["c4"]["frac_8d"] == 0.12346 and "profiles/" not in text
+    assert line["scaling_table"] == [{"n": 8, "value": 150000000000.0, "frac_hbm": 0.12346, "c4_kernel_only_ms": 0.12346, "c4_gathered_ms": 0.12346}]
     # and a record so large that it cannot fit sheds whole optional blocks instead of growing
     big = fat_record()
     big["legs"] = {f"leg{i}": big["legs"]["c4"] for i in range(40)}
@@ -208,10 +215,12 @@ def test_single_rank_line_has_the_contract_fields():
         assert key in line["config"], key
     roof = line["roofline"]
     for key in ("bound", "achieved", "peak", "unit", "frac", "traffic", "algorithmic_bytes_per_launch", "kernel", "launch_us",
-                "launch_source", "frac_events", "launch_us_events"):
+                "launch_source", "frac_wall"):
         assert key in roof, key
     assert roof["bound"] == "hbm" and roof["unit"] == "GB/s" and abs(roof["frac"] - roof["achieved"] / roof["peak"]) < 1e-4
-    assert roof["frac"] <= 1.0 and roof["frac_events"] <= 1.0
+    assert roof["frac"] <= 1.0 and roof["frac_wall"] <= roof["frac"] * 1.02 and roof["launch_source"] == "hip events (this run)"
+    assert detail["roofline"]["timed_regions_ms"]["n"] >= 15
+    assert line["scaling_table"][0]["n"] == 1 and line["scaling_table"][0]["value"] == line["value"]
     assert abs(roof["achieved"] - roof["algorithmic_bytes_per_launch"] / roof["launch_us"] / 1e3) < 1e-3 * roof["achieved"]
     long_roof = detail["roofline"]
     assert long_roof["dropin_call"]["ms_per_call"] > 0 and long_roof["dropin_call"]["queries_per_s"] > 1e9
