@@ -359,6 +359,19 @@ int pvamd_mesh_query(const pvamd_mesh_t* mesh, const float* points, const int32_
                      uint64_t jitter_seed, int64_t index_base, float* out_closest, float* out_dist, float* out_grad, int32_t* out_face,
                      float* out_normal, void* scratch, void* stream);
 
+/* CachedSDF construction from a mesh on the device (sdf.py:498-516: the ground-truth SDF over every voxel centre of the grid
+ * voxel.py:20-25 builds, then the two arrays the reference keeps), in at most three launches for a small grid: the voxel
+ * centres (cartesian product of the three coordinate arrays, x slowest) and a processing order that walks them in 4 x 4 x 4
+ * bricks are written by one kernel -- no sort --, then pvamd_mesh_query's launches, whose last one writes the packed
+ * (val, gx, gy, gz) record of voxel i = (x * ny + y) * nz + z straight into the cache.  Same bits as pvamd_mesh_query over the
+ * same centres followed by pvamd_pack_grid (results do not depend on the processing order; the sign jitter is indexed by i).
+ * cx / cy / cz: device [nx] / [ny] / [nz] float32.  out_packed: device [nx*ny*nz][4], 16-byte aligned.
+ * points_scratch: device [nx*ny*nz][3] float32.  order_scratch: device [nx*ny*nz] int32.
+ * scratch: device, PVAMD_MESH_SCRATCH_BYTES(nx*ny*nz) bytes, 8-byte aligned, or NULL.                                    */
+int pvamd_cache_build(const pvamd_mesh_t* mesh, const float* cx, const float* cy, const float* cz, int32_t nx, int32_t ny,
+                      int32_t nz, uint64_t jitter_seed, float* out_packed, float* points_scratch, int32_t* order_scratch,
+                      void* scratch, void* stream);
+
 /* The same query for at most PVAMD_MESH_SMALL_POINTS points that come without a processing order: the order is worked out
  * inside (into order_scratch: device [P] int32, contents on return = the order used), by one workgroup of a launch whose
  * other workgroups already do the per-point work that does not need it -- a separate pvamd_morton_order call in front of

@@ -172,6 +172,9 @@ SIGNATURES = {
                                                   ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
                                                   ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
                                                   ctypes.c_void_p]),
+    "pvamd_cache_build": (ctypes.c_int, [ctypes.POINTER(MeshDesc), ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int32,
+                                         ctypes.c_int32, ctypes.c_int32, ctypes.c_uint64, ctypes.c_void_p, ctypes.c_void_p,
+                                         ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]),
     "pvamd_sample_surface": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int32, ctypes.c_int64, ctypes.c_uint64,
                                             ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]),
     "pvamd_chamfer_mesh": (ctypes.c_int, [ctypes.POINTER(MeshDesc), ctypes.c_void_p, ctypes.c_int32, ctypes.c_void_p,

@@ -937,6 +937,7 @@ struct QueryOut {
     float* grad;
     int* face;
     float* normal;
+    float* packed;  // NULL, or [P][4] (dist, gx, gy, gz) records instead of dist / grad (pvamd_cache_build: the voxel cache itself)
 };
 
 // the index (caller order) of the point at position `k` of the processing order
@@ -963,10 +964,14 @@ PVAMD_DEV void write_query(const MeshArgs& m, const QueryOut& out, int64_t i, V3
         out.closest[3 * i + 1] = q.y;
         out.closest[3 * i + 2] = q.z;
     }
-    out.dist[i] = d;
-    out.grad[3 * i] = g.x;
-    out.grad[3 * i + 1] = g.y;
-    out.grad[3 * i + 2] = g.z;
+    if (out.packed) {
+        reinterpret_cast<f32x4*>(out.packed)[i] = f32x4{d, g.x, g.y, g.z};
+    } else {
+        out.dist[i] = d;
+        out.grad[3 * i] = g.x;
+        out.grad[3 * i + 1] = g.y;
+        out.grad[3 * i + 2] = g.z;
+    }
     if (out.face) out.face[i] = f;
     if (out.normal) {                            // :169-171
         out.normal[3 * i] = f >= 0 ? m.normal[3 * f] : NAN;
@@ -1436,6 +1441,30 @@ constexpr int kMinParts = PVAMD_MESH_MIN_PARTS;     // fewer parts than this (a 
 //                            can be handed over (C5, 389 tiles: 5.2 ms with 8, 11.5 with 2); when the heavy groups go
 //                            to a launch of their own the tail is gone and the count of groups decides as above (C5:
 //                            3.17 ms with 2, 3.55 with 4).
+// Voxel centres of a regular grid (the cartesian product of three coordinate arrays, x slowest: voxel.py:20-25) and a
+// processing order for them in ONE launch: thread i writes centre i (caller order = the cache's C order) and its position in an
+// order that walks the grid in 4 x 4 x 4 bricks (clipped at the far faces), bricks in C order, voxels in C order inside a brick
+// -- so that a run of 64 consecutive positions is a cube of 64 neighbouring centres, the most compact group the mesh kernels can
+// be given, with no sort: the position of a voxel follows from its coordinates in closed form.
+__global__ __launch_bounds__(256) void grid_points_kernel(const float* __restrict__ cx, const float* __restrict__ cy,
+                                                          const float* __restrict__ cz, int nx, int ny, int nz,
+                                                          float* __restrict__ pts, int* __restrict__ order) {
+    const int64_t n = (int64_t)nx * ny * nz;
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int z = (int)(i % nz), y = (int)((i / nz) % ny), x = (int)(i / ((int64_t)nz * ny));
+    pts[3 * i] = cx[x];
+    pts[3 * i + 1] = cy[y];
+    pts[3 * i + 2] = cz[z];
+    const int bx = x >> 2, by = y >> 2, bz = z >> 2;
+    const int wx = min(4, nx - 4 * bx), wy = min(4, ny - 4 * by), wz = min(4, nz - 4 * bz);
+    // voxels in the brick slabs before this one (all four thick), in the brick rows before this one inside the slab, in the
+    // bricks before this one inside the row, and before this voxel inside the brick
+    const int64_t j = (int64_t)(4 * bx) * ny * nz + (int64_t)wx * (4 * by) * nz + (int64_t)wx * wy * (4 * bz) +
+                      ((int64_t)((x & 3) * wy + (y & 3)) * wz + (z & 3));
+    order[j] = (int)i;
+}
+
 static int pick_slices(int64_t groups, int mesh_tiles, bool hand_over) {
     int s = 2;
     while (s < 8 && (int64_t)s * groups < 16384) s <<= 1;
@@ -1512,10 +1541,10 @@ static void launch_heavy_parts(const MeshArgs& m, const int* order, const float*
 // sort_into != nullptr: the caller brings no order; one is worked out into sort_into (P <= kSmallPoints)
 static int mesh_query_impl(const pvamd_mesh_t* mesh, const float* points, const int32_t* order, int32_t* sort_into, int64_t P,
                            uint64_t jitter_seed, int64_t index_base, float* out_closest, float* out_dist, float* out_grad,
-                           int32_t* out_face, float* out_normal, void* scratch, void* stream) {
+                           int32_t* out_face, float* out_normal, void* scratch, void* stream, float* out_packed = nullptr) {
     if (P < 0) return PVAMD_E_SHAPE;
     if (P == 0) return 0;
-    if (!mesh || !out_dist || !out_grad) return PVAMD_E_NULL;
+    if (!mesh || (!out_packed && (!out_dist || !out_grad))) return PVAMD_E_NULL;
     if (mesh->F < 0) return PVAMD_E_SHAPE;
     if (!points || (mesh->F > 0 && (!mesh->rec || !mesh->tiles || !mesh->normal || !mesh->rec_of_face))) return PVAMD_E_NULL;
     if (scratch && !aligned_to(scratch, 8)) return PVAMD_E_ALIGN;
@@ -1524,7 +1553,7 @@ static int mesh_query_impl(const pvamd_mesh_t* mesh, const float* points, const 
     const int64_t groups = (P + 63) / 64;
     if (groups > 0x7fffffff) return PVAMD_E_SHAPE;
     hipStream_t s = (hipStream_t)stream;
-    const QueryOut out{out_closest, out_dist, out_grad, out_face, out_normal};
+    const QueryOut out{out_closest, out_dist, out_grad, out_face, out_normal, out_packed};
     const int ntiles = (mesh->F + kTile - 1) / kTile;
     
     const int cap = (int)PVAMD_MESH_SCRATCH_SLOTS(P);  // what PVAMD_MESH_SCRATCH_BYTES(P) holds
@@ -1602,6 +1631,19 @@ extern "C" int pvamd_mesh_query_unordered(const pvamd_mesh_t* mesh, const float*
     if (P > 0 && !order_scratch) return PVAMD_E_NULL;
     return mesh_query_impl(mesh, points, nullptr, order_scratch, P, jitter_seed, index_base, out_closest, out_dist, out_grad,
                            out_face, out_normal, scratch, stream);
+}
+
+extern "C" int pvamd_cache_build(const pvamd_mesh_t* mesh, const float* cx, const float* cy, const float* cz, int32_t nx, int32_t ny,
+                                 int32_t nz, uint64_t jitter_seed, float* out_packed, float* points_scratch, int32_t* order_scratch,
+                                 void* scratch, void* stream) {
+    if (nx < 1 || ny < 1 || nz < 1 || (int64_t)nx * ny * nz > (int64_t)INT32_MAX) return PVAMD_E_SHAPE;
+    if (!mesh || !cx || !cy || !cz || !out_packed || !points_scratch || !order_scratch) return PVAMD_E_NULL;
+    if (!aligned_to(out_packed, 16)) return PVAMD_E_ALIGN;
+    const int64_t n = (int64_t)nx * ny * nz;
+    hipLaunchKernelGGL(grid_points_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, cx, cy, cz, nx, ny, nz,
+                       points_scratch, order_scratch);
+    return mesh_query_impl(mesh, points_scratch, order_scratch, nullptr, n, jitter_seed, 0, nullptr, nullptr, nullptr, nullptr, nullptr,
+                           scratch, stream, out_packed);
 }
 
 // W != nullptr: B transforms x N points, grid (groups, B).  W == nullptr: the flat call -- N = B * per transformed points.

@@ -406,7 +406,7 @@ class CachedSDF(ObjectFrameSDF):
         self.ranges = range_per_dim
         self.name = f"{object_name} {resolution} {tuple(range_per_dim)}"
 
-        val, grad = None, None
+        val, grad, built = None, None, None
         data = {}
         if cache_path is not None and os.path.exists(cache_path):
             data = torch.load(cache_path, weights_only=False) or {}
@@ -423,12 +423,18 @@ class CachedSDF(ObjectFrameSDF):
             # product is formed on the GPU so that a 10^7-voxel grid never exists in host memory
             coords, _ = get_coordinates_and_points_in_grid(self.resolution, self.ranges, get_points=False)
             dev_q = _lib.require_gpu()
-            pts = torch.cartesian_prod(*[c.to(dev_q) for c in coords])
-            sdf_val, sdf_grad = gt_sdf(pts)  # with a MeshSDF this is the mesh kernel over every voxel centre
-            val = sdf_val.reshape([len(coord) for coord in coords])
-            grad = sdf_grad.reshape(-1, len(coords))  # (N, d): what the reference stores and pickles (sdf.py:505, squeeze(0))
+            built = self._build_from_mesh(gt_sdf, coords, dev_q)
+            if built is not None:
+                # a plain MeshSDF: centres, processing order, mesh kernel and packing in <= 3 launches (pvamd_cache_build);
+                # `val` / `grad` are views of the packed records -- what the reference stores and pickles
+                val, grad = built[:, 0].reshape([len(coord) for coord in coords]), built[:, 1:4]
+            else:
+                pts = torch.cartesian_prod(*[c.to(dev_q) for c in coords])
+                sdf_val, sdf_grad = gt_sdf(pts)  # any other ground truth: asked at every voxel centre
+                val = sdf_val.reshape([len(coord) for coord in coords])
+                grad = sdf_grad.reshape(-1, len(coords))  # (N, d): what the reference stores and pickles (sdf.py:505, squeeze(0))
             if cache_path is not None:
-                data[self.name] = val.cpu(), grad.cpu()
+                data[self.name] = val.contiguous().cpu(), grad.contiguous().cpu()  # (views of the packed records after a fused build)
                 torch.save(data, cache_path)
                 logger.info("caching sdf for %s to %s", self.name, cache_path)
 
@@ -449,12 +455,15 @@ class CachedSDF(ObjectFrameSDF):
         self._view = RangeView(view_ranges, val.shape)
         dev = _lib.require_gpu()
         lib = _lib.load()
-        val_d = val.to(device=dev, dtype=torch.float32).contiguous().reshape(-1)
-        grad_d = grad.to(device=dev, dtype=torch.float32).contiguous().reshape(-1, 3)
-        self._packed = torch.empty((val_d.shape[0], 4), dtype=torch.float32, device=dev)
-        with _lib.on_device(dev):
-            _lib.check(lib.pvamd_pack_grid(_lib.ptr(val_d), _lib.ptr(grad_d), val_d.shape[0], _lib.ptr(self._packed),
-                                           _lib.stream_ptr()), "pvamd_pack_grid")
+        if built is not None and self._dim == 3 and built.device == dev:
+            self._packed = built  # the mesh kernel wrote the records themselves
+        else:
+            val_d = val.to(device=dev, dtype=torch.float32).contiguous().reshape(-1)
+            grad_d = grad.to(device=dev, dtype=torch.float32).contiguous().reshape(-1, 3)
+            self._packed = torch.empty((val_d.shape[0], 4), dtype=torch.float32, device=dev)
+            with _lib.on_device(dev):
+                _lib.check(lib.pvamd_pack_grid(_lib.ptr(val_d), _lib.ptr(grad_d), val_d.shape[0], _lib.ptr(self._packed),
+                                               _lib.stream_ptr()), "pvamd_pack_grid")
         self.voxels = VoxelView(self)
         self.voxels_grad = self._packed[:, 1:]
         self.bb = self.surface_bounding_box().to(device=dev)
@@ -467,6 +476,35 @@ class CachedSDF(ObjectFrameSDF):
             ok = self.voxels.get_valid_values(pts).to(q.device)  # fp32 boundary centres can round outside a f64 range
             centre_val = val[..., 0] if self._dim == 2 else val
             assert torch.allclose(centre_val.reshape(-1).to(q.device, q.dtype)[ok], q[ok])  # voxel centres map to themselves
+
+    @staticmethod
+    def _build_from_mesh(gt_sdf, coords, dev):
+        """The cache of a plain MeshSDF in at most three launches (pvamd_cache_build; sdf.py:498-516 on the device): packed
+        (n, 4) records on `dev`, or None when the ground truth is anything else (a subclass, a planar grid, a mesh elsewhere)."""
+        if type(gt_sdf) is not MeshSDF or len(coords) != 3 or not isinstance(gt_sdf.obj_factory, ObjectFactory):
+            return None
+        obj = gt_sdf.obj_factory
+        shape = [len(c) for c in coords]
+        n = shape[0] * shape[1] * shape[2]
+        if n == 0 or n > 2 ** 31 - 1:
+            return None
+        lib = _lib.load()
+        with _lib.on_device(dev):
+            desc = obj._mesh_desc()
+            if obj._rec_dev.device != dev:
+                return None
+            # one host -> device copy for the three coordinate arrays (fp32, exactly as voxel.py:20-25 builds them)
+            allc = torch.cat([c.to(torch.float32) for c in coords]).to(dev)
+            cx, cy, cz = allc[:shape[0]], allc[shape[0]:shape[0] + shape[1]], allc[shape[0] + shape[1]:]
+            packed = torch.empty((n, 4), dtype=torch.float32, device=dev)
+            pts = torch.empty((n, 3), dtype=torch.float32, device=dev)
+            order = torch.empty((n,), dtype=torch.int32, device=dev)
+            scratch = torch.empty((_lib.mesh_scratch_bytes(n) // 8,), dtype=torch.int64, device=dev) \
+                if getattr(obj, "tile_split", True) else None
+            _lib.check(lib.pvamd_cache_build(ctypes.byref(desc), _lib.ptr(cx), _lib.ptr(cy), _lib.ptr(cz), shape[0], shape[1], shape[2],
+                                             ctypes.c_uint64(obj.jitter_seed), _lib.ptr(packed), _lib.ptr(pts), _lib.ptr(order),
+                                             _lib.ptr(scratch), _lib.stream_ptr()), "pvamd_cache_build")
+        return packed
 
     _PLAN_ATTRS = frozenset(("device", "out_of_bounds_strategy", "debug_check_sdf", "_packed", "bb"))
 

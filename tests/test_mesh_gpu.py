@@ -333,3 +333,35 @@ def test_points_aabb_ignores_non_finite_coordinates():
     assert np.array_equal(box.cpu().numpy(), np.stack((np.nanmin(fin, axis=0), np.nanmax(fin, axis=0))))
     _lib.check(lib.pvamd_points_aabb(None, 0, _lib.ptr(box), _lib.stream_ptr()), "aabb empty")
     assert np.array_equal(box.cpu().numpy(), np.array([[np.inf] * 3, [-np.inf] * 3], dtype=np.float32))
+
+
+class _ViaGenericPath(pv.MeshSDF):
+    """A MeshSDF that CachedSDF does not recognise as one: the cache is then built through gt_sdf(points) + pvamd_pack_grid."""
+
+
+@pytest.mark.parametrize("mesh,res,pad", [("ycb_power_drill.npz", 0.01, 0.1), ("ycb_power_drill.npz", 0.02, 0.013),
+                                          ("box_template.obj", 0.25, 0.3), ("offset_wrench_nogrip.obj", 0.004, 0.05)])
+def test_fused_cache_build_writes_the_bits_of_the_generic_build(mesh, res, pad, tmp_path):
+    """Round 6: pvamd_cache_build -- voxel centres + a 4 x 4 x 4-brick processing order in one launch, the
+    mesh kernel writing packed records -- against the generic construction (cartesian_prod, Hilbert sort, mesh query, pack):
+    the same cache, bit for bit, for grids whose sides are and are not multiples of 4; and the reference-format pickle."""
+    obj = factory(mesh)
+    rng = obj.bounding_box(padding=pad)
+    path = str(tmp_path / "sdf_cache.pkl")
+    fused = pv.CachedSDF(mesh, res, rng, pv.MeshSDF(obj), device="cuda", cache_path=path)
+    generic = pv.CachedSDF(mesh, res, rng, _ViaGenericPath(obj), device="cuda", cache_path=None)
+    assert fused._packed.shape == generic._packed.shape and fused._view.shape == generic._view.shape
+    assert torch.equal(fused._packed.view(torch.int32), generic._packed.view(torch.int32))
+    val, grad = torch.load(path, weights_only=False)[fused.name]
+    assert val.shape == tuple(fused._view.shape) and grad.shape == (fused._packed.shape[0], 3) and val.is_contiguous()
+    assert torch.equal(val.reshape(-1), generic._packed[:, 0].cpu()) and torch.equal(grad, generic._packed[:, 1:4].cpu())
+    again = pv.CachedSDF(mesh, res, rng, pv.MeshSDF(obj), device="cuda", cache_path=path)  # from the pickle: nothing is rebuilt
+    assert torch.equal(again._packed.view(torch.int32), fused._packed.view(torch.int32))
+    # and a slice of it against the oracle's mesh query at the same global indices
+    _, pts = pv.get_coordinates_and_points_in_grid(res, fused.ranges)
+    n = len(pts)
+    a = n // 3
+    b = min(n, a + 300)
+    oc, od, og, of, on = oracle.mesh_query(H.oracle_mesh_from_factory(obj), pts[a:b].numpy(), seed=obj.jitter_seed, index_base=a)
+    assert np.array_equal(fused._packed[a:b, 0].cpu().numpy(), od, equal_nan=True)
+    assert np.array_equal(fused._packed[a:b, 1:4].cpu().numpy(), og, equal_nan=True)
