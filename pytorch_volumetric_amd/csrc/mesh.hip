@@ -496,7 +496,7 @@ PVAMD_DEV void visit_tile(const MeshArgs& m, GroupShared<WITH_RAY>& g, WaveLocal
 #ifdef PVAMD_MESH_STATS
             if (need && wv.live) mine_groups |= 1u << b;
 #endif
-            if (__any(need && wv.live)) gm |= 1u << b;
+            if (__ballot(need && wv.live) != 0ull) gm |= 1u << b;  // (the ballot IS the compare mask: __any materialises 0 / 1 and compares again)
         }
     }
     const f32x4* P0 = tile_plane(m.rec, ti, kPlaneSphere);
@@ -534,6 +534,7 @@ PVAMD_DEV void visit_tile(const MeshArgs& m, GroupShared<WITH_RAY>& g, WaveLocal
         wl.m0[lane] = am0;
         PVAMD_WAVE_SYNC();
         const int j0 = ti * kTile + pass * 64;
+        const unsigned long long live_mask = __ballot(wv.live);
         TIC(t_surv);
         while (todo != 0ull) {
             const int b = __builtin_ctzll(todo);
@@ -542,26 +543,28 @@ PVAMD_DEV void visit_tile(const MeshArgs& m, GroupShared<WITH_RAY>& g, WaveLocal
             const f32x4 o = wl.sphere[b];  // wave-uniform address: LDS broadcast
             const V3 w = v3(o.x - wv.s.p.x, o.y - wv.s.p.y, o.z - wv.s.p.z);
             const float dist2 = dot(w, w);
-            if ((mc >> b) & 1ull) {
-                const bool near_c = wv.live && sphere_may_improve(wv.s, dist2, o.w);
-                if (__any(near_c)) {
+            // Lane predicates stay LANE MASKS (the compare's own SGPR pair) from the test to the queue: a bool that crosses a
+            // branch is materialised as 0 / 1 in a VGPR and compared again at every use (two vector instructions per survivor
+            // in the sphere stage and two more in the rectangle stage: 11 % of this kernel's vector instructions on C5), and
+            // `a && f(...)` wraps f in an exec-mask save / restore.  The rectangle test runs for every lane; the masks are ANDed.
+            if (!WITH_RAY || ((mc >> b) & 1ull)) {  // (without rays every survivor is a closest-point candidate: todo == mc)
+                const unsigned long long near_c = live_mask & __ballot(sphere_may_improve(wv.s, dist2, o.w));
+                if (near_c != 0ull) {
                     STAT(7, 1);
                     const f32x4 u = wl.fu[b], v = wl.fv[b];
-                    const bool need_c = near_c && rect_may_improve(wv.s, w, dist2, xyz(u), u.w, xyz(v), v.w, wl.m0[b]);
-                    const unsigned long long mk = __ballot(need_c);
+                    const unsigned long long mk = near_c & __ballot(rect_may_improve(wv.s, w, dist2, xyz(u), u.w, xyz(v), v.w, wl.m0[b]));
                     if (mk) {
                         STAT(4, __popcll(mk)); STAT(8, 1);
-                        enqueue(wl.qc, wv.nc, mk, need_c, j0 + b);
+                        enqueue(wl.qc, wv.nc, mk, __builtin_amdgcn_inverse_ballot_w64(mk), j0 + b);
                         if (wv.nc >= 64) drain_closest(m, g, wl, wv, false);
                     }
                 }
             }
             if (WITH_RAY && ((mr >> b) & 1ull)) {
-                const bool need_r = wv.live && sphere_may_hit(dist2, dot(w, wv.dn), o.w);
-                const unsigned long long mk = __ballot(need_r);
+                const unsigned long long mk = live_mask & __ballot(sphere_may_hit(dist2, dot(w, wv.dn), o.w));
                 if (mk) {
                     STAT(5, __popcll(mk)); STAT(8, 1);
-                    enqueue(wl.qr, wv.nr, mk, need_r, j0 + b);
+                    enqueue(wl.qr, wv.nr, mk, __builtin_amdgcn_inverse_ballot_w64(mk), j0 + b);
                     if (wv.nr >= 64) drain_rays(m, g, wl, wv, false);
                 }
             }
@@ -685,7 +688,7 @@ PVAMD_DEV void scan_tiles(const MeshArgs& m, GroupShared<WITH_RAY>& g, WaveLocal
             const float d2 = dot(wl_, wl_);
             bool mine_too = sphere_may_improve(wv.s, d2, r);
             if (WITH_RAY) mine_too = mine_too || sphere_may_hit(d2, dot(wl_, wv.dn), r);
-            if (!__any(mine_too && wv.live)) continue;
+            if (__ballot(mine_too && wv.live) == 0ull) continue;
             visit_tile<WITH_RAY>(m, g, wl, wv, base + t, pass_lo, pass_hi);
         }
     }
@@ -825,7 +828,7 @@ PVAMD_DEV bool part_has_work(const MeshArgs& m, const float* __restrict__ b, int
         const float dist2 = dot(w, w);
         bool need = sphere_may_improve(wb.q, dist2, ts.w);
         if (WITH_RAY) need = need || axis_may_hit(wb, w, dist2, ts.w);
-        if (__any(need && ti < ntiles)) return true;
+        if (__ballot(need && ti < ntiles) != 0ull) return true;
     }
     return false;
 }
@@ -983,8 +986,14 @@ PVAMD_DEV void write_query(const MeshArgs& m, const QueryOut& out, int64_t i, V3
 // grid: x = groups of 64 points
 // waves per SIMD the allocator is held to (it would settle for 6): 8 fit beside the LDS of an 8-wave block (C5 query with
 // sign 7.4 -> 6.2 ms), 7 beside that of the smaller ones (2.16 M-point cache build 1.84 -> 1.73 ms; 8 spill: 1.85)
+#ifndef PVAMD_MESH_MINWAVES
+#define PVAMD_MESH_MINWAVES(SLICES) ((SLICES) == 8 ? 8 : ((SLICES) == 1 ? 6 : 7))
+#endif
+#ifndef PVAMD_CHAMFER_MINWAVES
+#define PVAMD_CHAMFER_MINWAVES(SLICES) 1  /* the allocator's own choice (88 VGPRs, 5 waves): see profiles/r06_mesh_variants.txt */
+#endif
 template <int SLICES>
-__global__ __launch_bounds__(64 * SLICES, SLICES == 8 ? 8 : (SLICES == 1 ? 6 : 7)) void mesh_query_kernel(MeshArgs m, const int* __restrict__ order,
+__global__ __launch_bounds__(64 * SLICES, PVAMD_MESH_MINWAVES(SLICES)) void mesh_query_kernel(MeshArgs m, const int* __restrict__ order,
                                                                 const float* __restrict__ pts, int64_t P,
                                                                 uint64_t seed, int64_t index_base, QueryOut out, HandOver ho) {
     __shared__ __attribute__((aligned(16))) MeshShared<SLICES, true> sh;
@@ -1030,7 +1039,7 @@ PVAMD_DEV void chamfer_accumulate(const MeshArgs& m, V3 p, bool live, unsigned l
 // grid: x = groups of 64 points, y = transform b (b0 = the slab's first transform).  W == nullptr: the flat call (see
 // chamfer_accumulate) -- `pts` are the N = B * per transformed points of all transforms, y = 1.
 template <int SLICES>
-__global__ __launch_bounds__(64 * SLICES) void chamfer_mesh_kernel(MeshArgs m, const int* __restrict__ order,
+__global__ __launch_bounds__(64 * SLICES, PVAMD_CHAMFER_MINWAVES(SLICES)) void chamfer_mesh_kernel(MeshArgs m, const int* __restrict__ order,
                                                                   const float* __restrict__ W, int b0,
                                                                   const float* __restrict__ pts, int64_t N, float scale,
                                                                   double* __restrict__ out_sum, HandOver ho, int64_t per) {
