@@ -218,6 +218,8 @@ int pvamd_voxel_scatter_u8(const pvamd_grid_t* grid, uint8_t* storage, const flo
 #define PVAMD_COMPOSED_FORCE_PER_LANE 2   /* testing / tuning: take the one-point-per-lane kernel whatever the size */
 #define PVAMD_COMPOSED_FORCE_WAVE_TILE 4  /* testing / tuning: take the wave-tile kernel whatever the size                 */
 #define PVAMD_COMPOSED_POINTS_FASTEST 8   /* tuning: per-lane kernel with blocks ordered points-fastest (default: configuration-fastest) */
+#define PVAMD_COMPOSED_NO_GROUPING 64   /* testing / tuning: never the chunk-grouped kernel (the round-5 kernels whatever the size) */
+#define PVAMD_COMPOSED_FORCE_FUSED 128  /* testing / tuning: the chunk-grouped kernel with the in-workgroup sort whenever P >= one chunk */
 #define PVAMD_COMPOSED_OUT_PACKED 32  /* pvamd_composed_query_grouped only: out_val takes [A][P] (val, gx, gy, gz) records (16-byte aligned), out_grad NULL */
 #define PVAMD_COMPOSED_LEGACY_LEAF_LOOP 16 /* testing / tuning: wave-tile kernel with the round-3 leaf loop (lookups and exact roots inside the leaf loop) */
 int pvamd_composed_query(const pvamd_grid_t* grids, int32_t S, const float* tf, int32_t A,

@@ -16,6 +16,8 @@ OOB_LOOKUP_GT_SDF = 0
 OOB_BOUNDING_BOX = 1
 COMPOSED_INLINE_EXACT = 1
 COMPOSED_OUT_PACKED = 32
+COMPOSED_NO_GROUPING = 64
+COMPOSED_FORCE_FUSED = 128
 RULE_VALID_ON_INDEX = 1
 RULE_ROUND_HALF_AWAY = 2
 RULE_ROUND_FLOOR_HALF = 4

@@ -402,9 +402,12 @@ struct GroupIO {
     const uint16_t* __restrict__ perm;  // their positions inside the chunk, caller order
     float* res;                         // the block's result slices, [tile][1024]
     int64_t chunk_first;                // caller index of the chunk's first point
+    const uint16_t* lperm;              // GROUPED == 2 (composed_query_fused): the same positions, in LDS; the points are in `res`
 };
 
-template <int PPP, bool PACKED, bool MASKED, bool GROUPED = false>
+// GROUPED: 0 = the wave's own tile; 1 = a sorted copy + positions in memory (group_points_kernel ran); 2 = the chunk was sorted by
+// this very workgroup: positions in LDS, a point is read from the caller-order slot its result will overwrite
+template <int PPP, bool PACKED, bool MASKED, int GROUPED = 0>
 PVAMD_DEV void tile_passes_split(const pvamd_grid_t* __restrict__ grids, int S, const float* __restrict__ tf, int A, int a,
                                  int64_t first, int64_t P, float* __restrict__ val, int* __restrict__ leaf, float* spf,
                                  int lane, uint64_t todo, float lower, const GroupIO gio = GroupIO{}) {
@@ -415,13 +418,20 @@ PVAMD_DEV void tile_passes_split(const pvamd_grid_t* __restrict__ grids, int S, 
 #pragma unroll
     for (int h = 0; h < 4; h += PPP) {
         float px[PPP], py[PPP], pz[PPP];
+        int slot_of[PPP];  // GROUPED == 2 only
         BestOut best[PPP];
         BestIn bin[PPP];
         uint64_t unsure[PPP];
 #pragma unroll
         for (int k = 0; k < PPP; ++k) {
             const int p = lane + 64 * (h + k);
-            if constexpr (GROUPED) {
+            if constexpr (GROUPED == 2) {
+                slot_of[k] = gio.lperm[p];
+                const float* q = gio.res + (slot_of[k] >> 8) * 1024 + 3 * (slot_of[k] & 255);
+                px[k] = q[0];
+                py[k] = q[1];
+                pz[k] = q[2];
+            } else if constexpr (GROUPED == 1) {
                 px[k] = gio.pts[3 * p];
                 py[k] = gio.pts[3 * p + 1];
                 pz[k] = gio.pts[3 * p + 2];
@@ -549,8 +559,8 @@ PVAMD_DEV void tile_passes_split(const pvamd_grid_t* __restrict__ grids, int S, 
             const float* M = tf + 16 * ((int64_t)s_win * A + a);
             float gx, gy, gz;
             rotate_back(M, fin[k], gx, gy, gz);
-            if constexpr (GROUPED) {
-                const int idx = gio.perm[p];
+            if constexpr (GROUPED != 0) {
+                const int idx = GROUPED == 2 ? slot_of[k] : (int)gio.perm[p];
                 float* slot = gio.res + (idx >> 8) * 1024;
                 const int q = idx & 255;
                 slot[768 + q] = fin[k].v;
@@ -949,6 +959,15 @@ __global__ __launch_bounds__(kUnpermuteWaves * 64) void composed_unpermute_kerne
 #endif
 constexpr int kGroupWaves = PVAMD_GROUP_WAVES;
 constexpr int kGroupChunk = kGroupWaves * kTilePoints;
+#ifndef PVAMD_FUSED_WAVES
+#define PVAMD_FUSED_WAVES 16
+#endif
+constexpr int kFusedWaves = PVAMD_FUSED_WAVES;  // waves (x 256 points) per chunk of the in-workgroup sort
+constexpr int kFusedChunk = kFusedWaves * kTilePoints;
+#ifndef PVAMD_FUSED_MIN_BLOCKS
+#define PVAMD_FUSED_MIN_BLOCKS 1024
+#endif
+constexpr int64_t kFusedMinBlocks = PVAMD_FUSED_MIN_BLOCKS;  // (chunk, configuration) workgroups below which the per-lane / wave-tile kernels keep the call
 static_assert(kGroupChunk <= 65536 && 4096 % (kGroupWaves * 64) == 0, "perm is uint16; the scan splits 4096 bins evenly");
 
 template <int NW>
@@ -1129,9 +1148,9 @@ __global__ __launch_bounds__(NW * 64, PVAMD_GROUP_MINWAVES) void composed_query_
         uint64_t todo = S >= 64 ? ~0ull : ((1ull << S) - 1ull);
         const bool masked = 2.f * rt <= span;  // false for the "no bounds" marker (+inf)
         if (masked) todo = leaf_mask_of_sphere(cull, S, lane, ct, rt, mag, lower);
-        const GroupIO gio{sorted + 3 * run, perm + run, &res[0][0], cfirst};
-        if (masked) tile_passes_split<PPP, false, true, true>(grids, S, tf, A, a, 0, P, val, leaf, nullptr, lane, todo, lower, gio);
-        else tile_passes_split<PPP, false, false, true>(grids, S, tf, A, a, 0, P, val, leaf, nullptr, lane, todo, lower, gio);
+        const GroupIO gio{sorted + 3 * run, perm + run, &res[0][0], cfirst, nullptr};
+        if (masked) tile_passes_split<PPP, false, true, 1>(grids, S, tf, A, a, 0, P, val, leaf, nullptr, lane, todo, lower, gio);
+        else tile_passes_split<PPP, false, false, 1>(grids, S, tf, A, a, 0, P, val, leaf, nullptr, lane, todo, lower, gio);
         __syncthreads();  // every result of the chunk is in its caller-order slot
         const f32x4_alias* sp = reinterpret_cast<const f32x4_alias*>(res[wave]);
         const int64_t o = (int64_t)a * P + cfirst + wave * kTilePoints;
@@ -1152,6 +1171,128 @@ __global__ __launch_bounds__(NW * 64, PVAMD_GROUP_MINWAVES) void composed_query_
             __builtin_nontemporal_store(sp[lane + 64], dst + lane + 64);
             __builtin_nontemporal_store(sp[lane + 128], dst + lane + 128);
         }
+        __syncthreads();  // the slices are free for the next chunk
+    }
+}
+
+
+// ---- the same regrouping with NO pre-pass and no scratch: the workgroup sorts its chunk itself ----
+// A single configuration (C3: 8 drills, 4M points) cannot amortise group_points_kernel's extra pass over the points (48 MB read,
+// 56 MB written, 56 MB read again against 112 MB of compulsory traffic), and a caller of pvamd_composed_query brings no scratch.
+// Here the chunk's points are loaded once into the LDS slices their results will leave from, sorted in place (Hilbert cell keys
+// over the chunk's box, counting sort: the count table borrows the value quarter of the slices, which nothing touches until
+// results arrive), and a wave then reads the points of its run through the position table.  ~250 instructions and six barriers
+// per thread against ~1500 of leaf loop (S = 8): worth it wherever the wave-tile kernel ran on scattered points.
+template <int NW, int PPP>
+__global__ __launch_bounds__(NW * 64, PVAMD_GROUP_MINWAVES) void composed_query_fused(
+    const pvamd_grid_t* __restrict__ grids, int S, const float* __restrict__ tf, int A, const float* __restrict__ pts, int64_t nchunks,
+    int64_t P, float* __restrict__ val, float* __restrict__ grad, int* __restrict__ leaf, int a0) {
+    // one count per Hilbert cell of the 16^3 grid, or per run of 2 / 4 consecutive cells of the curve when the chunk has fewer value
+    // slots than cells (the table lives in the value quarters of the slices)
+    constexpr int N = NW * kTilePoints, kBins = N < 4096 ? N : 4096, kPerThread = kBins / (NW * 64), kKeyShift = kBins == 4096 ? 0 : (kBins == 2048 ? 1 : 2);
+    static_assert(kBins >= 1024 && kBins % (NW * 64) == 0, "4, 8 or 16 waves");
+    __shared__ __attribute__((aligned(16))) float res[NW][1024];
+    __shared__ uint16_t sperm[N];
+    __shared__ unsigned box[6];
+    __shared__ unsigned wsum[NW];
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int a = a0 + blockIdx.x;
+    auto hist = [&](int bin) -> unsigned& { return reinterpret_cast<unsigned*>(res[bin >> 8])[768 + (bin & 255)]; };
+    // (The cells span the chunk's own box.  Cells over the SCENE instead -- the cube that holds every leaf's range, known from the
+    // culling spheres without a reduction or a barrier -- were tried: C4 with the sort per configuration 0.651 -> 0.615 ms, but C3
+    // 0.076 -> 0.088 ms, no better than unsorted: 16 cells per axis spread over empty space leave runs of 64 points long and thin.
+    // The Z curve in place of the Hilbert table: slower on both.  profiles/r06_composed_variants.txt.)
+    for (int64_t chunk = blockIdx.y; chunk < nchunks; chunk += gridDim.y) {
+        const int64_t cfirst = chunk * N <= P - N ? chunk * N : P - N;
+        f32x4_alias* sp = reinterpret_cast<f32x4_alias*>(res[wave]);
+        {
+            const f32x4_u* src = reinterpret_cast<const f32x4_u*>(pts + 3 * (cfirst + wave * kTilePoints));
+            sp[lane] = src[lane];
+            sp[lane + 64] = src[lane + 64];
+            sp[lane + 128] = src[lane + 128];
+        }
+        for (int i = threadIdx.x; i < kBins; i += NW * 64) hist(i) = 0u;
+        if (threadIdx.x < 3) {
+            box[threadIdx.x] = 0xffffffffu;
+            box[3 + threadIdx.x] = 0u;
+        }
+        PVAMD_WAVE_SYNC();
+        const f32x4 q0 = sp[3 * lane], q1 = sp[3 * lane + 1], q2 = sp[3 * lane + 2];
+        const float px[4] = {q0.x, q0.w, q1.z, q2.y}, py[4] = {q0.y, q1.x, q1.w, q2.z}, pz[4] = {q0.z, q1.y, q2.x, q2.w};
+        float lo[3], hi[3];
+#pragma unroll
+        for (int d = 0; d < 3; ++d) {
+            lo[d] = __builtin_inff();
+            hi[d] = -__builtin_inff();
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const float c[3] = {px[k], py[k], pz[k]};
+#pragma unroll
+            for (int d = 0; d < 3; ++d) {
+                const bool fin = fabsf(c[d]) < __builtin_inff();
+                lo[d] = fin ? fminf(lo[d], c[d]) : lo[d];
+                hi[d] = fin ? fmaxf(hi[d], c[d]) : hi[d];
+            }
+        }
+        __syncthreads();  // box[] and the count table initialised, every tile in LDS
+#pragma unroll
+        for (int d = 0; d < 3; ++d) {
+            const float l = wave_min(lo[d]), h = wave_max(hi[d]);
+            if (lane == 0) {
+                atomicMin(&box[d], order_code(l));
+                atomicMax(&box[3 + d], order_code(h));
+            }
+        }
+        __syncthreads();
+        float blo[3], scale[3];
+#pragma unroll
+        for (int d = 0; d < 3; ++d) {
+            blo[d] = order_decode(box[d]);
+            scale[d] = 15.999f / fmaxf(order_decode(box[3 + d]) - blo[d], 1e-30f);
+        }
+        unsigned key[4], rank[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            key[k] = hilbert_cell16(px[k], py[k], pz[k], blo, scale) >> kKeyShift;
+            rank[k] = atomicAdd(&hist((int)key[k]), 1u);
+        }
+        __syncthreads();
+        unsigned local[kPerThread], sum = 0u;
+#pragma unroll
+        for (int i = 0; i < kPerThread; ++i) {
+            local[i] = hist((int)threadIdx.x * kPerThread + i);
+            sum += local[i];
+        }
+        unsigned inc = sum;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const unsigned t = __shfl_up(inc, off);
+            inc += lane >= off ? t : 0u;
+        }
+        if (lane == 63) wsum[wave] = inc;
+        __syncthreads();
+        unsigned base = inc - sum;
+        for (int w = 0; w < wave; ++w) base += wsum[w];
+#pragma unroll
+        for (int i = 0; i < kPerThread; ++i) {
+            hist((int)threadIdx.x * kPerThread + i) = base;
+            base += local[i];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < 4; ++k) sperm[hist((int)key[k]) + rank[k]] = (uint16_t)(wave * kTilePoints + 4 * lane + k);
+        __syncthreads();  // the position table is complete; the count table is dead: the value quarters are free for results
+        const GroupIO gio{nullptr, nullptr, &res[0][0], cfirst, sperm + wave * kTilePoints};
+        const uint64_t todo = S >= 64 ? ~0ull : ((1ull << S) - 1ull);
+        tile_passes_split<PPP, false, false, 2>(grids, S, tf, A, a, 0, P, val, leaf, nullptr, lane, todo, -__builtin_inff(), gio);
+        __syncthreads();  // every result of the chunk is in its caller-order slot
+        const int64_t o = (int64_t)a * P + cfirst + wave * kTilePoints;
+        __builtin_nontemporal_store(sp[192 + lane], reinterpret_cast<f32x4_u*>(val + o) + lane);
+        f32x4_u* dst = reinterpret_cast<f32x4_u*>(grad + 3 * o);
+        __builtin_nontemporal_store(sp[lane], dst + lane);
+        __builtin_nontemporal_store(sp[lane + 64], dst + lane + 64);
+        __builtin_nontemporal_store(sp[lane + 128], dst + lane + 128);
         __syncthreads();  // the slices are free for the next chunk
     }
 }
@@ -1239,6 +1380,25 @@ extern "C" int pvamd_composed_query(const pvamd_grid_t* grids, int32_t S, const 
     // one launch per slab (fewer than 256 points always take the per-lane kernel).
     // (flags bits 1 and 2, for tools/scalar_probe.py and the tests: force the per-lane / the wave-tile kernel.)
     const int64_t ntiles = (P + kTilePoints - 1) / kTilePoints;
+    // Round 6: the chunk-grouped kernel with the sort inside the workgroup (composed_query_fused) wherever there are enough
+    // (chunk, configuration) workgroups to fill the chip twice over and the grids are L2-resident: scattered points cost it a
+    // sixth more work per chunk and save a third of the leaf loop (C3 0.081 -> see profiles/r06_composed_variants.txt); a caller
+    // with scratch and several configurations sorts once instead (pvamd_group_points + pvamd_composed_query_grouped).
+    {
+        const int64_t nchunks = (P + kFusedChunk - 1) / kFusedChunk;
+        const bool plain_flags = !(flags & (PVAMD_COMPOSED_INLINE_EXACT | PVAMD_COMPOSED_LEGACY_LEAF_LOOP | PVAMD_COMPOSED_FORCE_PER_LANE |
+                                            PVAMD_COMPOSED_FORCE_WAVE_TILE | PVAMD_COMPOSED_POINTS_FASTEST | PVAMD_COMPOSED_NO_GROUPING));
+        const bool fused = P >= kFusedChunk && S < kNoLeaf &&
+                           ((plain_flags && nchunks * (int64_t)A >= kFusedMinBlocks) || (flags & PVAMD_COMPOSED_FORCE_FUSED));
+        if (fused) {
+            int64_t cap = ((int64_t)65536 + A - 1) / A;
+            if (cap > 65535) cap = 65535;
+            const unsigned gy = (unsigned)(nchunks < cap ? nchunks : (cap < 1 ? 1 : cap));
+            hipLaunchKernelGGL((composed_query_fused<kFusedWaves, PVAMD_COMPOSED_PPP>), dim3(A, gy), dim3(kFusedWaves * 64), 0, s, grids, S, tf,
+                               A, points, nchunks, P, out_val, out_grad, out_leaf, 0);
+            return (int)hipGetLastError();
+        }
+    }
     const bool wave_tiles = P >= kTilePoints && ((A >= 2 && ntiles * (int64_t)A >= kWaveTileMinTiles && !(flags & 2)) || (flags & 4));
     // up to ~65536 blocks in total, split over the A configurations: about one 256-point tile per wave.  (Sweep on C4,
     // 200 x 262,144: 1024 blocks 1.40 ms, 4096 1.17, 8192 1.13, 32768 1.09, 65536 1.08 -- the hardware dispatcher

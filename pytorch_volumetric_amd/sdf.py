@@ -790,6 +790,11 @@ class ComposedSDF(ObjectFrameSDF):
     bucket_points = "auto"  # True / False / "auto": sort the query points spatially before the fused kernel (see __call__)
     group_points = "auto"   # True / False / "auto": regroup the points spatially inside chunks (pvamd_composed_query_grouped)
 
+    def _direct_flags(self):
+        """flags of a pvamd_composed_query call: the grid-size hint, plus "no regrouping" when group_points is False (the entry point
+        regroups inside its workgroups on its own where that pays: composed_query_fused)"""
+        return self._query_flags | (_lib.COMPOSED_NO_GROUPING if self.group_points is False else 0)
+
     def _grouping_pays(self, A, P, flags):
         """The chunk-grouped kernel (round 6): one small sort launch shared by the A configurations, then waves of
         neighbouring points -- most leaf visits become all-outside instead of paying the look-up half for a few lanes (C4:
@@ -923,7 +928,7 @@ class ComposedSDF(ObjectFrameSDF):
                                "pvamd_composed_query_grouped")
                     return val, grad
                 rc = plan[4](plan[2], plan[3], tfd.data_ptr(), A, p.data_ptr(), P, val.data_ptr(), grad.data_ptr(), None,
-                             flags, _lib.current_raw_stream(plan[1]))
+                             flags | (64 if self.group_points is False else 0), _lib.current_raw_stream(plan[1]))  # 64 = COMPOSED_NO_GROUPING
                 if rc != 0:
                     _lib.check(rc, "pvamd_composed_query")
                 return val, grad
@@ -969,7 +974,7 @@ class ComposedSDF(ObjectFrameSDF):
                 else:
                     _lib.check(lib.pvamd_composed_query(_lib.ptr(grids), S, _lib.ptr(self._tf_device(dev)),
                                                         A, _lib.ptr(flat), P, _lib.ptr(val), _lib.ptr(grad), None,
-                                                        self._query_flags, _lib.stream_ptr()), "pvamd_composed_query")
+                                                        self._direct_flags(), _lib.stream_ptr()), "pvamd_composed_query")
         else:
             val, grad = self._generic(flat, S, A)
         if self.tsf_batch is not None:
@@ -1025,8 +1030,10 @@ class ComposedSDF(ObjectFrameSDF):
             grids = self._leaf_grids(dev)
             tfd = self._tf_device(dev)
             if order == "sorted":
+                # (already sorted along the Hilbert curve: regrouping inside chunks would only cost its sort)
                 _lib.check(lib.pvamd_composed_query(_lib.ptr(grids), S, _lib.ptr(tfd), A, _lib.ptr(prepared.sorted_points), P,
-                                                    _lib.ptr(val), _lib.ptr(grad), None, self._query_flags, _lib.stream_ptr()),
+                                                    _lib.ptr(val), _lib.ptr(grad), None, self._query_flags | _lib.COMPOSED_NO_GROUPING,
+                                                    _lib.stream_ptr()),
                            "pvamd_composed_query")
             else:
                 Pp = prepared.padded_points.shape[0]
@@ -1129,7 +1136,7 @@ class ComposedSDF(ObjectFrameSDF):
         with _lib.on_device(dev):
             grids = self._leaf_grids(dev)
             _lib.check(_lib.load().pvamd_composed_query(_lib.ptr(grids), S, _lib.ptr(sub), count, _lib.ptr(flat), P,
-                                                        _lib.ptr(val), _lib.ptr(grad), None, self._query_flags,
+                                                        _lib.ptr(val), _lib.ptr(grad), None, self._direct_flags(),
                                                         _lib.stream_ptr()), "pvamd_composed_query")
         return val, grad
 
@@ -1169,7 +1176,7 @@ class ComposedSDF(ObjectFrameSDF):
                 return
             _lib.check(_lib.load().pvamd_composed_query(_lib.ptr(grids), len(self.sdfs),
                                                         _lib.ptr(self._tf_device(dev)), A, _lib.ptr(points), P,
-                                                        _lib.ptr(out_val), _lib.ptr(out_grad), None, self._query_flags,
+                                                        _lib.ptr(out_val), _lib.ptr(out_grad), None, self._direct_flags(),
                                                         _lib.stream_ptr()),
                        "pvamd_composed_query")
 

@@ -211,3 +211,49 @@ def test_eight_shards_computed_one_by_one_unpack_to_the_unsharded_call(P, A, wor
     sh = pvdist.ShardedSDF(comp)
     val, grad = sh._unpack_records(gathered, index, P, Pp, A, pts.device)
     assert same_bits(val.cpu().numpy(), dv.cpu().numpy()) and same_bits(grad.cpu().numpy(), dg.cpu().numpy())
+
+
+@pytest.mark.parametrize("S,A,P", [(8, 1, 4096), (8, 1, 50_001), (5, 3, 9000), (64, 1, 4200), (70, 2, 4100)])
+def test_fused_in_workgroup_sort_matches_the_oracle_bitwise(S, A, P):
+    """composed_query_fused (round 6): pvamd_composed_query itself regroups every chunk inside its workgroup -- no scratch, no
+    pre-pass -- for a single configuration too (C3).  Forced here at sizes the entry point would leave to the older kernels; more
+    leaves than the culling table holds; out_leaf; against the oracle and against the ungrouped kernels."""
+    comp, leaves, tfm = composed(S, A, seed=7 * S + A)
+    pts = scene_points(P, seed=P + 1, extent=0.6)
+    pts[11] = float("nan")
+    pts[P - 1, 2] = float("inf")
+    pts = pts.cuda()
+    lib = _lib.load()
+    dev = pts.device
+    grids = comp._leaf_grids(dev)
+    out = {}
+    for flags in (_lib.COMPOSED_FORCE_FUSED, _lib.COMPOSED_NO_GROUPING):
+        val = torch.empty((A, P), device=dev)
+        grad = torch.empty((A, P, 3), device=dev)
+        leaf = torch.full((A, P), -1, dtype=torch.int32, device=dev)
+        _lib.check(lib.pvamd_composed_query(_lib.ptr(grids), S, _lib.ptr(comp._tf_device(dev)), A, _lib.ptr(pts), P, _lib.ptr(val),
+                                            _lib.ptr(grad), _lib.ptr(leaf), flags, _lib.stream_ptr()), "pvamd_composed_query")
+        out[flags] = (val.cpu().numpy(), grad.cpu().numpy(), leaf.cpu().numpy())
+    f, n = out[_lib.COMPOSED_FORCE_FUSED], out[_lib.COMPOSED_NO_GROUPING]
+    assert same_bits(f[0], n[0]) and same_bits(f[1], n[1]) and np.array_equal(f[2], n[2])
+    oval, ograd, oleaf = oracle.composed_query([H.oracle_grid_from_cached(l) for l in leaves], tfm.numpy(), A, pts.cpu().numpy())
+    assert np.array_equal(f[0], oval, equal_nan=True) and np.array_equal(f[1], ograd, equal_nan=True)
+    assert np.array_equal(f[2], oleaf)
+
+
+def test_the_entry_point_picks_the_fused_kernel_for_a_large_single_configuration():
+    """A = 1, 4,194,304 + 77 points (C3's size, ragged): what comp(points) runs is the fused kernel; same bits as with
+    group_points = False (the per-lane kernel) and as the oracle on three slices."""
+    comp, leaves, tfm = composed(8, 1, seed=3)
+    comp.set_transforms(pv.Transform3d(matrix=tfm))  # no batch: flat outputs
+    P = (1 << 22) + 77
+    pts = H.uniform_points(P, [-0.5] * 3, [0.5] * 3, seed=5).cuda()
+    v1, g1 = comp(pts)
+    comp.group_points = False
+    v0, g0 = comp(pts)
+    assert v1.shape == (P,) and torch.equal(v1.view(torch.int32), v0.view(torch.int32)) and torch.equal(g1.view(torch.int32), g0.view(torch.int32))
+    ogrids = [H.oracle_grid_from_cached(l) for l in leaves]
+    for a, b in ((0, 3000), (P // 2, P // 2 + 3000), (P - 3000, P)):
+        oval, ograd, _ = oracle.composed_query(ogrids, tfm.numpy(), 1, pts[a:b].cpu().numpy())
+        assert np.array_equal(v1[a:b].cpu().numpy(), oval[0], equal_nan=True)
+        assert np.array_equal(g1[a:b].cpu().numpy(), ograd[0], equal_nan=True)
