@@ -466,22 +466,24 @@ PVAMD_DEV void tile_passes_split(const pvamd_grid_t* __restrict__ grids, int S, 
                 // visits end here: 9 vector instructions and the vlo / vhi scalar loads become one compare.  A NaN n2 (NaN
                 // point, or a descriptor without a box) proves nothing and takes the range test.
                 uint64_t vm = 0;
-                if (__builtin_amdgcn_ballot_w64(!(n2 > g.range_n2)) != 0) vm = in_range_mask(g, x, y, z);
-                if (vm != 0) {
-                    // the lanes in range look their value up (index estimate; shaky ones are redone exactly below)
-                    const bool valid = __builtin_amdgcn_inverse_ballot_w64(vm);
-                    bool shaky = false;
-                    const int flat = voxel_flat_estimate(g, x, y, z, shaky);
-                    unsure[k] |= vm & __builtin_amdgcn_ballot_w64(shaky);
-                    float v = __builtin_inff();
-                    if (valid) v = reinterpret_cast<const float __attribute__((address_space(1)))*>((uintptr_t)g.vox)[4 * (int64_t)flat];
-                    // ascending leaves: "strictly smaller, or the first" is the first minimum; NaN counts as the minimum
-                    const uint64_t better = __builtin_amdgcn_ballot_w64(!(v >= bin[k].v)) & __builtin_amdgcn_ballot_w64(bin[k].v == bin[k].v);
-                    const bool t = __builtin_amdgcn_inverse_ballot_w64(vm & (better | __builtin_amdgcn_ballot_w64(bin[k].leaf == kNoLeaf)));
-                    bin[k].v = t ? v : bin[k].v;
-                    bin[k].leaf = t ? s : bin[k].leaf;
-                    bin[k].flat = t ? flat : bin[k].flat;
-                    if (vm == everyone) continue;
+                if (__builtin_amdgcn_ballot_w64(!(n2 > g.range_n2)) != 0) {
+                    vm = in_range_mask(g, x, y, z);
+                    if (vm != 0) {
+                        // the lanes in range look their value up (index estimate; shaky ones are redone exactly below)
+                        const bool valid = __builtin_amdgcn_inverse_ballot_w64(vm);
+                        bool shaky = false;
+                        const int flat = voxel_flat_estimate(g, x, y, z, shaky);
+                        unsure[k] |= vm & __builtin_amdgcn_ballot_w64(shaky);
+                        float v = __builtin_inff();
+                        if (valid) v = reinterpret_cast<const float __attribute__((address_space(1)))*>((uintptr_t)g.vox)[4 * (int64_t)flat];
+                        // ascending leaves: "strictly smaller, or the first" is the first minimum; NaN counts as the minimum
+                        const uint64_t better = __builtin_amdgcn_ballot_w64(!(v >= bin[k].v)) & __builtin_amdgcn_ballot_w64(bin[k].v == bin[k].v);
+                        const bool t = __builtin_amdgcn_inverse_ballot_w64(vm & (better | __builtin_amdgcn_ballot_w64(bin[k].leaf == kNoLeaf)));
+                        bin[k].v = t ? v : bin[k].v;
+                        bin[k].leaf = t ? s : bin[k].leaf;
+                        bin[k].flat = t ? flat : bin[k].flat;
+                        if (vm == everyone) continue;
+                    }
                 }
                 // first minimum, NaN counts as minimum (keep_first_minimum), on the squared norms
                 uint64_t take = __builtin_amdgcn_ballot_w64(!(n2 >= best[k].n2)) &
