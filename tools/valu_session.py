@@ -8,13 +8,13 @@ import csv, glob, json, os, re, sys, collections
 sess, out_path = sys.argv[1], sys.argv[2]
 WORK = {  # key -> (run_valu.py name, calls, kernel regex, description)
     "c1_mesh_query": ("c1", 6, r"mesh_|hand_over|order_|radix_|aabb_|morton|invert_face", "C1: MeshSDF(drill), 10,000 grid points, one call = point sort + list / parts / finish launches"),
-    "c3_composed_query": ("c3", 6, r"composed_query", "C3: ComposedSDF of 8 drills, 4,194,304 random points, one launch"),
-    "c4_composed_query_wave": ("c4", 4, r"composed_query", "C4: RobotSDF 8 links (100 KB grids), 200 configurations x 262,144 random points, one launch"),
+    "c3_composed_query": ("c3", 6, r"composed_query|group_points", "C3: ComposedSDF of 8 drills, 4,194,304 random points, one launch"),
+    "c4_composed_query_wave": ("c4", 4, r"composed_query|group_points", "C4: RobotSDF 8 links (100 KB grids), 200 configurations x 262,144 random points, one launch"),
     "c5_chamfer_mesh": ("c5", 3, r"mesh_|chamfer|hand_over|order_|radix_|aabb_|morton|invert_face", "C5: chamfer, 2,097,152 points -> 99,500-triangle sphere, one call = point sort + main launch + heavy-group launches"),
     # cache construction: CachedSDF(...) over a MeshSDF = point sort + mesh query over every voxel centre + pack
-    "build_drill_0.01": ("bd1", 6, r"mesh_|hand_over|order_|radix_|aabb_|morton|invert_face|pack_grid", "cache build: drill, res 0.01 pad 0.1, 37x33x40 = 48,840 voxel centres"),
-    "build_drill_0.002": ("bd2", 4, r"mesh_|hand_over|order_|radix_|aabb_|morton|invert_face|pack_grid", "cache build: drill, res 0.002 pad 0.01, 92x73x105 = 705,180 voxel centres"),
-    "build_wrench_0.001": ("bw", 3, r"mesh_|hand_over|order_|radix_|aabb_|morton|invert_face|pack_grid", "cache build: offset_wrench_nogrip, res 0.001 pad 0.05, 218x126x111 = 3,048,948 voxel centres"),
+    "build_drill_0.01": ("bd1", 6, r"mesh_|hand_over|order_|radix_|aabb_|morton|invert_face|pack_grid|grid_points", "cache build: drill, res 0.01 pad 0.1, 37x33x40 = 48,840 voxel centres"),
+    "build_drill_0.002": ("bd2", 4, r"mesh_|hand_over|order_|radix_|aabb_|morton|invert_face|pack_grid|grid_points", "cache build: drill, res 0.002 pad 0.01, 92x73x105 = 705,180 voxel centres"),
+    "build_wrench_0.001": ("bw", 3, r"mesh_|hand_over|order_|radix_|aabb_|morton|invert_face|pack_grid|grid_points", "cache build: offset_wrench_nogrip, res 0.001 pad 0.05, 218x126x111 = 3,048,948 voxel centres"),
 }
 
 
