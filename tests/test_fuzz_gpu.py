@@ -8,6 +8,7 @@ import pytest
 import torch
 
 import pytorch_volumetric_amd as pv
+from pytorch_volumetric_amd import _lib
 from oracle import oracle
 from pytorch_volumetric_amd import mesh_io
 from tests import helpers as H
@@ -106,6 +107,15 @@ def test_composed_query_fuzz(seed):
         val, grad = comp(torch.from_numpy(pts).cuda())
         assert np.array_equal(val.cpu().numpy().reshape(A, -1), oval, equal_nan=True), (flags, bucket)
         assert np.array_equal(grad.cpu().numpy().reshape(A, -1, 3), ograd, equal_nan=True), (flags, bucket)
+    if n >= _lib.group_chunk_points():
+        # round 6: the chunk-grouped kernels -- the sort inside the workgroup (FORCE_FUSED) and the pre-pass + grouped pair
+        comp.bucket_points = False
+        for flags, group in ((_lib.COMPOSED_FORCE_FUSED, "auto"), (0, True)):
+            comp._query_flags = flags
+            comp.group_points = group
+            val, grad = comp(torch.from_numpy(pts).cuda())
+            assert np.array_equal(val.cpu().numpy().reshape(A, -1), oval, equal_nan=True), (flags, group)
+            assert np.array_equal(grad.cpu().numpy().reshape(A, -1, 3), ograd, equal_nan=True), (flags, group)
 
 
 def random_mesh(rng):
@@ -161,7 +171,7 @@ def test_rules_and_float64_compositions_fuzz(seed):
         tfm = H.random_rigid(S * A, seed=seed, trans=1.0)
         comp = pv.ComposedSDF(leaves, None)
         comp.set_transforms(tfm, batch_dim=(A,) if A > 1 else None)
-        n = int(rng.choice([9, 300, 2049]))
+        n = int(rng.choice([9, 300, 2049, 4100]))
         pts = (rng.random((n, 3)) * 4 - 2).astype(np.float32)
         # leaf-frame half-voxel planes and range edges of leaf 0 under configuration 0, brought back to the object frame
         v0 = leaves[0]._view
@@ -173,11 +183,14 @@ def test_rules_and_float64_compositions_fuzz(seed):
         ogrids = [H.oracle_grid_from_cached(l) for l in leaves]
         oval, ograd, _ = oracle.composed_query(ogrids, tfm.numpy(), A, pts)
         comp._leaf_grids(torch.device("cuda", torch.cuda.current_device()))
-        for flags in (2, 4, 4 | 1):
+        for flags, group in ((2, "auto"), (4, "auto"), (4 | 1, "auto")) + \
+                (((_lib.COMPOSED_FORCE_FUSED, "auto"), (0, True)) if n >= _lib.group_chunk_points() else ()):
             comp._query_flags = flags
+            comp.group_points = group
             val, grad = comp(torch.from_numpy(pts).cuda())
-            assert np.array_equal(val.cpu().numpy().reshape(A, -1), oval, equal_nan=True), (rule, flags)
-            assert np.array_equal(grad.cpu().numpy().reshape(A, -1, 3), ograd, equal_nan=True), (rule, flags)
+            assert np.array_equal(val.cpu().numpy().reshape(A, -1), oval, equal_nan=True), (rule, flags, group)
+            assert np.array_equal(grad.cpu().numpy().reshape(A, -1, 3), ograd, equal_nan=True), (rule, flags, group)
+        comp.group_points = "auto"
         p64 = pts.astype(np.float64) + rng.normal(scale=1e-10, size=pts.shape)
         v64, g64 = comp(torch.from_numpy(p64).cuda())
         ov, og, _ = oracle.composed_query_f64(ogrids, tfm.double().numpy(), A, p64)
