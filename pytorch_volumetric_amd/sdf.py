@@ -928,7 +928,8 @@ class ComposedSDF(ObjectFrameSDF):
                                "pvamd_composed_query_grouped")
                     return val, grad
                 rc = plan[4](plan[2], plan[3], tfd.data_ptr(), A, p.data_ptr(), P, val.data_ptr(), grad.data_ptr(), None,
-                             flags | (64 if self.group_points is False else 0), _lib.current_raw_stream(plan[1]))  # 64 = COMPOSED_NO_GROUPING
+                             flags | (_lib.COMPOSED_NO_GROUPING if self.group_points is False else 0),
+                             _lib.current_raw_stream(plan[1]))
                 if rc != 0:
                     _lib.check(rc, "pvamd_composed_query")
                 return val, grad
@@ -1165,9 +1166,15 @@ class ComposedSDF(ObjectFrameSDF):
                 # allocated after the first call of a size, so a captured graph replays both
                 lib = _lib.load()
                 need = int(lib.pvamd_group_scratch_bytes(P))
-                scratch = self.__dict__.get("_group_scratch")
-                if scratch is None or scratch.numel() != need or scratch.device != dev:
-                    scratch = self._group_scratch = torch.empty((need,), dtype=torch.uint8, device=dev)
+                # one buffer per (point count, device, stream): two streams querying the same object never share a scratch
+                # (at most 8 are remembered)
+                table = self.__dict__.setdefault("_group_scratch", {})
+                key = (need, str(dev), _lib.stream_ptr().value or 0)
+                scratch = table.get(key)
+                if scratch is None:
+                    if len(table) >= 8:
+                        table.pop(next(iter(table)))
+                    scratch = table[key] = torch.empty((need,), dtype=torch.uint8, device=dev)
                 _lib.check(lib.pvamd_group_points(_lib.ptr(points), P, _lib.ptr(scratch), _lib.stream_ptr()), "pvamd_group_points")
                 _lib.check(lib.pvamd_composed_query_grouped(_lib.ptr(grids), len(self.sdfs), _lib.ptr(self._tf_device(dev)), A,
                                                             _lib.ptr(scratch), P, _lib.ptr(out_val), _lib.ptr(out_grad), None,
