@@ -169,6 +169,16 @@ def frac_8d_pairs(pairs, ms):
     return pairs * FLOP_PER_EXACT_PAIR / (ms * 1e-3) / (FP32_PEAK_TFLOPS * 1e12)
 
 
+LEG_REGIONS = 3  # timed regions per leg figure; the median one is reported (one host stall inside a single region read as 16 ms / step once)
+
+
+def median_region(timer, fn, regions=LEG_REGIONS):
+    """`regions` timed regions of `fn` (each: barrier + synchronize on both sides, MAX over ranks), the median one.  Every rank runs
+    the same number of regions: the timer holds collectives."""
+    times = sorted(timer(fn) for _ in range(regions))
+    return times[len(times) // 2]
+
+
 class LegSkipped(Exception):
     pass
 
@@ -225,7 +235,7 @@ def leg_c4(torch, dist, Wk, pv, timer, gate, robots, rank, world, steps, padding
 
     settle(torch, one_step)
     gate()
-    t = timer(sharded_steps)
+    t = median_region(timer, sharded_steps)
     pairs = A * P * steps
     out = {"config": f"C4: RobotSDF 8 links, grids res 0.02 padding {padding}, A={A} x P={P}, points sharded x{world}",
            "scaling": "strong", "n_gpus": world, "steps": steps, "unit": "(configuration, point) pairs/s",
@@ -251,7 +261,7 @@ def leg_c4(torch, dist, Wk, pv, timer, gate, robots, rank, world, steps, padding
                     return robot.sdf.query_prepared(handle, order=order)
 
                 settle(torch, prepared_step, seconds=0.1)
-                tp = timer(lambda: [prepared_step() for _ in range(steps)])
+                tp = median_region(timer, lambda: [prepared_step() for _ in range(steps)])
                 out["sharded"][f"prepared_{order}_ms"] = tp / steps * 1e3
             v0, g0 = robot(mine)
             v1, g1 = robot.sdf.query_prepared(handle, order="caller")
@@ -271,7 +281,7 @@ def leg_c4(torch, dist, Wk, pv, timer, gate, robots, rank, world, steps, padding
                 full = sharded(pts)
 
         sharded(pts)
-        tg = timer(gather_steps)
+        tg = median_region(timer, gather_steps)
         ref = robot(pts[:65536])  # after timing: the gathered result against the unsharded call, bit for bit
         same = bool(torch.equal(full[0][:, :65536], ref[0]) and torch.equal(full[1][:, :65536], ref[1]))
         recv = getattr(sharded, "bytes_received_per_rank", None)
@@ -302,7 +312,7 @@ def leg_c4(torch, dist, Wk, pv, timer, gate, robots, rank, world, steps, padding
                     cfull = by_cfg(pts)
 
             by_cfg(pts)
-            tc = timer(config_steps)
+            tc = median_region(timer, config_steps)
             same_c = bool(torch.equal(cfull[0][:, :65536], ref[0]) and torch.equal(cfull[1][:, :65536], ref[1]))
             out["gathered_by_configs"] = {"gather": True, "shard": "configs", "value": A * P * gsteps / tc,
                                           "ms_per_step": tc / gsteps * 1e3, "steps": gsteps,
@@ -370,7 +380,7 @@ def leg_c3(torch, Wk, pv, timer, gate, cached, rank, world, steps, small=False):
 
     settle(torch, run)
     gate()
-    t = timer(run)
+    t = median_region(timer, run)
     gbs = BYTES_PER_QUERY * P * steps / t / 1e9
     return {"config": f"C3: ComposedSDF of 8 transformed drills (37x33x40 cache each), {P} points, points sharded x{world}",
             "scaling": "strong", "n_gpus": world, "steps": steps, "unit": "queries/s", "value": P * steps / t,
@@ -427,7 +437,7 @@ def leg_c5(torch, dist, Wk, pv, timer, gate, rank, world, steps, small=False, us
     gate()
     # (with ranks the warm-up count must be the same on every rank: `run` holds a collective)
     settle(torch, run, seconds=0.0 if (world > 1 or use_pg) else 0.3, at_least=2 if (world > 1 or use_pg) else 1)
-    t = timer(run)
+    t = median_region(timer, run)
     F = mesh.num_faces
     analytic = float((((pts.norm(dim=-1) - 0.1) * 1000.0) ** 2).mean())
     return {"config": f"C5: chamfer, {N} points -> {F}-triangle sphere mesh, points sharded x{world}, B=1",
