@@ -364,7 +364,7 @@ int pvamd_mesh_query(const pvamd_mesh_t* mesh, const float* points, const int32_
 /* CachedSDF construction from a mesh on the device (sdf.py:498-516: the ground-truth SDF over every voxel centre of the grid
  * voxel.py:20-25 builds, then the two arrays the reference keeps), in at most three launches for a small grid: the voxel
  * centres (cartesian product of the three coordinate arrays, x slowest) and a processing order that walks them in 4 x 4 x 4
- * bricks are written by one kernel -- no sort --, then pvamd_mesh_query's launches, whose last one writes the packed
+ * bricks (inside 16^3 super-bricks) are written by one kernel -- no sort --, then pvamd_mesh_query's launches, whose last one writes the packed
  * (val, gx, gy, gz) record of voxel i = (x * ny + y) * nz + z straight into the cache.  Same bits as pvamd_mesh_query over the
  * same centres followed by pvamd_pack_grid (results do not depend on the processing order; the sign jitter is indexed by i).
  * cx / cy / cz: device [nx] / [ny] / [nz] float32.  out_packed: device [nx*ny*nz][4], 16-byte aligned.
