@@ -964,6 +964,10 @@ constexpr int kGroupChunk = kGroupWaves * kTilePoints;
 #ifndef PVAMD_FUSED_WAVES
 #define PVAMD_FUSED_WAVES 16
 #endif
+#ifndef PVAMD_FUSED_COHERENT_SPAN
+#define PVAMD_FUSED_COHERENT_SPAN 0.45f
+#endif
+constexpr float kCoherentSpan = PVAMD_FUSED_COHERENT_SPAN;  // a chunk whose tiles each span at most this much of it is not sorted
 constexpr int kFusedWaves = PVAMD_FUSED_WAVES;  // waves (x 256 points) per chunk of the in-workgroup sort
 constexpr int kFusedChunk = kFusedWaves * kTilePoints;
 #ifndef PVAMD_FUSED_MIN_BLOCKS
@@ -1197,6 +1201,7 @@ __global__ __launch_bounds__(NW * 64, PVAMD_GROUP_MINWAVES) void composed_query_
     __shared__ uint16_t sperm[N];
     __shared__ unsigned box[6];
     __shared__ unsigned wsum[NW];
+    __shared__ float wspan[NW];
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int a = a0 + blockIdx.x;
     auto hist = [&](int bin) -> unsigned& { return reinterpret_cast<unsigned*>(res[bin >> 8])[768 + (bin & 255)]; };
@@ -1238,21 +1243,38 @@ __global__ __launch_bounds__(NW * 64, PVAMD_GROUP_MINWAVES) void composed_query_
             }
         }
         __syncthreads();  // box[] and the count table initialised, every tile in LDS
+        float tile_span = 0.f;  // L1 diameter of this wave's 256 points (finite coordinates)
 #pragma unroll
         for (int d = 0; d < 3; ++d) {
             const float l = wave_min(lo[d]), h = wave_max(hi[d]);
+            tile_span += fmaxf(h - l, 0.f);
             if (lane == 0) {
                 atomicMin(&box[d], order_code(l));
                 atomicMax(&box[3 + d], order_code(h));
             }
         }
+        if (lane == 0) wspan[wave] = tile_span;
         __syncthreads();
-        float blo[3], scale[3];
+        float blo[3], scale[3], chunk_span = 0.f;
 #pragma unroll
         for (int d = 0; d < 3; ++d) {
             blo[d] = order_decode(box[d]);
-            scale[d] = 15.999f / fmaxf(order_decode(box[3 + d]) - blo[d], 1e-30f);
+            const float ext = order_decode(box[3 + d]) - blo[d];
+            chunk_span += fmaxf(ext, 0.f);
+            scale[d] = 15.999f / fmaxf(ext, 1e-30f);
         }
+        // The caller's order may already be as coherent as a sort could make it (an ordered slice, a pre-sorted set: a run of 64
+        // points out of 4096 sorted ones spans ~0.25-0.4 of the chunk): then every wave keeps its own tile and the sort -- a
+        // quarter of this kernel -- is skipped for the chunk.  Block-uniform: every thread reads the same 16 spans.
+        float worst_tile = 0.f;
+        for (int w = 0; w < NW; ++w) worst_tile = fmaxf(worst_tile, wspan[w]);
+        const bool coherent = worst_tile <= kCoherentSpan * chunk_span;
+        if (coherent) {
+            // identity positions (each wave fills and later reads only its own 256 entries): the same leaf loop, no second copy of it
+#pragma unroll
+            for (int k = 0; k < 4; ++k) sperm[wave * kTilePoints + 4 * lane + k] = (uint16_t)(wave * kTilePoints + 4 * lane + k);
+            PVAMD_WAVE_SYNC();
+        } else {
         unsigned key[4], rank[4];
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
@@ -1285,6 +1307,7 @@ __global__ __launch_bounds__(NW * 64, PVAMD_GROUP_MINWAVES) void composed_query_
 #pragma unroll
         for (int k = 0; k < 4; ++k) sperm[hist((int)key[k]) + rank[k]] = (uint16_t)(wave * kTilePoints + 4 * lane + k);
         __syncthreads();  // the position table is complete; the count table is dead: the value quarters are free for results
+        }
         const GroupIO gio{nullptr, nullptr, &res[0][0], cfirst, sperm + wave * kTilePoints};
         const uint64_t todo = S >= 64 ? ~0ull : ((1ull << S) - 1ull);
         tile_passes_split<PPP, false, false, 2>(grids, S, tf, A, a, 0, P, val, leaf, nullptr, lane, todo, -__builtin_inff(), gio);

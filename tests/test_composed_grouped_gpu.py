@@ -257,3 +257,28 @@ def test_the_entry_point_picks_the_fused_kernel_for_a_large_single_configuration
         oval, ograd, _ = oracle.composed_query(ogrids, tfm.numpy(), 1, pts[a:b].cpu().numpy())
         assert np.array_equal(v1[a:b].cpu().numpy(), oval[0], equal_nan=True)
         assert np.array_equal(g1[a:b].cpu().numpy(), ograd[0], equal_nan=True)
+
+
+def test_fused_kernel_on_points_that_are_already_ordered():
+    """A chunk whose 256-point tiles each span less than half of it (an ordered slice, a pre-sorted set) is not sorted inside the
+    workgroup (composed_query_fused: identity positions through the same leaf loop); a set that is ordered in its first chunks
+    and scattered in its last ones takes both paths in one launch.  The oracle's bits either way."""
+    comp, leaves, tfm = composed(8, 1, seed=13)
+    ax = torch.linspace(-0.6, 0.6, 128)
+    slab = torch.cartesian_prod(ax, ax, torch.tensor([0.05]))              # 16,384 points of a planar slice, row by row
+    pts = torch.cat((slab, scene_points(3 * 4096 + 5, seed=1, extent=0.6))).cuda().contiguous()
+    P = pts.shape[0]
+    lib = _lib.load()
+    dev = pts.device
+    grids = comp._leaf_grids(dev)
+    out = {}
+    for flags in (_lib.COMPOSED_FORCE_FUSED, _lib.COMPOSED_NO_GROUPING):
+        val = torch.empty((1, P), device=dev)
+        grad = torch.empty((1, P, 3), device=dev)
+        _lib.check(lib.pvamd_composed_query(_lib.ptr(grids), 8, _lib.ptr(comp._tf_device(dev)), 1, _lib.ptr(pts), P, _lib.ptr(val),
+                                            _lib.ptr(grad), None, flags, _lib.stream_ptr()), "pvamd_composed_query")
+        out[flags] = (val.cpu().numpy(), grad.cpu().numpy())
+    f, n = out[_lib.COMPOSED_FORCE_FUSED], out[_lib.COMPOSED_NO_GROUPING]
+    assert same_bits(f[0], n[0]) and same_bits(f[1], n[1])
+    oval, ograd, _ = oracle.composed_query([H.oracle_grid_from_cached(l) for l in leaves], tfm.numpy(), 1, pts.cpu().numpy())
+    assert np.array_equal(f[0], oval, equal_nan=True) and np.array_equal(f[1], ograd, equal_nan=True)
