@@ -960,14 +960,14 @@ __global__ __launch_bounds__(kUnpermuteWaves * 64) void composed_unpermute_kerne
 #define PVAMD_GROUP_WAVES 16
 #endif
 constexpr int kGroupWaves = PVAMD_GROUP_WAVES;
-constexpr int kGroupChunk = kGroupWaves * kTilePoints;
-#ifndef PVAMD_FUSED_WAVES
-#define PVAMD_FUSED_WAVES 16
-#endif
 #ifndef PVAMD_FUSED_COHERENT_SPAN
 #define PVAMD_FUSED_COHERENT_SPAN 0.45f
 #endif
 constexpr float kCoherentSpan = PVAMD_FUSED_COHERENT_SPAN;  // a chunk whose tiles each span at most this much of it is not sorted
+constexpr int kGroupChunk = kGroupWaves * kTilePoints;
+#ifndef PVAMD_FUSED_WAVES
+#define PVAMD_FUSED_WAVES 16
+#endif
 constexpr int kFusedWaves = PVAMD_FUSED_WAVES;  // waves (x 256 points) per chunk of the in-workgroup sort
 constexpr int kFusedChunk = kFusedWaves * kTilePoints;
 #ifndef PVAMD_FUSED_MIN_BLOCKS
@@ -986,6 +986,7 @@ __global__ __launch_bounds__(NW * 64) void group_points_kernel(const float* __re
     __shared__ uint16_t sperm[N];
     __shared__ unsigned box[6];
     __shared__ unsigned wsum[NW];
+    __shared__ float wspan[NW];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int64_t chunk = blockIdx.x;
     const int64_t cfirst = chunk * N <= P - N ? chunk * N : P - N;  // the last chunk is moved back to end at the last point
@@ -1022,6 +1023,12 @@ __global__ __launch_bounds__(NW * 64) void group_points_kernel(const float* __re
         }
     }
     __syncthreads();  // box[] initialised, every tile in LDS
+    // L1 diameter of the widest run of 64 consecutive caller-order points of this wave (a lane holds four consecutive points, so a
+    // run is a row of 16 lanes): what the leaf loop's 64 lanes would be handed without regrouping
+    float run_span = 0.f;
+#pragma unroll
+    for (int d = 0; d < 3; ++d) run_span += fmaxf(group16_max(hi[d]) - group16_min(lo[d]), 0.f);
+    const float tile_span = wave_max(run_span);
 #pragma unroll
     for (int d = 0; d < 3; ++d) {
         const float l = wave_min(lo[d]), h = wave_max(hi[d]);
@@ -1030,13 +1037,22 @@ __global__ __launch_bounds__(NW * 64) void group_points_kernel(const float* __re
             atomicMax(&box[3 + d], order_code(h));
         }
     }
+    if (lane == 0) wspan[wave] = tile_span;
     __syncthreads();
-    float blo[3], scale[3];
+    float blo[3], scale[3], chunk_span = 0.f;
 #pragma unroll
     for (int d = 0; d < 3; ++d) {
         blo[d] = order_decode(box[d]);
-        scale[d] = 15.999f / fmaxf(order_decode(box[3 + d]) - blo[d], 1e-30f);
+        const float ext = order_decode(box[3 + d]) - blo[d];
+        chunk_span += fmaxf(ext, 0.f);
+        scale[d] = 15.999f / fmaxf(ext, 1e-30f);
     }
+    // a chunk whose runs of 64 consecutive points each span at most kCoherentSpan of it is already coherent where it matters -- the 64
+    // lanes of a leaf-loop pass -- (an ordered slice, a pre-sorted set): it keeps the caller's order; regrouping a 512 x 512 slice
+    // made C4 8 % SLOWER (the LDS scatter of the results costs, and there was nothing left to gain)
+    float worst_tile = 0.f;
+    for (int w = 0; w < NW; ++w) worst_tile = fmaxf(worst_tile, wspan[w]);
+    const bool coherent = worst_tile <= kCoherentSpan * chunk_span;  // block-uniform
     unsigned key[4], rank[4];
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
@@ -1070,6 +1086,10 @@ __global__ __launch_bounds__(NW * 64) void group_points_kernel(const float* __re
 #pragma unroll
     for (int k = 0; k < 4; ++k) sperm[hist[key[k]] + rank[k]] = (uint16_t)(wave * kTilePoints + 4 * lane + k);
     __syncthreads();
+    if (coherent) {
+        for (int k = 0; k < 4; ++k) sperm[wave * kTilePoints + 4 * lane + k] = (uint16_t)(wave * kTilePoints + 4 * lane + k);
+        __syncthreads();
+    }
     // wave w writes sorted run w and its bounding sphere (the statements of tile_leaf_mask)
     float tlo[3], thi[3];
     bool odd = false;
@@ -1243,7 +1263,9 @@ __global__ __launch_bounds__(NW * 64, PVAMD_GROUP_MINWAVES) void composed_query_
             }
         }
         __syncthreads();  // box[] and the count table initialised, every tile in LDS
-        float tile_span = 0.f;  // L1 diameter of this wave's 256 points (finite coordinates)
+        // L1 diameter of this wave's 256 points.  (The pre-pass kernel measures runs of 64 instead -- the finer test; here its extra
+        // reductions cost the scattered case 2 % and the tile test already catches ordered slices.)
+        float tile_span = 0.f;
 #pragma unroll
         for (int d = 0; d < 3; ++d) {
             const float l = wave_min(lo[d]), h = wave_max(hi[d]);
@@ -1263,9 +1285,9 @@ __global__ __launch_bounds__(NW * 64, PVAMD_GROUP_MINWAVES) void composed_query_
             chunk_span += fmaxf(ext, 0.f);
             scale[d] = 15.999f / fmaxf(ext, 1e-30f);
         }
-        // The caller's order may already be as coherent as a sort could make it (an ordered slice, a pre-sorted set: a run of 64
-        // points out of 4096 sorted ones spans ~0.25-0.4 of the chunk): then every wave keeps its own tile and the sort -- a
-        // quarter of this kernel -- is skipped for the chunk.  Block-uniform: every thread reads the same 16 spans.
+        // The caller's order may already be coherent (an ordered slice, a pre-sorted set): where every wave's tile spans at most
+        // kCoherentSpan of the chunk, every wave keeps its own tile and the sort -- a quarter of this kernel -- is skipped for the
+        // chunk.  Block-uniform: every thread reads the same 16 spans.
         float worst_tile = 0.f;
         for (int w = 0; w < NW; ++w) worst_tile = fmaxf(worst_tile, wspan[w]);
         const bool coherent = worst_tile <= kCoherentSpan * chunk_span;

@@ -32,4 +32,14 @@ PVAMD_DEV float group8_min(float v) {
 }
 PVAMD_DEV float group8_max(float v) { return -group8_min(-v); }
 
+// ... and within each row of 16 consecutive lanes
+PVAMD_DEV float group16_min(float v) {
+    PVAMD_DPP_MIN(v, "quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf");
+    PVAMD_DPP_MIN(v, "quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf");
+    PVAMD_DPP_MIN(v, "row_half_mirror row_mask:0xf bank_mask:0xf");
+    PVAMD_DPP_MIN(v, "row_mirror row_mask:0xf bank_mask:0xf");
+    return v;
+}
+PVAMD_DEV float group16_max(float v) { return -group16_min(-v); }
+
 }  // namespace pvamd
