@@ -1221,7 +1221,7 @@ __global__ __launch_bounds__(NW * 64, PVAMD_GROUP_MINWAVES) void composed_query_
     __shared__ uint16_t sperm[N];
     __shared__ unsigned box[6];
     __shared__ unsigned wsum[NW];
-    __shared__ float wspan[NW];
+    __shared__ __attribute__((aligned(16))) float wspan[NW];
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int a = a0 + blockIdx.x;
     auto hist = [&](int bin) -> unsigned& { return reinterpret_cast<unsigned*>(res[bin >> 8])[768 + (bin & 255)]; };
@@ -1289,7 +1289,16 @@ __global__ __launch_bounds__(NW * 64, PVAMD_GROUP_MINWAVES) void composed_query_
         // kCoherentSpan of the chunk, every wave keeps its own tile and the sort -- a quarter of this kernel -- is skipped for the
         // chunk.  Block-uniform: every thread reads the same 16 spans.
         float worst_tile = 0.f;
-        for (int w = 0; w < NW; ++w) worst_tile = fmaxf(worst_tile, wspan[w]);
+        if constexpr (NW % 4 == 0) {  // four spans per LDS read
+            const f32x4_alias* w4 = reinterpret_cast<const f32x4_alias*>(wspan);
+#pragma unroll
+            for (int w = 0; w < NW / 4; ++w) {
+                const f32x4 v = w4[w];
+                worst_tile = fmaxf(worst_tile, fmaxf(fmaxf(v.x, v.y), fmaxf(v.z, v.w)));
+            }
+        } else {
+            for (int w = 0; w < NW; ++w) worst_tile = fmaxf(worst_tile, wspan[w]);
+        }
         const bool coherent = worst_tile <= kCoherentSpan * chunk_span;
         if (coherent) {
             // identity positions (each wave fills and later reads only its own 256 entries): the same leaf loop, no second copy of it
