@@ -185,9 +185,10 @@ class RobotSDF(sdf.ObjectFrameSDF):
 
     def configure_and_query_into(self, joint_config, points, out_val, out_grad):
         """A planner's inner step without host work between its two launches: joint values (A, M) float32 ALREADY ON THE GPU
-        -> pvamd_configure_chain -> pvamd_composed_query into the caller's (A, P) / (A, P, 3) buffers.  No host data, no
+        -> pvamd_configure_chain -> pvamd_composed_query into the caller's (A, P) / (A, P, 3) buffers (for large batches on small
+        link grids the query is the chunk-grouped pair, ComposedSDF.group_points: one more launch).  No host data, no
         allocation after the first call with this batch size: capturable in a hipGraph (model_to_sdf.py:82-125 as two
-        kernels).  Needs a kinematics.Chain (on-device FK) and BOUNDING_BOX CachedSDF leaves; afterwards the object is
+        or three kernels).  Needs a kinematics.Chain (on-device FK) and BOUNDING_BOX CachedSDF leaves; afterwards the object is
         configured exactly as by set_joint_configuration(joint_config)."""
         if not hasattr(self.chain, "joint_table"):
             raise ValueError("configure_and_query_into needs the on-device forward kinematics (pytorch_volumetric_amd.kinematics.Chain)")
