@@ -85,6 +85,57 @@ def test_finalize_finds_the_float32_end_points_of_the_valid_interval(rule, f64):
     assert _lib.load().pvamd_grid_finalize(ctypes.byref(desc)) < 0
 
 
+def _n2_float32(p, bb_min, bb_max):
+    """The kernels' statements in numpy float32: t = median(p - bb_min, p - bb_max, 0) per axis, n2 = fma(tz, tz, fma(ty, ty, tx * tx))
+    (the fused multiply-adds evaluated in float64 and rounded once: exact for float32 operands)."""
+    p = p.astype(np.float32)
+    d1, d2 = (p - bb_min.astype(np.float32)).astype(np.float32), (p - bb_max.astype(np.float32)).astype(np.float32)
+    t = np.where(d1 < 0, d1, np.where(d2 > 0, d2, np.float32(0))).astype(np.float32)
+    acc = (t[..., 0].astype(np.float32) * t[..., 0]).astype(np.float32)
+    acc = (t[..., 1].astype(np.float64) * t[..., 1] + acc).astype(np.float32)
+    return (t[..., 2].astype(np.float64) * t[..., 2] + acc).astype(np.float32)
+
+
+@pytest.mark.parametrize("rule,f64", itertools.product([0, ON_INDEX], [True, False]))
+def test_range_n2_bounds_every_valid_point_and_is_attained(rule, f64):
+    """pvamd_grid_t.range_n2 (round 6): the composed kernels skip the range test of a leaf visit when the squared bounding-box
+    distance n2 exceeds it.  That is exact only if NO valid point has a larger n2: checked here on 200,000 points of the valid
+    interval [vlo, vhi] (its corners, faces and random interiors) for boxes inside, touching and sticking out of the range --
+    and the bound is attained at a corner, so it is not loose either.  Host arithmetic only."""
+    rng = np.random.default_rng(7 + rule + 2 * f64)
+    for case in range(6):
+        lo = rng.uniform(-2, 2, 3)
+        ext = rng.uniform(0.2, 1.5, 3)
+        ranges = [(np.float64(a), np.float64(a + e)) if f64 else (float(a), float(a + e)) for a, e in zip(lo, ext)]
+        view = voxel.RangeView(ranges, (int(rng.integers(8, 40)), int(rng.integers(8, 40)), int(rng.integers(8, 40))), rule=rule)
+        pad = rng.uniform(-0.05, 0.3, (3, 2)) if case else np.zeros((3, 2))  # case 0: the box IS the range; negative: it sticks out
+        bb_min = (lo + pad[:, 0]).astype(np.float32)
+        bb_max = np.maximum(lo + ext - pad[:, 1], bb_min + 1e-3).astype(np.float32)
+        desc = _lib.GridDesc()
+        view.fill(desc)
+        for d in range(3):
+            desc.bb_min[d], desc.bb_max[d], desc.dbb_min[d], desc.dbb_max[d] = bb_min[d], bb_max[d], float(bb_min[d]), float(bb_max[d])
+        desc.oob_mode = _lib.OOB_BOUNDING_BOX
+        assert _lib.load().pvamd_grid_finalize(ctypes.byref(desc)) == 0
+        vlo, vhi = np.array(desc.vlo[:], np.float32), np.array(desc.vhi[:], np.float32)
+        bound = np.float32(desc.range_n2)
+        corners = np.array(list(itertools.product(*zip(vlo, vhi))), np.float32)
+        inside = (vlo + rng.random((200_000, 3)).astype(np.float32) * (vhi - vlo)).astype(np.float32)
+        inside = np.clip(inside, vlo, vhi)
+        faces = inside[:20_000].copy()
+        pick = rng.integers(0, 3, len(faces))
+        faces[np.arange(len(faces)), pick] = np.where(rng.integers(0, 2, len(faces)) == 0, vlo[pick], vhi[pick])
+        pts = np.concatenate((corners, faces, inside))
+        n2 = _n2_float32(pts, bb_min, bb_max)
+        assert (n2 <= bound).all(), (case, float(n2.max()), float(bound))
+        assert _n2_float32(corners, bb_min, bb_max).max() == bound, (case, "the bound is a corner's n2")
+    # a descriptor without a box (NaN bounds): the pre-test must never claim "out of range"
+    for d in range(3):
+        desc.bb_min[d] = desc.bb_max[d] = float("nan")
+        desc.dbb_min[d] = desc.dbb_max[d] = float("nan")
+    assert _lib.load().pvamd_grid_finalize(ctypes.byref(desc)) == 0 and desc.range_n2 == float("inf")
+
+
 # ------------------------------------------------------------------------------------------------------------- GPU
 def _spray(view, n, seed):
     """points at the places where the rules differ: exact half-voxel planes (and +- a few ulps), the range edges, half a voxel
