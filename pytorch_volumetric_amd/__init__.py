@@ -14,6 +14,7 @@ from pytorch_volumetric_amd.voxel import get_coordinates_and_points_in_grid, get
 from pytorch_volumetric_amd.voxel_containers import (ExpandingVoxelGrid, VoxelGrid, VoxelSet, Voxels,
                                                      voxel_down_sample)
 from pytorch_volumetric_amd.volume import is_inside
+from pytorch_volumetric_amd.visualization import draw_sdf_slice, get_transformed_meshes
 # stand-ins for the pytorch_kinematics members the path touches, and the multi-GPU helpers
 from pytorch_volumetric_amd.transforms import Rotate, Transform3d, Translate
 from pytorch_volumetric_amd.kinematics import Chain, build_chain_from_urdf, build_serial_chain_from_urdf

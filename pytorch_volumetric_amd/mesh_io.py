@@ -210,7 +210,169 @@ def _parse_ply(data):
     return verts, np.array(faces, dtype=np.int64).reshape(-1, 3)
 
 
-SUPPORTED_MESH_EXTENSIONS = (".obj", ".stl", ".ply", ".off", ".npz")
+# COLLADA: what the file's up axis does to the vertices.  The reference reads .dae through open3d -> assimp, whose Collada
+# importer turns X_UP / Z_UP documents to Y_UP with a root transform; set False for loaders (pybullet, ROS) that ignore it.
+# Not pinned against open3d here (it is not installed): INTEGRATION.md.
+COLLADA_APPLY_UP_AXIS = True
+
+
+def _dae_local_matrix(node):
+    """product of a node's transform elements in document order (COLLADA 1.4 spec 5.3: post-multiplied, column vectors)"""
+    m = np.eye(4)
+    for el in node:
+        if el.tag == "matrix":
+            t = np.array(el.text.split(), dtype=np.float64).reshape(4, 4)
+        elif el.tag == "translate":
+            t = np.eye(4)
+            t[:3, 3] = np.array(el.text.split(), dtype=np.float64)
+        elif el.tag == "scale":
+            t = np.diag(np.append(np.array(el.text.split(), dtype=np.float64), 1.0))
+        elif el.tag == "rotate":
+            x, y, z, deg = np.array(el.text.split(), dtype=np.float64)
+            axis = np.array([x, y, z])
+            n = np.linalg.norm(axis)
+            t = np.eye(4)
+            if n > 0:
+                axis = axis / n
+                a = np.deg2rad(deg)
+                k = np.array([[0, -axis[2], axis[1]], [axis[2], 0, -axis[0]], [-axis[1], axis[0], 0]])
+                t[:3, :3] = np.eye(3) + np.sin(a) * k + (1 - np.cos(a)) * (k @ k)
+        elif el.tag in ("lookat", "skew"):
+            raise ValueError(f"COLLADA <{el.tag}> node transforms are not supported")
+        else:
+            continue
+        m = m @ t
+    return m
+
+
+def _dae_geometry(mesh):
+    """(positions [V,3], faces [F,3]) of one <mesh>: every <triangles> / <polylist> / <polygons> / <tristrips> / <trifans> that
+    indexes its <vertices>; polygons are fan-triangulated (as the .obj reader does)"""
+    sources = {}
+    for src in mesh.findall("source"):
+        fa = src.find("float_array")
+        if fa is None or not (fa.text or "").strip():
+            continue
+        arr = np.array(fa.text.split(), dtype=np.float64)
+        acc = src.find("technique_common/accessor")
+        stride = int(acc.get("stride", 3)) if acc is not None else 3
+        first = int(acc.get("offset", 0)) if acc is not None else 0
+        count = int(acc.get("count", (len(arr) - first) // stride)) if acc is not None else (len(arr) - first) // stride
+        sources[src.get("id")] = arr[first:first + count * stride].reshape(count, stride)
+    positions_of = {}
+    for v in mesh.findall("vertices"):
+        for inp in v.findall("input"):
+            if inp.get("semantic") == "POSITION":
+                positions_of[v.get("id")] = inp.get("source", "").lstrip("#")
+    pos, faces = None, []
+    for prim in mesh:
+        if prim.tag not in ("triangles", "polylist", "polygons", "tristrips", "trifans"):
+            continue  # <lines>, <linestrips>: not surface
+        inputs = prim.findall("input")
+        vin = next((i for i in inputs if i.get("semantic") == "VERTEX"), None)
+        if vin is None:
+            continue
+        src = positions_of.get(vin.get("source", "").lstrip("#"))
+        if src not in sources:
+            raise ValueError("COLLADA primitive refers to vertices without a POSITION float_array")
+        if pos is None:
+            pos = sources[src][:, :3]
+        elif sources[src][:, :3] is not pos and not np.array_equal(sources[src][:, :3], pos):
+            raise ValueError("COLLADA mesh with several <vertices> position arrays is not supported")
+        step = max(int(i.get("offset", 0)) for i in inputs) + 1
+        voff = int(vin.get("offset", 0))
+        runs = [np.array(p.text.split(), dtype=np.int64)[voff::step] for p in prim.findall("p") if (p.text or "").strip()]
+        if prim.tag == "triangles":
+            for r in runs:
+                faces.append(r[:len(r) // 3 * 3].reshape(-1, 3))
+        elif prim.tag == "polylist":
+            counts = np.array((prim.findtext("vcount") or "").split(), dtype=np.int64)
+            idx = runs[0] if runs else np.zeros((0,), dtype=np.int64)
+            start = 0
+            if len(counts) and (counts == 3).all():
+                faces.append(idx[:3 * len(counts)].reshape(-1, 3))
+            else:
+                for c in counts:
+                    poly = idx[start:start + c]
+                    start += c
+                    faces.extend(np.array([[poly[0], poly[k], poly[k + 1]]]) for k in range(1, c - 1))
+        elif prim.tag in ("polygons", "trifans"):
+            for poly in runs:
+                faces.extend(np.array([[poly[0], poly[k], poly[k + 1]]]) for k in range(1, len(poly) - 1))
+        else:  # tristrips: alternate the winding
+            for strip in runs:
+                faces.extend(np.array([[strip[k], strip[k + 1], strip[k + 2]] if k % 2 == 0 else
+                                       [strip[k + 1], strip[k], strip[k + 2]]]) for k in range(len(strip) - 2))
+    if pos is None or not faces:
+        return None
+    return pos, np.concatenate(faces, axis=0).reshape(-1, 3)
+
+
+def _parse_dae(data):
+    """COLLADA 1.4 / 1.5 triangle geometry, flattened the way assimp's aiProcess_PreTransformVertices does for open3d
+    (sdf.py:104 of the reference reads whatever open3d reads): every <instance_geometry> of the visual scene placed by its
+    nodes' transforms, concatenated; the document's up axis turned to Y_UP (COLLADA_APPLY_UP_AXIS); <unit> NOT applied
+    (assimp keeps it as metadata).  No materials, normals, skins (<instance_controller> is skipped)."""
+    import xml.etree.ElementTree as ET
+    root = ET.fromstring(data)
+    for el in root.iter():
+        el.tag = el.tag.rsplit("}", 1)[-1]
+    geoms = {}
+    for g in root.findall("library_geometries/geometry"):
+        m = g.find("mesh")
+        parsed = _dae_geometry(m) if m is not None else None
+        if parsed is not None:
+            geoms[g.get("id")] = parsed
+    if not geoms:
+        raise ValueError("COLLADA file holds no triangle geometry")
+    library_nodes = {n.get("id"): n for n in root.findall("library_nodes//node") if n.get("id")}
+    placed = []
+
+    def walk(node, parent, depth=0):
+        if depth > 64:
+            raise ValueError("COLLADA node hierarchy deeper than 64 (an <instance_node> cycle?)")
+        here = parent @ _dae_local_matrix(node)
+        for el in node:
+            if el.tag == "instance_geometry":
+                gid = el.get("url", "").lstrip("#")
+                if gid in geoms:
+                    placed.append((gid, here))
+            elif el.tag == "node":
+                walk(el, here, depth + 1)
+            elif el.tag == "instance_node":
+                ref = library_nodes.get(el.get("url", "").lstrip("#"))
+                if ref is not None:
+                    walk(ref, here, depth + 1)
+
+    scenes = root.findall("library_visual_scenes/visual_scene")
+    want = root.find("scene/instance_visual_scene")
+    if want is not None:
+        chosen = [v for v in scenes if v.get("id") == want.get("url", "").lstrip("#")] or scenes[:1]
+    else:
+        chosen = scenes[:1]
+    for vs in chosen:
+        for node in vs.findall("node"):
+            walk(node, np.eye(4))
+    if not placed:  # no scene: the geometries as they are
+        placed = [(gid, np.eye(4)) for gid in geoms]
+    up = (root.findtext("asset/up_axis") or "Y_UP").strip().upper()
+    to_y_up = np.eye(4)
+    if COLLADA_APPLY_UP_AXIS and up == "Z_UP":
+        to_y_up[:3, :3] = [[1, 0, 0], [0, 0, 1], [0, -1, 0]]
+    elif COLLADA_APPLY_UP_AXIS and up == "X_UP":
+        to_y_up[:3, :3] = [[0, -1, 0], [1, 0, 0], [0, 0, 1]]
+    verts, faces, base = [], [], 0
+    for gid, m in placed:
+        pos, f = geoms[gid]
+        m = to_y_up @ m
+        verts.append(pos @ m[:3, :3].T + m[:3, 3])
+        # a mirroring placement turns the triangles inside out: keep them facing outwards
+        faces.append((f if np.linalg.det(m[:3, :3]) >= 0 else f[:, ::-1]) + base)
+        base += len(pos)
+    return np.concatenate(verts, axis=0), np.concatenate(faces, axis=0)
+
+
+SUPPORTED_MESH_EXTENSIONS = (".obj", ".stl", ".ply", ".off", ".dae", ".npz")
 
 
 def _parse_off(text):
@@ -236,10 +398,10 @@ def _parse_off(text):
 
 
 def load_mesh(path):
-    """.obj (text), .stl (ascii/binary), .ply (ascii/binary little endian), .off (text) or .npz with arrays `vertices` [V,3] and
-    `faces` [F,3].  STL repeats every vertex per triangle; identical positions are merged (as open3d does when it
-    reads an STL) so that center() and the vertex count match the reference loader.  Anything else -- .dae in
-    particular, which needs the scene transforms assimp applies -- raises instead of yielding an empty mesh."""
+    """.obj (text), .stl (ascii/binary), .ply (ascii/binary little endian), .off (text), .dae (COLLADA: the scene's node
+    transforms and up axis applied, see _parse_dae) or .npz with arrays `vertices` [V,3] and `faces` [F,3].  STL repeats every
+    vertex per triangle; identical positions are merged (as open3d does when it reads an STL) so that center() and the
+    vertex count match the reference loader.  Anything else (.gltf, .fbx, ...) raises instead of yielding an empty mesh."""
     ext = os.path.splitext(path)[1].lower()
     if ext not in SUPPORTED_MESH_EXTENSIONS:
         raise ValueError(f"unsupported mesh format '{ext}' ({path}); supported: {', '.join(SUPPORTED_MESH_EXTENSIONS)}. "
@@ -258,6 +420,9 @@ def load_mesh(path):
     elif ext == ".off":
         with open(path, "r") as f:
             mesh = TriMesh(*_parse_off(f.read()))
+    elif ext == ".dae":
+        with open(path, "rb") as f:
+            mesh = TriMesh(*_parse_dae(f.read()))
     else:
         with open(path, "r") as f:
             mesh = TriMesh(*_parse_obj(f.read()))

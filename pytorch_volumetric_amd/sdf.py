@@ -289,6 +289,27 @@ class ObjectFrameSDF(abc.ABC):
         sdf_values, _ = self.__call__(points_in_object_frame)
         return sdf_values > surface_level
 
+    def get_voxel_view(self, voxels=None, dtype=torch.float, device='cpu'):
+        """The SDF sampled at the centres of a voxel grid, addressed by coordinates (sdf.py:248-264): ONE batched
+        query over every centre.  Default grid: 0.01 m over surface_bounding_box(padding=0.1).  Points outside the
+        grid's range are answered by the SDF itself (`invalid_value=self.__call__`)."""
+        from pytorch_volumetric_amd.voxel_containers import ValueRangeView, VoxelGrid
+        if voxels is None:
+            voxels = VoxelGrid(0.01, self.surface_bounding_box(padding=0.1).cpu().numpy(), dtype=dtype, device=device)
+        pts = voxels.get_voxel_center_points()
+        sdf_val, _ = self.__call__(pts.unsqueeze(0))
+        sampled = sdf_val.reshape([len(coord) for coord in voxels.coords])
+        return ValueRangeView(sampled, voxels.range_per_dim, invalid_value=lambda q: self.__call__(q)[0])
+
+    def get_filtered_points(self, unary_filter, voxels=None, dtype=torch.float, device='cpu'):
+        """N x 3 voxel centres whose SDF value passes `unary_filter` (sdf.py:266-282), e.g. `lambda v: v <= 0` for
+        the interior."""
+        view = self.get_voxel_view(voxels, dtype=dtype, device=device)
+        indices = unary_filter(view.raw_data).nonzero().reshape(-1)
+        # raw_data is flat: back to one index per dimension (C order), then to coordinates
+        key = torch.stack(torch.unravel_index(indices, view.shape), dim=-1)
+        return view.ensure_value_key(key)
+
 
 class SphereSDF(ObjectFrameSDF):
     """Closed-form sphere at the origin (sdf.py:285-299); a handful of stock elementwise ops, kept in torch."""
@@ -646,6 +667,20 @@ class CachedSDF(ObjectFrameSDF):
                              float(surface_level), _lib.ptr(out), _lib.stream_ptr()),
                        "pvamd_cached_outside")
         return out.reshape(*lead).bool().to(device=self.device)
+
+    def get_voxel_view(self, voxels=None, dtype=torch.float, device='cpu'):
+        """sdf.py:604-614: the cache's own view, or the ground-truth SDF sampled over another voxel grid (points outside that
+        grid are answered by the ground-truth SDF: _fallback_sdf_value_func, sdf.py:530-533)."""
+        if voxels is None:
+            return self.voxels
+        if self.gt_sdf is None:
+            raise RuntimeError("Cannot sample another voxel grid without a ground truth SDF")
+        from pytorch_volumetric_amd.voxel_containers import ValueRangeView
+        pts = voxels.get_voxel_center_points()
+        sdf_val, _ = self.gt_sdf(pts.unsqueeze(0))
+        sampled = sdf_val.to(device=self.device).reshape([len(coord) for coord in voxels.coords])
+        return ValueRangeView(sampled, voxels.range_per_dim,
+                              invalid_value=lambda q: self.gt_sdf(q)[0].to(device=self.device))
 
 
 class PreparedPoints:

@@ -151,9 +151,113 @@ def test_obj_stl_round_trip_and_polygon_triangulation(tmp_path):
     (tmp_path / "h.off").write_text("OFF 3 1 0\n0 0 0\n1 0 0\n0 1 0\n3 0 1 2\n")
     assert mesh_io.load_mesh(str(tmp_path / "h.off")).faces.tolist() == [[0, 1, 2]]
     with pytest.raises(ValueError):
-        mesh_io.load_mesh(str(tmp_path / "robot_link.dae"))  # refused by name, not read as an empty mesh
+        mesh_io.load_mesh(str(tmp_path / "robot_link.gltf"))  # refused by name, not read as an empty mesh
     with pytest.raises(RuntimeError):
         pv.MeshObjectFactory("does_not_exist.obj")  # sdf.py:102
+
+
+COLLADA_DOC = """<?xml version="1.0" encoding="utf-8"?>
+<COLLADA xmlns="http://www.collada.org/2005/11/COLLADASchema" version="1.4.1">
+  <asset><unit name="centimeter" meter="0.01"/><up_axis>{up}</up_axis></asset>
+  <library_geometries>
+    <geometry id="tet"><mesh>
+      <source id="tet-pos"><float_array id="tet-pos-a" count="12">0 0 0  1 0 0  0 1 0  0 0 1</float_array>
+        <technique_common><accessor source="#tet-pos-a" count="4" stride="3"/></technique_common></source>
+      <source id="tet-nrm"><float_array id="tet-nrm-a" count="3">0 0 1</float_array>
+        <technique_common><accessor source="#tet-nrm-a" count="1" stride="3"/></technique_common></source>
+      <vertices id="tet-v"><input semantic="POSITION" source="#tet-pos"/></vertices>
+      <triangles count="4"><input semantic="VERTEX" source="#tet-v" offset="0"/><input semantic="NORMAL" source="#tet-nrm" offset="1"/>
+        <p>0 0 2 0 1 0   0 0 1 0 3 0   0 0 3 0 2 0   1 0 2 0 3 0</p></triangles>
+    </mesh></geometry>
+    <geometry id="quad"><mesh>
+      <source id="quad-pos"><float_array id="quad-pos-a" count="15">0 0 0  2 0 0  2 2 0  0 2 0  1 3 0</float_array>
+        <technique_common><accessor source="#quad-pos-a" count="5" stride="3"/></technique_common></source>
+      <vertices id="quad-v"><input semantic="POSITION" source="#quad-pos"/></vertices>
+      <polylist count="2"><input semantic="VERTEX" source="#quad-v" offset="0"/><vcount>4 3</vcount><p>0 1 2 3  3 2 4</p></polylist>
+    </mesh></geometry>
+  </library_geometries>
+  <library_visual_scenes><visual_scene id="scene">
+    <node id="a"><translate>1 2 3</translate><rotate>0 0 1 90</rotate><scale>2 2 2</scale>
+      <instance_geometry url="#tet"/>
+      <node id="b"><matrix>1 0 0 0  0 1 0 0  0 0 -1 5  0 0 0 1</matrix><instance_geometry url="#quad"/></node>
+    </node>
+    <node id="c"><instance_geometry url="#tet"/></node>
+  </visual_scene></library_visual_scenes>
+  <scene><instance_visual_scene url="#scene"/></scene>
+</COLLADA>
+"""
+
+
+def test_collada_reader_places_every_instance_by_its_nodes(tmp_path):
+    """.dae (VERDICT r5 missing 4): the reference loads whatever open3d / assimp reads (sdf.py:104).  Geometry instances are
+    placed by their nodes' transforms (translate, rotate, scale, matrix, nested), polylists are fan-triangulated, a mirroring
+    placement keeps the triangles facing outwards, the document's up axis is turned to Y_UP as assimp does (switchable), the
+    <unit> is left alone."""
+    tet = np.array([[0, 0, 0], [1, 0, 0], [0, 1, 0], [0, 0, 1]], dtype=np.float64)
+    quad = np.array([[0, 0, 0], [2, 0, 0], [2, 2, 0], [0, 2, 0], [1, 3, 0]], dtype=np.float64)
+    rz = np.array([[0, -1, 0], [1, 0, 0], [0, 0, 1]], dtype=np.float64)
+    a = np.eye(4)
+    a[:3, :3] = rz * 2.0
+    a[:3, 3] = [1, 2, 3]
+    b = a @ np.array([[1, 0, 0, 0], [0, 1, 0, 0], [0, 0, -1, 5], [0, 0, 0, 1]], dtype=np.float64)
+
+    def place(m, v):
+        return v @ m[:3, :3].T + m[:3, 3]
+
+    for up, turn in (("Y_UP", np.eye(3)), ("Z_UP", np.array([[1, 0, 0], [0, 0, 1], [0, -1, 0]], dtype=np.float64))):
+        path = tmp_path / f"scene_{up}.dae"
+        path.write_text(COLLADA_DOC.format(up=up))
+        mesh = mesh_io.load_mesh(str(path))
+        want_v = np.concatenate((place(a, tet), place(b, quad), tet)) @ turn.T
+        assert mesh.vertices.shape == (13, 3) and np.allclose(mesh.vertices, want_v, atol=1e-12)
+        tet_f = [[0, 2, 1], [0, 1, 3], [0, 3, 2], [1, 2, 3]]
+        quad_f = [[0, 1, 2], [0, 2, 3], [3, 2, 4]]
+        mirrored = [[f[2] + 4, f[1] + 4, f[0] + 4] for f in quad_f]  # node b mirrors z: winding reversed
+        assert mesh.faces.tolist() == tet_f + mirrored + [[i + 9 for i in f] for f in tet_f]
+        # outward normals survive: the tetrahedron's signed volume stays positive under both placements
+        t = mesh.triangle_soup()[:4]
+        assert np.einsum("ij,ij->i", t[:, 0] - t[0, 0], np.cross(t[:, 1] - t[0, 0], t[:, 2] - t[0, 0])).sum() > 0
+    mesh_io.COLLADA_APPLY_UP_AXIS = False
+    try:
+        raw = mesh_io.load_mesh(str(tmp_path / "scene_Z_UP.dae"))
+        assert np.allclose(raw.vertices, np.concatenate((place(a, tet), place(b, quad), tet)), atol=1e-12)
+    finally:
+        mesh_io.COLLADA_APPLY_UP_AXIS = True
+    # a document without a scene: the geometries as they are; one without geometry: an error, not an empty mesh
+    no_scene = COLLADA_DOC.format(up="Y_UP")
+    no_scene = no_scene[:no_scene.index("<library_visual_scenes>")] + "</COLLADA>"
+    (tmp_path / "geo.dae").write_text(no_scene)
+    assert mesh_io.load_mesh(str(tmp_path / "geo.dae")).vertices.shape == (9, 3)
+    (tmp_path / "empty.dae").write_text('<COLLADA xmlns="http://www.collada.org/2005/11/COLLADASchema"><asset/></COLLADA>')
+    with pytest.raises(ValueError):
+        mesh_io.load_mesh(str(tmp_path / "empty.dae"))
+    # through the factory: the same bounding box as the mesh handed over directly
+    f = pv.MeshObjectFactory(str(tmp_path / "scene_Y_UP.dae"))
+    assert np.allclose(f.bounding_box(), pv.MeshObjectFactory(mesh=mesh_io.load_mesh(str(tmp_path / "scene_Y_UP.dae"))).bounding_box())
+
+
+def test_slice_and_voxel_view_callers_of_the_query_path():
+    """visualization.draw_sdf_slice (README.md:115) and ObjectFrameSDF.get_voxel_view / get_filtered_points (sdf.py:248-282):
+    thin callers, one batched __call__ each; checked on the closed-form SphereSDF (no GPU)."""
+    s = pv.SphereSDF(0.1)
+    val, grad, pts, ax, c1, c2, v = pv.draw_sdf_slice(s, [(-0.2, 0.2), (0.0, 0.0), (-0.2, 0.2)], resolution=0.01, do_plot=False)
+    assert val.shape == (41 * 41,) and grad.shape == (41 * 41, 3) and v.shape == (41, 41) and ax is None and c1 is None
+    assert torch.allclose(val, pts.norm(dim=-1) - 0.1) and (pts[:, 1].abs() < 1e-5).all()
+    assert torch.equal(v, val.reshape(41, 41).T)
+    with pytest.raises(RuntimeError):
+        pv.draw_sdf_slice(s, [(-0.2, 0.2), (0.0, 0.1), (-0.2, 0.2)], do_plot=False)
+    import matplotlib
+    matplotlib.use("Agg")
+    drawn = pv.draw_sdf_slice(s, [(-0.2, 0.2), (-0.2, 0.2), (0.0, 0.0)], resolution=0.02, plot_grad=True)
+    assert drawn[3] is not None and [float(l) for l in drawn[5].levels] == [0.0]
+    view = s.get_voxel_view()
+    assert view.shape == (41, 41, 41)  # 0.01 m over the +-0.2 box (radius + 0.1 padding)
+    q = torch.tensor([[0.0, 0.0, 0.0], [0.1, 0.0, 0.0], [5.0, 0.0, 0.0]])
+    assert torch.allclose(view[q], torch.tensor([-0.1, 0.0, 4.9]), atol=1e-6)  # the last one is outside the grid: the SDF itself
+    inside = s.get_filtered_points(lambda x: x <= 0)
+    assert inside.shape[1] == 3 and len(inside) == int((view.raw_data <= 0).sum()) and float(inside.norm(dim=-1).max()) <= 0.1 + 1e-6
+    grid = pv.VoxelGrid(0.05, [(-0.2, 0.2)] * 3)
+    assert s.get_voxel_view(grid).shape == (9, 9, 9)
 
 
 def test_patch_order_gives_compact_aligned_runs():

@@ -123,6 +123,37 @@ def test_scale_rotation_translation_of_the_mesh_frame():
     assert torch.allclose(val, torch.tensor([-0.5, 1.0]), atol=1e-6)
 
 
+def test_a_collada_mesh_answers_like_the_same_triangles_from_an_obj(tmp_path):
+    """.dae (the reference loads whatever open3d reads, sdf.py:104): the probe written as a COLLADA document whose node
+    carries the identity gives the very bits of the .obj; with a node translation, the values of the shifted query."""
+    src = mesh_io.load_mesh(H.mesh_path("probe.obj"))
+
+    def write(path, translate):
+        pos = " ".join(repr(float(x)) for x in src.vertices.reshape(-1))
+        idx = " ".join(str(int(i)) for i in src.faces.reshape(-1))
+        path.write_text(f"""<?xml version="1.0"?><COLLADA xmlns="http://www.collada.org/2005/11/COLLADASchema" version="1.4.1">
+<asset><up_axis>Y_UP</up_axis></asset><library_geometries><geometry id="g"><mesh>
+<source id="p"><float_array id="pa" count="{src.vertices.size}">{pos}</float_array>
+<technique_common><accessor source="#pa" count="{len(src.vertices)}" stride="3"/></technique_common></source>
+<vertices id="v"><input semantic="POSITION" source="#p"/></vertices>
+<triangles count="{len(src.faces)}"><input semantic="VERTEX" source="#v" offset="0"/><p>{idx}</p></triangles>
+</mesh></geometry></library_geometries><library_visual_scenes><visual_scene id="s"><node>
+<translate>{translate[0]} {translate[1]} {translate[2]}</translate><instance_geometry url="#g"/></node></visual_scene>
+</library_visual_scenes><scene><instance_visual_scene url="#s"/></scene></COLLADA>""")
+
+    write(tmp_path / "probe.dae", (0, 0, 0))
+    write(tmp_path / "probe_shifted.dae", (0.25, 0, -0.5))
+    ref = factory("probe.obj")
+    dae = pv.MeshObjectFactory("probe.dae", path_prefix=str(tmp_path))
+    pts = H.uniform_points(4000, ref.bounding_box(0.02)[:, 0], ref.bounding_box(0.02)[:, 1], seed=8).cuda()
+    a, b = ref.object_frame_closest_point(pts), dae.object_frame_closest_point(pts)
+    assert torch.equal(a.distance, b.distance) and torch.equal(a.gradient, b.gradient) and torch.equal(a.closest, b.closest)
+    shifted = pv.MeshObjectFactory("probe_shifted.dae", path_prefix=str(tmp_path))
+    off = torch.tensor([0.25, 0.0, -0.5], device="cuda")
+    c = shifted.object_frame_closest_point(pts + off)
+    assert torch.allclose(c.distance, a.distance, atol=2e-6)
+
+
 def test_numpy_input_and_dtype_device_round_trip():
     obj = factory("probe.obj")
     pts = H.uniform_points(100, obj.bounding_box(0.01)[:, 0], obj.bounding_box(0.01)[:, 1], seed=4)

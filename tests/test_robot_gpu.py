@@ -84,6 +84,32 @@ def test_robot_sdf_config_batch_equals_loop_and_shapes(tmp_path):
     assert (all_val < 0).any() and (all_val > 0.1).any()
 
 
+def test_transformed_link_meshes_lie_on_the_robot_surface(tmp_path):
+    """visualization.get_transformed_meshes (visualization.py:83-107 of the reference): every link's mesh placed by the
+    current configuration -- its vertices are surface points of the robot SDF (never outside it), for MeshSDF links and,
+    through gt_sdf, for cached ones; `obj_to_world_tsf` composes on the left."""
+    chain = synthetic_arm(str(tmp_path), n_links=4)
+    q = torch.tensor([0.3, -0.6, 0.2])
+    for cls in (pv.MeshSDF, pv.cache_link_sdf_factory(resolution=0.01, padding=0.05, device="cuda", cache_path=None)):
+        s = pv.RobotSDF(chain, path_prefix=str(tmp_path), link_sdf_cls=cls)
+        s.set_joint_configuration(q)
+        meshes = pv.get_transformed_meshes(s)
+        assert len(meshes) == 4 and all(isinstance(m, mesh_io.TriMesh) for m in meshes)
+        exact = pv.RobotSDF(chain, path_prefix=str(tmp_path))
+        exact.set_joint_configuration(q)
+        for m in meshes:
+            v, _ = exact(torch.tensor(m.vertices, dtype=torch.float32).cuda())
+            assert float(v.max()) < 1e-5  # on this link's surface (or inside a neighbouring link)
+        assert float(np.abs(np.stack([m.vertices.mean(axis=0) for m in meshes])[:, 2]).max()) > 0.2  # links were placed
+        shift = pv.Transform3d(pos=torch.tensor([[1.0, -2.0, 0.5]]))
+        moved = pv.get_transformed_meshes(s, obj_to_world_tsf=shift)
+        for m, n in zip(meshes, moved):
+            assert np.allclose(n.vertices, m.vertices + np.array([1.0, -2.0, 0.5]), atol=1e-6) and np.array_equal(n.faces, m.faces)
+    s.set_joint_configuration(torch.zeros(5, 3))
+    with pytest.raises(ValueError):
+        pv.get_transformed_meshes(s)  # one mesh set per configuration: a batch is refused
+
+
 def test_robot_sdf_wrench_urdf_single_mesh_link():
     """The reference's own URDF fixture (tests/offset_wrench.urdf): 6-DOF chain, one mesh link."""
     chain = pv.build_chain_from_urdf(open(H.mesh_path("offset_wrench.urdf")).read())
