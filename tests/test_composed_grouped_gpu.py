@@ -37,7 +37,7 @@ def same_bits(a, b):
     return np.array_equal(a.view(np.int32), b.view(np.int32))
 
 
-@pytest.mark.parametrize("S,A,P", [(8, 3, 4096), (8, 2, 4097), (8, 5, 12_345), (3, 7, 8191), (1, 2, 4096), (20, 2, 5000)])
+@pytest.mark.parametrize("S,A,P", [(8, 3, 4096), (8, 2, 4097), (8, 5, 12_345), (3, 7, 8191), (1, 2, 4096), (20, 2, 5000), (64, 2, 4500), (70, 1, 4096)])
 def test_grouped_matches_the_oracle_and_the_ungrouped_kernels_bitwise(S, A, P):
     """Any P >= one chunk (a ragged end: the last chunk is moved back and overlaps its neighbour), mixed float64 / float32 index
     arithmetic per leaf, odd row starts of the (A, P) outputs."""
