@@ -83,3 +83,24 @@ if "c4" in which:
             lib.pvamd_composed_query_grouped(_lib.ptr(grids), 8, _lib.ptr(tfd), A, _lib.ptr(scratch), P, _lib.ptr(val), _lib.ptr(grad), None, 0, _lib.stream_ptr())
         return call
     compare("C4 200 x 262144", c4_call)
+if "rg" in which:  # README-size link grids (8 x 21 MB): Hilbert-sorted random points, and the README's own slice
+    import numpy as np
+    robot = Wk.build_c4(0.02, 1.0)
+    A, P = 200, 1 << 18
+    robot.set_joint_configuration(Wk.c4_joint_configs(A))
+    comp = robot.sdf
+    pts = Wk.c4_points(P)
+    prep = comp.prepare_points(pts)
+    spts = prep.sorted_points.contiguous()
+    grids = comp._leaf_grids(pts.device); tfd = comp._tf_device(pts.device)
+    flags = comp._query_flags | _lib.COMPOSED_NO_GROUPING
+    val = torch.empty((A, P), device="cuda"); grad = torch.empty((A, P, 3), device="cuda")
+    compare(f"README grids, 200 x 262144 sorted (flags {flags})", lambda lib: (lambda: lib.pvamd_composed_query(_lib.ptr(grids), 8, _lib.ptr(tfd), A, _lib.ptr(spts), P, _lib.ptr(val), _lib.ptr(grad), None, flags, _lib.stream_ptr())))
+    compare("README grids, 200 x 262144 random", lambda lib: (lambda: lib.pvamd_composed_query(_lib.ptr(grids), 8, _lib.ptr(tfd), A, _lib.ptr(pts), P, _lib.ptr(val), _lib.ptr(grad), None, flags, _lib.stream_ptr())))
+    _, sl = pv.get_coordinates_and_points_in_grid(0.01, np.array([[-1, 0.5], [0.02, 0.02], [-0.2, 0.8]]))
+    sl = sl.cuda().contiguous()
+    Ps = sl.shape[0]
+    for A2 in (20, 200):
+        robot.set_joint_configuration(Wk.c4_joint_configs(A2))
+        tfd2 = comp._tf_device(sl.device)
+        compare(f"README slice {A2} x {Ps}", lambda lib: (lambda: lib.pvamd_composed_query(_lib.ptr(grids), 8, _lib.ptr(tfd2), A2, _lib.ptr(sl), Ps, _lib.ptr(val), _lib.ptr(grad), None, flags, _lib.stream_ptr())))
