@@ -1201,15 +1201,20 @@ class ComposedSDF(ObjectFrameSDF):
                 # allocated after the first call of a size, so a captured graph replays both
                 lib = _lib.load()
                 need = int(lib.pvamd_group_scratch_bytes(P))
-                # one buffer per (point count, device, stream): two streams querying the same object never share a scratch
-                # (at most 8 are remembered)
+                # one buffer per (point count, device, stream): two streams querying the same object never share a scratch.
+                # At most 8 are remembered -- except those a stream capture has seen: a captured graph replays with the
+                # buffer's address, so such a buffer lives as long as this object
                 table = self.__dict__.setdefault("_group_scratch", {})
                 key = (need, str(dev), _lib.stream_ptr().value or 0)
-                scratch = table.get(key)
-                if scratch is None:
-                    if len(table) >= 8:
-                        table.pop(next(iter(table)))
-                    scratch = table[key] = torch.empty((need,), dtype=torch.uint8, device=dev)
+                entry = table.get(key)
+                if entry is None:
+                    loose = [k for k, e in table.items() if not e[1]]
+                    if len(loose) >= 8:
+                        table.pop(loose[0])
+                    entry = table[key] = [torch.empty((need,), dtype=torch.uint8, device=dev), False]
+                if not entry[1] and torch.cuda.is_current_stream_capturing():
+                    entry[1] = True
+                scratch = entry[0]
                 _lib.check(lib.pvamd_group_points(_lib.ptr(points), P, _lib.ptr(scratch), _lib.stream_ptr()), "pvamd_group_points")
                 _lib.check(lib.pvamd_composed_query_grouped(_lib.ptr(grids), len(self.sdfs), _lib.ptr(self._tf_device(dev)), A,
                                                             _lib.ptr(scratch), P, _lib.ptr(out_val), _lib.ptr(out_grad), None,

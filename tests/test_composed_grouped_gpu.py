@@ -171,6 +171,41 @@ def test_query_into_grouped_at_odd_addresses_and_replayed_from_a_graph():
     assert np.array_equal(gview.cpu().numpy(), ograd, equal_nan=True)
 
 
+def test_a_captured_graph_keeps_its_scratch_while_other_sizes_come_and_go():
+    """query_into remembers one scratch buffer per point count (8 at most) -- but a buffer a stream capture has seen belongs to
+    a graph that replays with its address: ten other sizes later the first graph still answers correctly."""
+    S, A = 4, 3
+    chunk = _lib.group_chunk_points()
+    comp, leaves, tfm = composed(S, A, seed=9)
+    comp.group_points = True
+    ogrids = [H.oracle_grid_from_cached(l) for l in leaves]
+    P0 = chunk + 33
+    pts0 = scene_points(P0, seed=3, extent=0.6).cuda()
+    val0, grad0 = torch.empty((A, P0), device="cuda"), torch.empty((A, P0, 3), device="cuda")
+    g = torch.cuda.CUDAGraph()
+    side = torch.cuda.Stream()
+    with torch.cuda.stream(side):
+        comp.query_into(pts0, val0, grad0)
+        with torch.cuda.graph(g, stream=side):
+            comp.query_into(pts0, val0, grad0)
+    torch.cuda.synchronize()
+    with torch.cuda.stream(side):  # the other sizes on the SAME stream: same table keys apart from the size
+        for i in range(10):
+            P = chunk + 100 * (i + 1)
+            p = scene_points(P, seed=20 + i, extent=0.6).cuda()
+            v, gr = torch.empty((A, P), device="cuda"), torch.empty((A, P, 3), device="cuda")
+            comp.query_into(p, v, gr)
+            v.fill_(float("nan"))  # and the freed buffers get reused by these allocations
+    torch.cuda.synchronize()
+    table = comp.__dict__["_group_scratch"]
+    assert sum(1 for e in table.values() if e[1]) == 1 and sum(1 for e in table.values() if not e[1]) <= 8
+    val0.fill_(-1.0)
+    g.replay()
+    torch.cuda.synchronize()
+    oval, ograd, _ = oracle.composed_query(ogrids, tfm.numpy(), A, pts0.cpu().numpy())
+    assert np.array_equal(val0.cpu().numpy(), oval, equal_nan=True) and np.array_equal(grad0.cpu().numpy(), ograd, equal_nan=True)
+
+
 def test_auto_takes_the_grouped_kernel_only_in_its_regime():
     comp, _, _ = composed(2, 2, seed=1)
     chunk = _lib.group_chunk_points()
