@@ -96,6 +96,57 @@ def test_cube_closed_form():
     assert ((grad.cpu()[face_region] - expect[face_region]).abs().amax(dim=-1).double() < 3e-6 / ref[face_region].abs()).all()
 
 
+def _box_sdf(p, centre, half):
+    q = (p - torch.tensor(centre, dtype=torch.float64)).abs() - torch.tensor(half, dtype=torch.float64)
+    return torch.linalg.norm(q.clamp(min=0), dim=-1) + q.max(dim=-1).values.clamp(max=0)
+
+
+@pytest.mark.parametrize("scene,z0", [("scene_mesh_separated.obj", 0.053449), ("scene_mesh_overlap.obj", -0.046147),
+                                      ("scene_mesh_wrong.obj", 0.0), ("scene_mesh_gt.obj", 0.0)])
+def test_reference_debug_scene_slices(scene, z0):
+    """tests/pv_sdf_debug/test_export_composed_sdf.py of the reference, headless: the y = 0 slice (its query_range, through
+    draw_sdf_slice) of MeshSDF over its four two-box scenes -- a slab B = [-0.3, 1.2] x [-0.4, 0.4] x [-0.2, 0] and a box
+    A = [0.4, 1.2] x [-0.4, 0.4] x [z0, z0 + 0.2] above it: apart, overlapping, touching as two closed surfaces ("wrong": the
+    shared face stays inside the solid) and touching as one proper union ("gt").  Bit for bit what the oracle's double loop gives,
+    and the closed forms where they exist: outside both boxes every scene is min(box A, box B); the overlap of two closed
+    surfaces reads as OUTSIDE (two ray hits: even parity, sdf.py:147-157); the doubled face of "wrong" pulls interior values
+    to zero where "gt" keeps the true depth."""
+    torch.manual_seed(0)  # draw_sdf_slice jitters the grid by 1e-6 from the global generator, as the reference does
+    obj = factory(scene)
+    sdf = pv.MeshSDF(obj)
+    query_range = np.array([[-0.5, 2], [0, 0], [-0.2, 0.3]])
+    val, grad, pts, ax, _, _, v = pv.draw_sdf_slice(sdf, query_range, device="cuda", do_plot=False)
+    assert val.shape == (251 * 51,) and v.shape == (51, 251) and ax is None
+    d = assert_query_matches(obj, pts.cpu(), seed=0)
+    assert np.array_equal(d, val.cpu().numpy())
+    p = pts.cpu().double()
+    a = _box_sdf(p, (0.8, 0.0, z0 + 0.1), (0.4, 0.4, 0.1))
+    b = _box_sdf(p, (0.45, 0.0, -0.1), (0.75, 0.4, 0.1))
+    both = torch.minimum(a, b)
+    got = val.cpu().double()
+    clear = (a.abs() > 1e-4) & (b.abs() > 1e-4)  # a 1e-6 jitter decides the side of points on a face
+    outside = (a > 0) & (b > 0) & clear
+    assert outside.sum() > 5000 and (got[outside] - both[outside]).abs().max() < 1e-6
+    in_a, in_b = (a < 0) & clear, (b < 0) & clear
+    if scene == "scene_mesh_separated.obj":
+        assert (got[clear] - both[clear]).abs().max() < 1e-6  # disjoint solids: the union's SDF everywhere
+    elif scene == "scene_mesh_overlap.obj":
+        inside_both = in_a & in_b
+        assert inside_both.sum() > 100 and (got[inside_both] > 0).all()  # even parity: the reference's known artefact
+        assert torch.allclose(got[inside_both], torch.minimum(a.abs(), b.abs())[inside_both], atol=1e-6)
+        once = (in_a ^ in_b)
+        assert (got[once] < 0).all() and torch.allclose(got[once].abs(), torch.minimum(a.abs(), b.abs())[once], atol=1e-6)
+    else:
+        inside = in_a | in_b
+        assert (got[inside] < 0).all()
+        if scene == "scene_mesh_wrong.obj":
+            assert torch.allclose(got[inside], both[inside], atol=1e-6)  # every face counts, the buried one too
+        else:
+            assert (got[inside] <= both[inside] + 1e-6).all()
+            near_seam = inside & (p[:, 0] > 0.6) & (p[:, 0] < 1.0) & (p[:, 2].abs() < 0.02)
+            assert near_seam.sum() > 50 and (got[near_seam] < both[near_seam] - 0.05).all()  # true depth, no seam at z = 0
+
+
 @pytest.mark.parametrize("mesh", ["probe.obj", "offset_wrench_nogrip.obj"])
 def test_surface_points_have_zero_distance_and_batch_dims(mesh):
     """The reference's own assertions (tests/test_sdf.py:18-29)."""
