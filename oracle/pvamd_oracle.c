@@ -33,24 +33,7 @@
 #include <omp.h>
 #endif
 
-/* ------------------------------------------------------------------------------------------------------------
- * Grid description used by the oracle: the reference's OWN layout (separate val [nx,ny,nz] and grad [n,3]
- * arrays, sdf.py:504-505,521-523), not the packed layout of the product.
- * ---------------------------------------------------------------------------------------------------------- */
-typedef struct oracle_grid {
-    const float* val;   /* [nx*ny*nz]      */
-    const float* grad;  /* [nx*ny*nz][3]   */
-    double dmin[3], dmax[3], dres[3];
-    float fmin[3], fmax[3], fres[3];
-    float bb_min[3], bb_max[3];
-    int32_t shape[3];
-    int32_t index_f64;
-    int32_t oob_mode; /* 0 LOOKUP_GT_SDF (zeros + mask), 1 BOUNDING_BOX */
-    int32_t rule;     /* which of the UNPINNED choices of the third-party view to restate (include/pvamd.h PVAMD_RULE_*):
-                         0 = round half to even + validity on the value; 1 validity on the rounded index; 2 round half away
-                         from zero; 4 floor(q + 0.5); 8 (host side only) resolution of a float32 range evaluated in float64 */
-    double dbb_min[3], dbb_max[3]; /* the bounding box as float64: what sdf.py:556-557 casts self.bb to for float64 queries */
-} oracle_grid_t;
+#include "pvamd_oracle.h" /* oracle_grid_t: the reference's OWN layout (separate val and grad arrays), and the prototypes a C checker uses */
 
 int oracle_num_threads(void) {
 #ifdef _OPENMP

@@ -1,0 +1,30 @@
+/* CPU oracle -- TEST INFRASTRUCTURE, not part of the product (see pvamd_oracle.c).  The grid description and the entry points a
+ * plain-C checker links against (tests/cabi/cabi_check.c); the Python binding (oracle/oracle.py) mirrors the same layout. */
+#ifndef PVAMD_ORACLE_H
+#define PVAMD_ORACLE_H
+#include <stdint.h>
+
+/* ------------------------------------------------------------------------------------------------------------
+ * Grid description used by the oracle: the reference's OWN layout (separate val [nx,ny,nz] and grad [n,3]
+ * arrays, sdf.py:504-505,521-523), not the packed layout of the product.
+ * ---------------------------------------------------------------------------------------------------------- */
+typedef struct oracle_grid {
+    const float* val;   /* [nx*ny*nz]      */
+    const float* grad;  /* [nx*ny*nz][3]   */
+    double dmin[3], dmax[3], dres[3];
+    float fmin[3], fmax[3], fres[3];
+    float bb_min[3], bb_max[3];
+    int32_t shape[3];
+    int32_t index_f64;
+    int32_t oob_mode; /* 0 LOOKUP_GT_SDF (zeros + mask), 1 BOUNDING_BOX */
+    int32_t rule;     /* which of the UNPINNED choices of the third-party view to restate (include/pvamd.h PVAMD_RULE_*):
+                         0 = round half to even + validity on the value; 1 validity on the rounded index; 2 round half away
+                         from zero; 4 floor(q + 0.5); 8 (host side only) resolution of a float32 range evaluated in float64 */
+    double dbb_min[3], dbb_max[3]; /* the bounding box as float64: what sdf.py:556-557 casts self.bb to for float64 queries */
+} oracle_grid_t;
+
+void oracle_cached_query(const oracle_grid_t* g, const float* pts, int64_t P, float* out_val, float* out_grad, uint8_t* out_oob);
+void oracle_voxel_index(const oracle_grid_t* g, const float* pts, int64_t P, int64_t* out_key, int64_t* out_flat, uint8_t* out_valid);
+void oracle_composed_query(const oracle_grid_t* grids, int32_t S, const float* tf, int32_t A, const float* pts, int64_t P,
+                           float* out_val, float* out_grad, int32_t* out_leaf);
+#endif

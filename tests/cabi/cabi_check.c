@@ -1,6 +1,7 @@
 /* Plain-C host program over include/pvamd.h: no Python, no torch.  Builds a small voxel cache, runs
- * pvamd_grid_finalize / pvamd_pack_grid / pvamd_cached_query / pvamd_voxel_index on hipMalloc'ed buffers and compares
- * every output with the CPU oracle linked next to it.  Exit code 0 = bit-exact.  (tests/test_cabi_gpu.py builds and
+ * pvamd_grid_finalize / pvamd_pack_grid / pvamd_cached_query / pvamd_voxel_index on hipMalloc'ed buffers, then the composed
+ * query three ways (pvamd_composed_query, its in-workgroup regrouping forced, pvamd_group_points + pvamd_composed_query_grouped
+ * over scratch the host sized with pvamd_group_scratch_bytes), and compares every output with the CPU oracle linked next to it.  Exit code 0 = bit-exact.  (tests/test_cabi_gpu.py builds and
  * runs it; it doubles as the example a non-Python host language would follow.) */
 #include <hip/hip_runtime_api.h>
 #include <math.h>
@@ -9,16 +10,7 @@
 #include <string.h>
 #include "pvamd.h"
 
-/* the oracle's grid layout (oracle/pvamd_oracle.c) */
-typedef struct oracle_grid {
-    const float* val; const float* grad;
-    double dmin[3], dmax[3], dres[3];
-    float fmin[3], fmax[3], fres[3];
-    float bb_min[3], bb_max[3];
-    int32_t shape[3]; int32_t index_f64; int32_t oob_mode; int32_t reserved;
-} oracle_grid_t;
-void oracle_cached_query(const oracle_grid_t*, const float*, int64_t, float*, float*, uint8_t*);
-void oracle_voxel_index(const oracle_grid_t*, const float*, int64_t, int64_t*, int64_t*, uint8_t*);
+#include "pvamd_oracle.h" /* the oracle's grid layout and entry points (oracle/) */
 
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %d at line %d\n", (int)e_, __LINE__); return 2; } } while (0)
 #define CKP(x) do { int r_ = (x); if (r_ != 0) { printf("pvamd error %d at line %d\n", r_, __LINE__); return 3; } } while (0)
@@ -42,6 +34,7 @@ int main(void) {
         g.fmin[d] = o.fmin[d] = (float)g.dmin[d]; g.fmax[d] = o.fmax[d] = (float)g.dmax[d];
         g.fres[d] = o.fres[d] = (g.fmax[d] - g.fmin[d]) / (float)(shape[d] - 1);
         g.bb_min[d] = o.bb_min[d] = (float)(lo[d] + 0.08); g.bb_max[d] = o.bb_max[d] = (float)(g.dmax[d] - 0.08);
+        o.dbb_min[d] = o.bb_min[d]; o.dbb_max[d] = o.bb_max[d];
     }
     for (int64_t i = 0; i < P; ++i) for (int d = 0; d < 3; ++d)
         pts[3 * i + d] = (float)(g.dmin[d] - 0.06 + frand(&seed) * (g.dmax[d] - g.dmin[d] + 0.12));
@@ -79,6 +72,67 @@ int main(void) {
         printf("index_f64=%d oob_mode=%d: %lld points, %lld out of range, %lld mismatches\n", f64, mode, (long long)P,
                (long long)noob, (long long)mism);
         bad += mism != 0;
+    }
+    /* ---- ComposedSDF.__call__ (sdf.py:392-433): S leaves sharing the cache above under S x A rigid transforms ----
+     * pvamd_composed_query as it picks its kernel, the same with the in-workgroup regrouping forced, and the pre-pass pair
+     * pvamd_group_points + pvamd_composed_query_grouped over caller-provided scratch: all three against the oracle. */
+    {
+        enum { S = 5, A = 3 };
+        const int64_t Pc = 3 * pvamd_group_chunk_points() + 777; /* a ragged last chunk */
+        g.index_f64 = o.index_f64 = 0; g.oob_mode = o.oob_mode = PVAMD_OOB_BOUNDING_BOX; g.finalized = 0;
+        CKP(pvamd_grid_finalize(&g));
+        pvamd_grid_t gs[S]; oracle_grid_t os[S];
+        for (int s2 = 0; s2 < S; ++s2) { gs[s2] = g; os[s2] = o; }
+        float tf[S * A * 16];
+        for (int k = 0; k < S * A; ++k) { /* rotation about a seeded axis (Rodrigues) + translation, row-major 4x4 */
+            float ax[3] = {frand(&seed) - 0.5f, frand(&seed) - 0.5f, frand(&seed) - 0.5f};
+            const float nrm = sqrtf(ax[0] * ax[0] + ax[1] * ax[1] + ax[2] * ax[2]) + 1e-9f, th = 3.0f * frand(&seed);
+            for (int d = 0; d < 3; ++d) ax[d] /= nrm;
+            const float c = cosf(th), sn = sinf(th), K[9] = {0, -ax[2], ax[1], ax[2], 0, -ax[0], -ax[1], ax[0], 0};
+            float* M = tf + 16 * k; memset(M, 0, 64); M[15] = 1.f;
+            for (int r = 0; r < 3; ++r) for (int q = 0; q < 3; ++q)
+                M[4 * r + q] = (r == q ? c : 0.f) + sn * K[3 * r + q] + (1.f - c) * ax[r] * ax[q];
+            for (int r = 0; r < 3; ++r) M[4 * r + 3] = 0.4f * (frand(&seed) - 0.5f);
+        }
+        float* cp = (float*)malloc(Pc * 12);
+        for (int64_t i = 0; i < 3 * Pc; ++i) cp[i] = 1.2f * (frand(&seed) - 0.5f);
+        float *dcp, *dtf, *dcv, *dcg; int32_t* dcl; pvamd_grid_t* dgs; void* dscr;
+        const int64_t scr = pvamd_group_scratch_bytes(Pc);
+        CK(hipMalloc((void**)&dcp, Pc * 12)); CK(hipMalloc((void**)&dtf, sizeof tf)); CK(hipMalloc((void**)&dgs, sizeof gs));
+        CK(hipMalloc((void**)&dcv, A * Pc * 4)); CK(hipMalloc((void**)&dcg, A * Pc * 12)); CK(hipMalloc((void**)&dcl, A * Pc * 4));
+        CK(hipMalloc(&dscr, scr));
+        CK(hipMemcpy(dcp, cp, Pc * 12, hipMemcpyHostToDevice)); CK(hipMemcpy(dtf, tf, sizeof tf, hipMemcpyHostToDevice));
+        CK(hipMemcpy(dgs, gs, sizeof gs, hipMemcpyHostToDevice));
+        float* rv = (float*)malloc(A * Pc * 4); float* rg = (float*)malloc(A * Pc * 12); int32_t* rl = (int32_t*)malloc(A * Pc * 4);
+        float* cv = (float*)malloc(A * Pc * 4); float* cg = (float*)malloc(A * Pc * 12); int32_t* cl = (int32_t*)malloc(A * Pc * 4);
+        oracle_composed_query(os, S, tf, A, cp, Pc, rv, rg, rl);
+        const char* names[3] = {"pvamd_composed_query", "pvamd_composed_query, regrouping forced", "pvamd_group_points + pvamd_composed_query_grouped"};
+        for (int way = 0; way < 3; ++way) {
+            CK(hipMemset(dcv, 0xff, A * Pc * 4)); CK(hipMemset(dcg, 0xff, A * Pc * 12)); CK(hipMemset(dcl, 0xff, A * Pc * 4));
+            if (way < 2) {
+                CKP(pvamd_composed_query(dgs, S, dtf, A, dcp, Pc, dcv, dcg, dcl, way == 1 ? PVAMD_COMPOSED_FORCE_FUSED : 0, NULL));
+            } else {
+                CKP(pvamd_group_points(dcp, Pc, dscr, NULL));
+                CKP(pvamd_composed_query_grouped(dgs, S, dtf, A, dscr, Pc, dcv, dcg, dcl, 0, NULL));
+            }
+            CK(hipDeviceSynchronize());
+            CK(hipMemcpy(cv, dcv, A * Pc * 4, hipMemcpyDeviceToHost)); CK(hipMemcpy(cg, dcg, A * Pc * 12, hipMemcpyDeviceToHost));
+            CK(hipMemcpy(cl, dcl, A * Pc * 4, hipMemcpyDeviceToHost));
+            int64_t mism = 0, inside = 0;
+            for (int64_t i = 0; i < A * Pc; ++i) {
+                inside += rv[i] < 0.f;
+                if (memcmp(&cv[i], &rv[i], 4) || cl[i] != rl[i]) {
+                    if (mism < 3) printf("  [%lld] val %.9g vs %.9g, leaf %d vs %d, grad (%g %g %g) vs (%g %g %g)\n", (long long)i, cv[i], rv[i],
+                                         cl[i], rl[i], cg[3 * i], cg[3 * i + 1], cg[3 * i + 2], rg[3 * i], rg[3 * i + 1], rg[3 * i + 2]);
+                    ++mism; continue;
+                }
+                for (int d = 0; d < 3; ++d) /* a NaN gradient (0 / 0 inside the box) compares as NaN == NaN */
+                    if (memcmp(&cg[3 * i + d], &rg[3 * i + d], 4) && !(isnan(cg[3 * i + d]) && isnan(rg[3 * i + d]))) { ++mism; break; }
+            }
+            printf("%s: %d leaves x %d configurations x %lld points, %lld negative, %lld mismatches\n", names[way], S, A, (long long)Pc,
+                   (long long)inside, (long long)mism);
+            bad += mism != 0;
+        }
     }
     printf(bad ? "FAILED\n" : "C-ABI check passed: %s\n", pvamd_build_info());
     return bad ? 4 : 0;

@@ -66,6 +66,27 @@ def test_struct_layouts_match_the_header():
     assert [int(x) for x in out[7:]] == [ctypes.sizeof(M), M.F.offset, M.ray_dir.offset]
 
 
+def test_oracle_grid_layout_is_one_definition():
+    """The checker's grid description lives in oracle/pvamd_oracle.h; the plain-C host test (tests/cabi/cabi_check.c) includes
+    it and the ctypes mirror in oracle/oracle.py must agree with it (an outdated private copy in the C test once made the
+    oracle read every grid after the first at the wrong stride)."""
+    from oracle import oracle as orc
+    src = r'''
+    #include <stdio.h>
+    #include <stddef.h>
+    #include "pvamd_oracle.h"
+    int main(void) {
+      printf("%zu %zu %zu %zu %zu %zu\n", sizeof(oracle_grid_t), offsetof(oracle_grid_t, dres), offsetof(oracle_grid_t, fres),
+             offsetof(oracle_grid_t, shape), offsetof(oracle_grid_t, rule), offsetof(oracle_grid_t, dbb_max));
+      return 0; }'''
+    exe = "/tmp/_pvamd_oracle_layout"
+    subprocess.run(["gcc", "-x", "c", "-", "-I", os.path.join(ROOT, "oracle"), "-o", exe], input=src.encode(), check=True)
+    out = [int(x) for x in subprocess.run([exe], capture_output=True, check=True).stdout.decode().split()]
+    G = orc.OracleGrid
+    assert out == [ctypes.sizeof(G), G.dres.offset, G.fres.offset, G.shape.offset, G.rule.offset, G.dbb_max.offset]
+    assert "pvamd_oracle.h" in open(os.path.join(ROOT, "tests", "cabi", "cabi_check.c")).read()
+
+
 def test_buffer_size_macros_match_the_python_mirrors():
     """The sizes the binding allocates are the header's macros (records in whole tiles, tile / group spheres, the scratch of
     the mesh entry points, the Morton-order scratch)."""
