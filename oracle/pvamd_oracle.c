@@ -362,13 +362,7 @@ void oracle_composed_query_f64(const oracle_grid_t* grids, int32_t S, const doub
 /* ------------------------------------------------------------------------------------------------------------
  * Mesh query: sdf.py:122-172
  * ---------------------------------------------------------------------------------------------------------- */
-typedef struct oracle_mesh {
-    const float* tri;    /* [F][3][3] */
-    const float* normal; /* [F][3]    */
-    int32_t F;
-    int32_t reserved;
-    double ray_dir[3];   /* bounding_box(padding=1.0)[:,1], sdf.py:147 */
-} oracle_mesh_t;
+/* oracle_mesh_t: pvamd_oracle.h */
 
 static float dot3(const float* u, const float* v) { return fmaf(u[2], v[2], fmaf(u[1], v[1], u[0] * v[0])); }
 static void sub3(const float* u, const float* v, float* o) {

@@ -23,8 +23,19 @@ typedef struct oracle_grid {
     double dbb_min[3], dbb_max[3]; /* the bounding box as float64: what sdf.py:556-557 casts self.bb to for float64 queries */
 } oracle_grid_t;
 
+/* A triangle mesh as the reference holds it after precompute_sdf (sdf.py:97-120): soup + per-face unit normals. */
+typedef struct oracle_mesh {
+    const float* tri;    /* [F][3][3] */
+    const float* normal; /* [F][3]    */
+    int32_t F;
+    int32_t reserved;
+    double ray_dir[3];   /* bounding_box(padding=1.0)[:,1], sdf.py:147 */
+} oracle_mesh_t;
+
 void oracle_cached_query(const oracle_grid_t* g, const float* pts, int64_t P, float* out_val, float* out_grad, uint8_t* out_oob);
 void oracle_voxel_index(const oracle_grid_t* g, const float* pts, int64_t P, int64_t* out_key, int64_t* out_flat, uint8_t* out_valid);
 void oracle_composed_query(const oracle_grid_t* grids, int32_t S, const float* tf, int32_t A, const float* pts, int64_t P,
                            float* out_val, float* out_grad, int32_t* out_leaf);
+void oracle_mesh_query(const oracle_mesh_t* m, const float* pts, int64_t P, uint64_t seed, int64_t index_base, float* out_closest,
+                       float* out_dist, float* out_grad, int32_t* out_face, float* out_normal);
 #endif

@@ -1,7 +1,8 @@
 /* Plain-C host program over include/pvamd.h: no Python, no torch.  Builds a small voxel cache, runs
  * pvamd_grid_finalize / pvamd_pack_grid / pvamd_cached_query / pvamd_voxel_index on hipMalloc'ed buffers, then the composed
  * query three ways (pvamd_composed_query, its in-workgroup regrouping forced, pvamd_group_points + pvamd_composed_query_grouped
- * over scratch the host sized with pvamd_group_scratch_bytes), and compares every output with the CPU oracle linked next to it.  Exit code 0 = bit-exact.  (tests/test_cabi_gpu.py builds and
+ * over scratch the host sized with pvamd_group_scratch_bytes), then a mesh it generates through pvamd_mesh_prepare / pvamd_mesh_query /
+ * pvamd_mesh_query_unordered, and compares every output with the CPU oracle linked next to it.  Exit code 0 = bit-exact.  (tests/test_cabi_gpu.py builds and
  * runs it; it doubles as the example a non-Python host language would follow.) */
 #include <hip/hip_runtime_api.h>
 #include <math.h>
@@ -132,6 +133,74 @@ int main(void) {
             printf("%s: %d leaves x %d configurations x %lld points, %lld negative, %lld mismatches\n", names[way], S, A, (long long)Pc,
                    (long long)inside, (long long)mism);
             bad += mism != 0;
+        }
+    }
+    /* ---- ObjectFactory._do_object_frame_closest_point (sdf.py:122-172): a 528-triangle ellipsoid built right here, prepared by
+     * pvamd_mesh_prepare, queried by pvamd_mesh_query (caller order, with scratch) and pvamd_mesh_query_unordered ---- */
+    {
+        enum { NLON = 24, NLAT = 12, F = 2 * NLON * (NLAT - 1) };
+        const double kPi = 3.14159265358979323846;
+        float* tri = (float*)malloc(F * 36); float* nrm = (float*)malloc(F * 12);
+        int f = 0;
+        #define VERT(i, j, out) do { const double th = kPi * (i) / NLAT, ph = 2.0 * kPi * ((j) % NLON) / NLON; \
+            (out)[0] = (float)(0.30 * sin(th) * cos(ph)); (out)[1] = (float)(0.20 * sin(th) * sin(ph)); (out)[2] = (float)(0.12 * cos(th) + 0.05); } while (0)
+        for (int i = 0; i < NLAT; ++i) for (int j = 0; j < NLON; ++j) {
+            float a[3], b[3], c[3], d[3];
+            VERT(i, j, a); VERT(i + 1, j, b); VERT(i + 1, j + 1, c); VERT(i, j + 1, d);
+            if (i > 0) { memcpy(tri + 9 * f, a, 12); memcpy(tri + 9 * f + 3, b, 12); memcpy(tri + 9 * f + 6, d, 12); ++f; }
+            if (i < NLAT - 1) { memcpy(tri + 9 * f, b, 12); memcpy(tri + 9 * f + 3, c, 12); memcpy(tri + 9 * f + 6, d, 12); ++f; }
+        }
+        if (f != F) { printf("mesh construction: %d triangles, expected %d\n", f, (int)F); return 5; }
+        for (int k = 0; k < F; ++k) { /* unit face normals in float64, rounded once (sdf.py:119-120) */
+            const float* t = tri + 9 * k; double u[3], v[3], n[3];
+            for (int d = 0; d < 3; ++d) { u[d] = (double)t[3 + d] - t[d]; v[d] = (double)t[6 + d] - t[d]; }
+            n[0] = u[1] * v[2] - u[2] * v[1]; n[1] = u[2] * v[0] - u[0] * v[2]; n[2] = u[0] * v[1] - u[1] * v[0];
+            const double len = sqrt(n[0] * n[0] + n[1] * n[1] + n[2] * n[2]);
+            for (int d = 0; d < 3; ++d) nrm[3 * k + d] = (float)(len > 0 ? n[d] / len : 0.0);
+        }
+        const int64_t Pm = 12000;
+        float* mp = (float*)malloc(Pm * 12);
+        for (int64_t i = 0; i < Pm; ++i) { mp[3 * i] = 0.9f * (frand(&seed) - 0.5f); mp[3 * i + 1] = 0.7f * (frand(&seed) - 0.5f); mp[3 * i + 2] = 0.5f * (frand(&seed) - 0.4f); }
+        float *dtri, *dnrm, *drec, *dtiles, *dmp, *dq, *dd, *dgr, *dn; int32_t *drof, *dface, *dord; void* dms;
+        CK(hipMalloc((void**)&dtri, F * 36)); CK(hipMalloc((void**)&dnrm, F * 12)); CK(hipMalloc((void**)&drec, PVAMD_REC_FLOATS(F) * 4));
+        CK(hipMalloc((void**)&dtiles, PVAMD_TILES_FLOATS(F) * 4)); CK(hipMalloc((void**)&drof, F * 4)); CK(hipMalloc((void**)&dmp, Pm * 12));
+        CK(hipMalloc((void**)&dq, Pm * 12)); CK(hipMalloc((void**)&dd, Pm * 4)); CK(hipMalloc((void**)&dgr, Pm * 12)); CK(hipMalloc((void**)&dn, Pm * 12));
+        CK(hipMalloc((void**)&dface, Pm * 4)); CK(hipMalloc((void**)&dord, Pm * 4)); CK(hipMalloc(&dms, PVAMD_MESH_SCRATCH_BYTES(Pm)));
+        CK(hipMemcpy(dtri, tri, F * 36, hipMemcpyHostToDevice)); CK(hipMemcpy(dnrm, nrm, F * 12, hipMemcpyHostToDevice));
+        CK(hipMemcpy(dmp, mp, Pm * 12, hipMemcpyHostToDevice));
+        CKP(pvamd_mesh_prepare(dtri, NULL, F, 1e-6f * (0.35f + 0.8f), drec, dtiles, drof, NULL));
+        pvamd_mesh_t mesh; memset(&mesh, 0, sizeof mesh);
+        mesh.normal = dnrm; mesh.rec = drec; mesh.tiles = dtiles; mesh.rec_of_face = drof; mesh.F = F;
+        oracle_mesh_t om; memset(&om, 0, sizeof om);
+        om.tri = tri; om.normal = nrm; om.F = F;
+        const double far_corner[3] = {1.30, 1.20, 1.17}; /* bounding_box(padding=1.0)[:, 1] (sdf.py:147) */
+        for (int d = 0; d < 3; ++d) mesh.ray_dir[d] = om.ray_dir[d] = far_corner[d];
+        float* rq = (float*)malloc(Pm * 12); float* rd = (float*)malloc(Pm * 4); float* rgr = (float*)malloc(Pm * 12);
+        float* rn = (float*)malloc(Pm * 12); int32_t* rf = (int32_t*)malloc(Pm * 4);
+        float* hq = (float*)malloc(Pm * 12); float* hd = (float*)malloc(Pm * 4); float* hgr = (float*)malloc(Pm * 12);
+        float* hn = (float*)malloc(Pm * 12); int32_t* hf = (int32_t*)malloc(Pm * 4);
+        const uint64_t jitter = 20240607u;
+        oracle_mesh_query(&om, mp, Pm, jitter, 0, rq, rd, rgr, rf, rn);
+        for (int way = 0; way < 2; ++way) {
+            CK(hipMemset(dd, 0xff, Pm * 4)); CK(hipMemset(dface, 0xff, Pm * 4));
+            if (way == 0) CKP(pvamd_mesh_query(&mesh, dmp, NULL, Pm, jitter, 0, dq, dd, dgr, dface, dn, dms, NULL));
+            else CKP(pvamd_mesh_query_unordered(&mesh, dmp, Pm, jitter, 0, dq, dd, dgr, dface, dn, dord, dms, NULL));
+            CK(hipDeviceSynchronize());
+            CK(hipMemcpy(hq, dq, Pm * 12, hipMemcpyDeviceToHost)); CK(hipMemcpy(hd, dd, Pm * 4, hipMemcpyDeviceToHost));
+            CK(hipMemcpy(hgr, dgr, Pm * 12, hipMemcpyDeviceToHost)); CK(hipMemcpy(hn, dn, Pm * 12, hipMemcpyDeviceToHost));
+            CK(hipMemcpy(hf, dface, Pm * 4, hipMemcpyDeviceToHost));
+            int64_t mism = 0, inside = 0;
+            for (int64_t i = 0; i < Pm; ++i) {
+                inside += rd[i] < 0.f;
+                if (memcmp(&hd[i], &rd[i], 4) || hf[i] != rf[i] || memcmp(&hq[3 * i], &rq[3 * i], 12) || memcmp(&hgr[3 * i], &rgr[3 * i], 12) ||
+                    memcmp(&hn[3 * i], &rn[3 * i], 12)) {
+                    if (mism < 3) printf("  [%lld] d %.9g vs %.9g, face %d vs %d\n", (long long)i, hd[i], rd[i], hf[i], rf[i]);
+                    ++mism;
+                }
+            }
+            printf("%s: %d triangles, %lld points, %lld inside, %lld mismatches\n", way == 0 ? "pvamd_mesh_query" : "pvamd_mesh_query_unordered",
+                   (int)F, (long long)Pm, (long long)inside, (long long)mism);
+            bad += mism != 0 || inside == 0;
         }
     }
     printf(bad ? "FAILED\n" : "C-ABI check passed: %s\n", pvamd_build_info());
