@@ -38,4 +38,7 @@ void oracle_composed_query(const oracle_grid_t* grids, int32_t S, const float* t
                            float* out_val, float* out_grad, int32_t* out_leaf);
 void oracle_mesh_query(const oracle_mesh_t* m, const float* pts, int64_t P, uint64_t seed, int64_t index_base, float* out_closest,
                        float* out_dist, float* out_grad, int32_t* out_face, float* out_normal);
+void oracle_chamfer_mesh(const oracle_mesh_t* m, const float* W, int32_t B, const float* pts, int64_t N, float scale, double* out_sum);
+void oracle_chamfer_grid(const oracle_grid_t* g, const float* W, int32_t B, const float* pts, int64_t N, float scale, double* out_sum);
+void oracle_transform_stack(const float* offset_inv, const float* link_world, int32_t S, int32_t A, float* out);
 #endif

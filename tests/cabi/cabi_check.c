@@ -202,6 +202,58 @@ int main(void) {
                    (int)F, (long long)Pm, (long long)inside, (long long)mism);
             bad += mism != 0 || inside == 0;
         }
+        /* ---- batch_chamfer_dist (chamfer.py:79-94): B world->object transforms, the same points, mesh branch and cached-grid
+         * branch; sums are float64 in an order of their own, so: relative 1e-9 (what the Python tests allow too) ---- */
+        enum { B = 4 };
+        float W[B * 16];
+        memset(W, 0, sizeof W);
+        for (int b = 0; b < B; ++b) { /* a small rotation about z and a shift */
+            const float th = 0.1f * b, c = cosf(th), sn = sinf(th);
+            float* M = W + 16 * b;
+            M[0] = c; M[1] = -sn; M[4] = sn; M[5] = c; M[10] = 1.f; M[15] = 1.f;
+            M[3] = 0.01f * b; M[7] = -0.02f * b; M[11] = 0.005f * b;
+        }
+        float* dW; double* dsum;
+        CK(hipMalloc((void**)&dW, sizeof W)); CK(hipMalloc((void**)&dsum, B * 8));
+        CK(hipMemcpy(dW, W, sizeof W, hipMemcpyHostToDevice));
+        double want[B], got[B];
+        oracle_chamfer_mesh(&om, W, B, mp, Pm, 1000.f, want);
+        CKP(pvamd_chamfer_mesh(&mesh, dW, B, dmp, NULL, Pm, 1000.f, dsum, dms, NULL));
+        CK(hipDeviceSynchronize());
+        CK(hipMemcpy(got, dsum, B * 8, hipMemcpyDeviceToHost));
+        int64_t cm = 0;
+        for (int b = 0; b < B; ++b) cm += !(fabs(got[b] - want[b]) <= 1e-9 * fabs(want[b]));
+        printf("pvamd_chamfer_mesh: %d transforms x %lld points, sum[1] = %.12g vs %.12g, %lld mismatches\n", (int)B, (long long)Pm, got[1], want[1], (long long)cm);
+        bad += cm != 0;
+        g.index_f64 = o.index_f64 = 0; g.oob_mode = o.oob_mode = PVAMD_OOB_BOUNDING_BOX; g.finalized = 0;
+        CKP(pvamd_grid_finalize(&g));
+        oracle_chamfer_grid(&o, W, B, mp, Pm, 1000.f, want);
+        CKP(pvamd_chamfer_grid(&g, dW, B, dmp, Pm, 1000.f, dsum, NULL));
+        CK(hipDeviceSynchronize());
+        CK(hipMemcpy(got, dsum, B * 8, hipMemcpyDeviceToHost));
+        cm = 0;
+        for (int b = 0; b < B; ++b) cm += !(fabs(got[b] - want[b]) <= 1e-9 * fabs(want[b]));
+        printf("pvamd_chamfer_grid: %d transforms x %lld points, sum[1] = %.12g vs %.12g, %lld mismatches\n", (int)B, (long long)Pm, got[1], want[1], (long long)cm);
+        bad += cm != 0;
+        /* ---- RobotSDF.set_joint_configuration's contraction (model_to_sdf.py:104-113) on the f32 MFMA: the B transforms above as
+         * offsets, 4 x 3 of them as link poses ---- */
+        enum { SS = 4, AA = 3 };
+        float link[SS * AA * 16], stack_want[SS * AA * 16], stack_got[SS * AA * 16];
+        for (int k = 0; k < SS * AA; ++k) {
+            const float th = 0.37f * (k + 1), c = cosf(th), sn = sinf(th);
+            float* M = link + 16 * k; memset(M, 0, 64);
+            M[0] = c; M[2] = sn; M[5] = 1.f; M[8] = -sn; M[10] = c; M[15] = 1.f; M[3] = 0.1f * k; M[7] = 0.3f; M[11] = -0.05f * k;
+        }
+        float *dlink, *dstack;
+        CK(hipMalloc((void**)&dlink, sizeof link)); CK(hipMalloc((void**)&dstack, sizeof link));
+        CK(hipMemcpy(dlink, link, sizeof link, hipMemcpyHostToDevice));
+        oracle_transform_stack(W, link, SS, AA, stack_want);
+        CKP(pvamd_transform_stack(dW, dlink, SS, AA, dstack, NULL));
+        CK(hipDeviceSynchronize());
+        CK(hipMemcpy(stack_got, dstack, sizeof link, hipMemcpyDeviceToHost));
+        const int64_t sm = memcmp(stack_got, stack_want, sizeof link) != 0;
+        printf("pvamd_transform_stack: %d x %d matrices, %lld mismatches\n", (int)SS, (int)AA, (long long)sm);
+        bad += sm != 0;
     }
     printf(bad ? "FAILED\n" : "C-ABI check passed: %s\n", pvamd_build_info());
     return bad ? 4 : 0;

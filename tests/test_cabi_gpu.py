@@ -23,4 +23,4 @@ def test_plain_c_host_program_is_bit_exact(tmp_path):
     out = subprocess.run([exe], capture_output=True, text=True, timeout=120)
     print(out.stdout, out.stderr)
     assert out.returncode == 0, out.stdout + out.stderr
-    assert "C-ABI check passed" in out.stdout and out.stdout.count(" 0 mismatches") == 9  # 4 cached + 3 composed ways + 2 mesh entries
+    assert "C-ABI check passed" in out.stdout and out.stdout.count(" 0 mismatches") == 12  # 4 cached + 3 composed ways + 2 mesh entries + 2 chamfer + the transform stack
