@@ -14,6 +14,7 @@ from pytorch_volumetric_amd import mesh_io
 from tests import helpers as H
 
 FUZZ_SCALE = int(os.environ.get("PVAMD_FUZZ_SCALE", "1"))  # PVAMD_FUZZ_SCALE=30 pytest ... for a long campaign
+FUZZ_BASE = int(os.environ.get("PVAMD_FUZZ_BASE", "0"))    # first seed: a second campaign draws cases the first did not
 pytestmark = pytest.mark.gpu
 
 
@@ -46,7 +47,7 @@ def random_cached(rng, f64, far=False):
     return c, rng_np
 
 
-@pytest.mark.parametrize("seed", range(12 * FUZZ_SCALE))
+@pytest.mark.parametrize("seed", range(FUZZ_BASE, FUZZ_BASE + 12 * FUZZ_SCALE))
 def test_cached_query_fuzz(seed):
     rng = np.random.default_rng(seed)
     f64, far = bool(seed % 2), seed % 3 == 0
@@ -80,7 +81,7 @@ def test_cached_query_fuzz(seed):
     assert np.array_equal(c.outside_surface(t, 0.01).cpu().numpy(), oracle.cached_outside(og, pts, 0.01))
 
 
-@pytest.mark.parametrize("seed", range(8 * FUZZ_SCALE))
+@pytest.mark.parametrize("seed", range(FUZZ_BASE, FUZZ_BASE + 8 * FUZZ_SCALE))
 def test_composed_query_fuzz(seed):
     rng = np.random.default_rng(100 + seed)
     S, A = int(rng.integers(1, 12)), int(rng.choice([1, 2, 5]))
@@ -133,7 +134,7 @@ def random_mesh(rng):
     return m
 
 
-@pytest.mark.parametrize("seed", range(10 * FUZZ_SCALE))
+@pytest.mark.parametrize("seed", range(FUZZ_BASE, FUZZ_BASE + 10 * FUZZ_SCALE))
 def test_mesh_query_and_chamfer_fuzz(seed):
     rng = np.random.default_rng(200 + seed)
     obj = pv.MeshObjectFactory(mesh=random_mesh(rng))
@@ -155,7 +156,7 @@ def test_mesh_query_and_chamfer_fuzz(seed):
     assert np.allclose(err.double().numpy(), oerr, rtol=1e-6, atol=1e-12)
 
 
-@pytest.mark.parametrize("seed", range(6 * FUZZ_SCALE))
+@pytest.mark.parametrize("seed", range(FUZZ_BASE, FUZZ_BASE + 6 * FUZZ_SCALE))
 def test_rules_and_float64_compositions_fuzz(seed):
     """Random compositions whose leaves were built under a random index rule (pvamd_grid_t.rule), queried with float32 points
     through every kernel variant and with float64 points through pvamd_composed_query_f64: the oracle's bits each time."""
