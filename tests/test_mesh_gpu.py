@@ -205,6 +205,26 @@ def test_a_collada_mesh_answers_like_the_same_triangles_from_an_obj(tmp_path):
     assert torch.allclose(c.distance, a.distance, atol=2e-6)
 
 
+def test_voxel_view_and_filtered_points_of_a_mesh_and_of_its_cache():
+    """ObjectFrameSDF.get_voxel_view / get_filtered_points (sdf.py:248-282) and CachedSDF.get_voxel_view (sdf.py:604-614) over the
+    HIP path: the cube's interior voxel centres, a view addressed by coordinates that falls back to the SDF outside its grid."""
+    obj = factory("box_template.obj", scale=0.1)  # the cube [-0.1, 0.1]^3
+    sdf = pv.MeshSDF(obj)
+    grid = pv.VoxelGrid(0.02, [(-0.2, 0.2)] * 3, device="cuda")
+    inside = sdf.get_filtered_points(lambda v: v < -0.01, voxels=grid)  # (centres ON the surface land on either side of 0)
+    assert inside.shape == (9 ** 3, 3) and float(inside.abs().max()) <= 0.08 + 1e-6  # the centres at multiples of 0.02 up to 0.08
+    view = sdf.get_voxel_view(grid)
+    q = torch.tensor([[0.0, 0.0, 0.0], [0.16, 0.0, 0.0], [0.5, 0.0, 0.0]], device="cuda")
+    assert torch.allclose(view[q].cpu(), torch.tensor([-0.1, 0.06, 0.4]), atol=1e-6)  # the last one: outside the grid, asked of the mesh
+    default = sdf.get_voxel_view(device="cuda")
+    assert default.shape == (41, 41, 41)  # 0.01 m over the bounding box + 0.1
+    cached = pv.CachedSDF("cube", 0.02, obj.bounding_box(padding=0.1), sdf, device="cuda", cache_path=None)
+    assert cached.get_voxel_view() is cached.voxels
+    other = cached.get_voxel_view(grid)
+    assert other.shape == (21, 21, 21) and torch.equal(other.raw_data, view.raw_data)
+    assert torch.allclose(other[q].cpu(), torch.tensor([-0.1, 0.06, 0.4]), atol=1e-6)
+
+
 def test_numpy_input_and_dtype_device_round_trip():
     obj = factory("probe.obj")
     pts = H.uniform_points(100, obj.bounding_box(0.01)[:, 0], obj.bounding_box(0.01)[:, 1], seed=4)
