@@ -372,7 +372,127 @@ def _parse_dae(data):
     return np.concatenate(verts, axis=0), np.concatenate(faces, axis=0)
 
 
-SUPPORTED_MESH_EXTENSIONS = (".obj", ".stl", ".ply", ".off", ".dae", ".npz")
+_GLTF_COMPONENT = {5120: np.int8, 5121: np.uint8, 5122: np.int16, 5123: np.uint16, 5125: np.uint32, 5126: np.float32}
+_GLTF_WIDTH = {"SCALAR": 1, "VEC2": 2, "VEC3": 3, "VEC4": 4, "MAT4": 16}
+
+
+def _parse_gltf(data, base_dir):
+    """glTF 2.0 (.gltf with external or data: buffers, .glb), flattened as assimp's aiProcess_PreTransformVertices does for
+    open3d: every mesh primitive of the default scene placed by its nodes (matrix, or translation * rotation * scale;
+    column-major, quaternions xyzw), concatenated.  Triangle lists, strips and fans; glTF is Y-up and metres by definition, so
+    nothing is turned or scaled.  Sparse accessors and compressed (Draco / meshopt) primitives raise."""
+    import base64
+    import json
+    import struct
+    blob = None
+    if data[:4] == b"glTF":
+        _, _, total = struct.unpack_from("<III", data, 0)
+        pos, doc = 12, None
+        while pos + 8 <= min(total, len(data)):
+            n, kind = struct.unpack_from("<II", data, pos)
+            chunk = data[pos + 8:pos + 8 + n]
+            if kind == 0x4E4F534A:
+                doc = json.loads(chunk.decode("utf-8"))
+            elif kind == 0x004E4942 and blob is None:
+                blob = chunk
+            pos += 8 + n + (-n % 4)
+        if doc is None:
+            raise ValueError("GLB file without a JSON chunk")
+    else:
+        doc = json.loads(data.decode("utf-8"))
+    if any(ext in doc.get("extensionsRequired", []) for ext in ("KHR_draco_mesh_compression", "EXT_meshopt_compression")):
+        raise ValueError("compressed glTF (Draco / meshopt) is not supported; re-export without compression")
+    buffers = []
+    for i, b in enumerate(doc.get("buffers", [])):
+        uri = b.get("uri")
+        if uri is None:
+            if blob is None:
+                raise ValueError("glTF buffer without a uri outside a GLB container")
+            buffers.append(blob)
+        elif uri.startswith("data:"):
+            buffers.append(base64.b64decode(uri.split(",", 1)[1]))
+        else:
+            from urllib.parse import unquote
+            with open(os.path.join(base_dir, unquote(uri)), "rb") as f:
+                buffers.append(f.read())
+
+    def accessor(index):
+        a = doc["accessors"][index]
+        if "sparse" in a:
+            raise ValueError("sparse glTF accessors are not supported")
+        dtype, width = np.dtype(_GLTF_COMPONENT[a["componentType"]]), _GLTF_WIDTH[a["type"]]
+        if "bufferView" not in a:
+            return np.zeros((a["count"], width), dtype=dtype)
+        view = doc["bufferViews"][a["bufferView"]]
+        start = view.get("byteOffset", 0) + a.get("byteOffset", 0)
+        stride = view.get("byteStride") or dtype.itemsize * width
+        raw = np.frombuffer(buffers[view["buffer"]], dtype=np.uint8)
+        rows = np.lib.stride_tricks.as_strided(raw[start:], shape=(a["count"], dtype.itemsize * width), strides=(stride, 1))
+        out = np.ascontiguousarray(rows).view(dtype).reshape(a["count"], width)
+        if a.get("normalized") and dtype.kind in "iu":
+            out = np.maximum(out.astype(np.float64) / np.iinfo(dtype).max, -1.0)
+        return out
+
+    def local_matrix(node):
+        if "matrix" in node:
+            return np.array(node["matrix"], dtype=np.float64).reshape(4, 4).T  # stored column-major
+        m = np.eye(4)
+        x, y, z, w = node.get("rotation", (0.0, 0.0, 0.0, 1.0))
+        n = np.sqrt(x * x + y * y + z * z + w * w) or 1.0
+        x, y, z, w = x / n, y / n, z / n, w / n
+        m[:3, :3] = [[1 - 2 * (y * y + z * z), 2 * (x * y - z * w), 2 * (x * z + y * w)],
+                     [2 * (x * y + z * w), 1 - 2 * (x * x + z * z), 2 * (y * z - x * w)],
+                     [2 * (x * z - y * w), 2 * (y * z + x * w), 1 - 2 * (x * x + y * y)]]
+        m[:3, :3] = m[:3, :3] * np.array(node.get("scale", (1.0, 1.0, 1.0)), dtype=np.float64)[None, :]
+        m[:3, 3] = node.get("translation", (0.0, 0.0, 0.0))
+        return m
+
+    verts, faces, base = [], [], 0
+
+    def emit(mesh_index, m):
+        nonlocal base
+        for prim in doc["meshes"][mesh_index].get("primitives", []):
+            if "KHR_draco_mesh_compression" in prim.get("extensions", {}):
+                raise ValueError("compressed glTF (Draco) is not supported; re-export without compression")
+            mode = prim.get("mode", 4)
+            if mode not in (4, 5, 6) or "POSITION" not in prim.get("attributes", {}):
+                continue  # points / lines: not surface
+            pos = accessor(prim["attributes"]["POSITION"]).astype(np.float64)[:, :3]
+            idx = accessor(prim["indices"]).reshape(-1).astype(np.int64) if "indices" in prim else np.arange(len(pos), dtype=np.int64)
+            if mode == 4:
+                f = idx[:len(idx) // 3 * 3].reshape(-1, 3)
+            elif mode == 5:
+                f = np.array([[idx[k], idx[k + 1], idx[k + 2]] if k % 2 == 0 else [idx[k + 1], idx[k], idx[k + 2]]
+                              for k in range(len(idx) - 2)], dtype=np.int64).reshape(-1, 3)
+            else:
+                f = np.array([[idx[0], idx[k], idx[k + 1]] for k in range(1, len(idx) - 1)], dtype=np.int64).reshape(-1, 3)
+            verts.append(pos @ m[:3, :3].T + m[:3, 3])
+            faces.append((f if np.linalg.det(m[:3, :3]) >= 0 else f[:, ::-1]) + base)
+            base += len(pos)
+
+    def walk(node_index, parent, depth=0):
+        if depth > 64:
+            raise ValueError("glTF node hierarchy deeper than 64 (a cycle?)")
+        node = doc["nodes"][node_index]
+        here = parent @ local_matrix(node)
+        if "mesh" in node:
+            emit(node["mesh"], here)
+        for child in node.get("children", []):
+            walk(child, here, depth + 1)
+
+    scenes = doc.get("scenes", [])
+    if scenes:
+        for root in scenes[doc.get("scene", 0)].get("nodes", []):
+            walk(root, np.eye(4))
+    if not verts:  # no scene (or an empty one): the meshes as they are
+        for i in range(len(doc.get("meshes", []))):
+            emit(i, np.eye(4))
+    if not verts:
+        raise ValueError("glTF file holds no triangle geometry")
+    return np.concatenate(verts, axis=0), np.concatenate(faces, axis=0)
+
+
+SUPPORTED_MESH_EXTENSIONS = (".obj", ".stl", ".ply", ".off", ".dae", ".gltf", ".glb", ".npz")
 
 
 def _parse_off(text):
@@ -399,9 +519,10 @@ def _parse_off(text):
 
 def load_mesh(path):
     """.obj (text), .stl (ascii/binary), .ply (ascii/binary little endian), .off (text), .dae (COLLADA: the scene's node
-    transforms and up axis applied, see _parse_dae) or .npz with arrays `vertices` [V,3] and `faces` [F,3].  STL repeats every
-    vertex per triangle; identical positions are merged (as open3d does when it reads an STL) so that center() and the
-    vertex count match the reference loader.  Anything else (.gltf, .fbx, ...) raises instead of yielding an empty mesh."""
+    transforms and up axis applied, see _parse_dae), .gltf / .glb (glTF 2.0, node transforms applied, see _parse_gltf) or .npz
+    with arrays `vertices` [V,3] and `faces` [F,3].  STL repeats every vertex per triangle; identical positions are merged (as
+    open3d does when it reads an STL) so that center() and the vertex count match the reference loader.  Anything else
+    (.fbx, .3ds, ...) raises instead of yielding an empty mesh."""
     ext = os.path.splitext(path)[1].lower()
     if ext not in SUPPORTED_MESH_EXTENSIONS:
         raise ValueError(f"unsupported mesh format '{ext}' ({path}); supported: {', '.join(SUPPORTED_MESH_EXTENSIONS)}. "
@@ -423,6 +544,9 @@ def load_mesh(path):
     elif ext == ".dae":
         with open(path, "rb") as f:
             mesh = TriMesh(*_parse_dae(f.read()))
+    elif ext in (".gltf", ".glb"):
+        with open(path, "rb") as f:
+            mesh = TriMesh(*_parse_gltf(f.read(), os.path.dirname(os.path.abspath(path))))
     else:
         with open(path, "r") as f:
             mesh = TriMesh(*_parse_obj(f.read()))

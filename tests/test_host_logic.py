@@ -151,7 +151,7 @@ def test_obj_stl_round_trip_and_polygon_triangulation(tmp_path):
     (tmp_path / "h.off").write_text("OFF 3 1 0\n0 0 0\n1 0 0\n0 1 0\n3 0 1 2\n")
     assert mesh_io.load_mesh(str(tmp_path / "h.off")).faces.tolist() == [[0, 1, 2]]
     with pytest.raises(ValueError):
-        mesh_io.load_mesh(str(tmp_path / "robot_link.gltf"))  # refused by name, not read as an empty mesh
+        mesh_io.load_mesh(str(tmp_path / "robot_link.fbx"))  # refused by name, not read as an empty mesh
     with pytest.raises(RuntimeError):
         pv.MeshObjectFactory("does_not_exist.obj")  # sdf.py:102
 
@@ -234,6 +234,79 @@ def test_collada_reader_places_every_instance_by_its_nodes(tmp_path):
     # through the factory: the same bounding box as the mesh handed over directly
     f = pv.MeshObjectFactory(str(tmp_path / "scene_Y_UP.dae"))
     assert np.allclose(f.bounding_box(), pv.MeshObjectFactory(mesh=mesh_io.load_mesh(str(tmp_path / "scene_Y_UP.dae"))).bounding_box())
+
+
+def test_gltf_reader_flattens_the_scene_like_the_collada_one(tmp_path):
+    """.gltf (data: and external buffers) and .glb: every mesh primitive of the default scene placed by its nodes (translation *
+    rotation * scale, or a column-major matrix; nested), uint16 / uint32 / absent indices, a triangle strip, byte strides."""
+    import base64
+    import json
+    import struct
+    tet = np.array([[0, 0, 0], [1, 0, 0], [0, 1, 0], [0, 0, 1]], dtype=np.float32)
+    tet_idx = np.array([0, 2, 1, 0, 1, 3, 0, 3, 2, 1, 2, 3], dtype=np.uint16)
+    quad = np.array([[0, 0, 0], [2, 0, 0], [0, 2, 0], [2, 2, 0]], dtype=np.float32)  # as a strip: (0 1 2) (2 1 3)
+    # the quad's positions interleaved with 4 bytes of padding per vertex (byteStride 16)
+    quad_padded = np.zeros((4, 4), dtype=np.float32)
+    quad_padded[:, :3] = quad
+    blob = tet.tobytes() + tet_idx.tobytes() + quad_padded.tobytes()
+    off_idx, off_quad = tet.nbytes, tet.nbytes + tet_idx.nbytes
+    s2 = np.sqrt(0.5)
+    doc = {
+        "asset": {"version": "2.0"}, "scene": 0, "scenes": [{"nodes": [0, 2]}],
+        "nodes": [{"translation": [1, 2, 3], "rotation": [0, 0, s2, s2], "scale": [2, 2, 2], "mesh": 0, "children": [1]},
+                  {"matrix": [1, 0, 0, 0, 0, 1, 0, 0, 0, 0, -1, 0, 0, 0, 5, 1], "mesh": 1},
+                  {"mesh": 0}],
+        "meshes": [{"primitives": [{"attributes": {"POSITION": 0}, "indices": 1}]},
+                   {"primitives": [{"attributes": {"POSITION": 2}, "mode": 5}]}],
+        "accessors": [{"bufferView": 0, "componentType": 5126, "count": 4, "type": "VEC3"},
+                      {"bufferView": 1, "componentType": 5123, "count": 12, "type": "SCALAR"},
+                      {"bufferView": 2, "componentType": 5126, "count": 4, "type": "VEC3"}],
+        "bufferViews": [{"buffer": 0, "byteOffset": 0, "byteLength": tet.nbytes},
+                        {"buffer": 0, "byteOffset": off_idx, "byteLength": tet_idx.nbytes},
+                        {"buffer": 0, "byteOffset": off_quad, "byteLength": quad_padded.nbytes, "byteStride": 16}],
+        "buffers": [{"byteLength": len(blob)}],
+    }
+    rz = np.array([[0, -1, 0], [1, 0, 0], [0, 0, 1]], dtype=np.float64)
+    a = np.eye(4)
+    a[:3, :3], a[:3, 3] = rz * 2.0, [1, 2, 3]
+    b = a @ np.array([[1, 0, 0, 0], [0, 1, 0, 0], [0, 0, -1, 5], [0, 0, 0, 1]], dtype=np.float64)
+
+    def place(m, v):
+        return v.astype(np.float64) @ m[:3, :3].T + m[:3, 3]
+
+    want_v = np.concatenate((place(a, tet), place(b, quad), tet.astype(np.float64)))
+    tet_f = tet_idx.reshape(-1, 3).astype(np.int64)
+    want_f = np.concatenate((tet_f, np.array([[0, 1, 2], [2, 1, 3]])[:, ::-1] + 4, tet_f + 8))  # node 1 mirrors z: winding reversed
+
+    def check(path):
+        mesh = mesh_io.load_mesh(str(path))
+        assert np.allclose(mesh.vertices, want_v, atol=1e-6) and np.array_equal(mesh.faces, want_f)
+
+    embedded = json.loads(json.dumps(doc))
+    embedded["buffers"][0]["uri"] = "data:application/octet-stream;base64," + base64.b64encode(blob).decode()
+    (tmp_path / "embedded.gltf").write_text(json.dumps(embedded))
+    check(tmp_path / "embedded.gltf")
+    external = json.loads(json.dumps(doc))
+    external["buffers"][0]["uri"] = "scene%20data.bin"
+    (tmp_path / "scene data.bin").write_bytes(blob)
+    (tmp_path / "external.gltf").write_text(json.dumps(external))
+    check(tmp_path / "external.gltf")
+    js = json.dumps(doc).encode()
+    js += b" " * (-len(js) % 4)
+    bn = blob + b"\0" * (-len(blob) % 4)
+    glb = struct.pack("<III", 0x46546C67, 2, 12 + 8 + len(js) + 8 + len(bn)) + struct.pack("<II", len(js), 0x4E4F534A) + js + \
+        struct.pack("<II", len(bn), 0x004E4942) + bn
+    (tmp_path / "packed.glb").write_bytes(glb)
+    check(tmp_path / "packed.glb")
+    # compressed primitives are refused by name; a document without geometry is an error, not an empty mesh
+    draco = json.loads(json.dumps(embedded))
+    draco["extensionsRequired"] = ["KHR_draco_mesh_compression"]
+    (tmp_path / "draco.gltf").write_text(json.dumps(draco))
+    with pytest.raises(ValueError, match="Draco"):
+        mesh_io.load_mesh(str(tmp_path / "draco.gltf"))
+    (tmp_path / "empty.gltf").write_text(json.dumps({"asset": {"version": "2.0"}}))
+    with pytest.raises(ValueError):
+        mesh_io.load_mesh(str(tmp_path / "empty.gltf"))
 
 
 def test_slice_and_voxel_view_callers_of_the_query_path():
