@@ -86,6 +86,12 @@ class ObjectFactory(abc.ABC):
     def get_mesh_high_poly_resource_filename(self):
         return self.get_mesh_resource_filename()
 
+    def draw_mesh(self, dd, name, pose, rgba, object_id=None):
+        """sdf.py:75-78: hand the mesh file and its visual frame to a caller-supplied debug drawer `dd`."""
+        frame_pos = np.array(self.vis_frame_pos) * self.scale
+        return dd.draw_mesh(name, self.get_mesh_resource_filename(), pose, scale=self.scale, rgba=rgba,
+                            object_id=object_id, vis_frame_pos=frame_pos, vis_frame_rot=self.vis_frame_rot)
+
     def bounding_box(self, padding=0., padding_ratio=0):
         """(3,2) float64 ndarray [[min,max],...] of the vertex AABB, inflated (sdf.py:80-89)."""
         lo, hi = self._mesh.aabb()
@@ -193,6 +199,10 @@ class ObjectFactory(abc.ABC):
     @property
     def num_faces(self):
         return int(self._mesh.faces.shape[0])
+
+    def _do_object_frame_closest_point(self, points_in_object_frame, compute_normal=False):
+        """sdf.py:122-172, the body the reference wraps with handle_batch_input: here the public method takes any batch shape."""
+        return self.object_frame_closest_point(points_in_object_frame, compute_normal=compute_normal)
 
     def object_frame_closest_point(self, points_in_object_frame, compute_normal=False, index_base=0, order=None) -> SDFQuery:
         """
@@ -668,6 +678,11 @@ class CachedSDF(ObjectFrameSDF):
                        "pvamd_cached_outside")
         return out.reshape(*lead).bool().to(device=self.device)
 
+    def _fallback_sdf_value_func(self, *args, **kwargs):
+        """sdf.py:530-533: the ground-truth value on this SDF's device (what a view answers outside its grid)"""
+        sdf_val, _ = self.gt_sdf(*args, **kwargs)
+        return sdf_val.to(device=self.device)
+
     def get_voxel_view(self, voxels=None, dtype=torch.float, device='cpu'):
         """sdf.py:604-614: the cache's own view, or the ground-truth SDF sampled over another voxel grid (points outside that
         grid are answered by the ground-truth SDF: _fallback_sdf_value_func, sdf.py:530-533)."""
@@ -680,7 +695,7 @@ class CachedSDF(ObjectFrameSDF):
         sdf_val, _ = self.gt_sdf(pts.unsqueeze(0))
         sampled = sdf_val.to(device=self.device).reshape([len(coord) for coord in voxels.coords])
         return ValueRangeView(sampled, voxels.range_per_dim,
-                              invalid_value=lambda q: self.gt_sdf(q)[0].to(device=self.device))
+                              invalid_value=self._fallback_sdf_value_func)
 
 
 class PreparedPoints:
