@@ -191,9 +191,13 @@ class PlausibleDiversity:
         return batch_chamfer_dist(relative.reshape(B * P, 4, 4), self.model_points_eval, self.obj_factory, obj_sdf=self.obj_sdf,
                                   scale=scale).view(B, P)
 
-    # the reference's names for the two steps
-    compute_tf_pairwise_error_per_batch = pairwise_errors
-    do_evaluate_plausible_diversity_on_pairwise_chamfer_dist = staticmethod(reduce_pairwise_errors)
+    # the reference's names for the two steps, with its parameter names (chamfer.py:173, 185)
+    def compute_tf_pairwise_error_per_batch(self, T_est_inv, T_p, scale=1000.):
+        return self.pairwise_errors(T_est_inv, T_p, scale=scale)
+
+    @staticmethod
+    def do_evaluate_plausible_diversity_on_pairwise_chamfer_dist(errors_per_batch):
+        return reduce_pairwise_errors(errors_per_batch)
 
     def __call__(self, T_est_inv, T_p, bidirectional=False, scale=1000.):
         forward = reduce_pairwise_errors(self.pairwise_errors(T_est_inv, T_p, scale=scale))

@@ -363,6 +363,43 @@ def test_every_public_name_of_the_reference_exists_here():
     assert [n for n in exported if not hasattr(pv, n)] == []  # pytorch_volumetric/__init__.py:1-9
 
 
+def test_reference_signatures_are_kept():
+    """tests/golden/reference_signatures.json (make_signatures.py: parameter NAMES of every public function / method of the
+    reference and which have defaults): the same positional names in the same order here (more may follow), and a default wherever
+    the reference has one -- keyword callers and positional callers both keep working."""
+    import importlib
+    import inspect
+    import json
+    ref = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "reference_signatures.json")))
+    assert len(ref) > 60
+    mods = {"voxel": ("voxel", "voxel_containers")}
+    problems = []
+    for key, (names, with_default) in ref.items():
+        mod, *path = key.split(".")
+        obj = None
+        for m in mods.get(mod, (mod,)):
+            cur = importlib.import_module("pytorch_volumetric_amd." + m)
+            try:
+                for part in path:
+                    cur = getattr(cur, part)
+                obj = cur
+                break
+            except AttributeError:
+                continue
+        if obj is None:
+            problems.append(f"{key}: missing")
+            continue
+        params = inspect.signature(obj).parameters
+        ours = [p.name for p in params.values() if p.kind in (p.POSITIONAL_ONLY, p.POSITIONAL_OR_KEYWORD)]
+        if names and names[0] == "self" and (not ours or ours[0] != "self"):
+            names = names[1:]  # a staticmethod / bound form here
+        if ours[:len(names)] != names:
+            problems.append(f"{key}: reference {names}, here {ours}")
+            continue
+        problems += [f"{key}: '{n}' has a default in the reference" for n in with_default if params[n].default is inspect.Parameter.empty]
+    assert problems == []
+
+
 def test_slice_and_voxel_view_callers_of_the_query_path():
     """visualization.draw_sdf_slice (README.md:115) and ObjectFrameSDF.get_voxel_view / get_filtered_points (sdf.py:248-282):
     thin callers, one batched __call__ each; checked on the closed-form SphereSDF (no GPU)."""
