@@ -91,3 +91,15 @@ def bounds_contain_another_bounds(outer_bounds, inner_bounds):
     """Whether outer_bounds (d x 2) contains inner_bounds (voxel.py:134-136)."""
     outer_bounds, inner_bounds = np.asarray(outer_bounds), np.asarray(inner_bounds)
     return bool(np.all(outer_bounds[:, 0] <= inner_bounds[:, 0]) and np.all(outer_bounds[:, 1] >= inner_bounds[:, 1]))
+
+
+_CONTAINERS = ("Voxels", "VoxelGrid", "ExpandingVoxelGrid", "VoxelSet", "voxel_down_sample", "ValueRangeView")
+
+
+def __getattr__(name):
+    """The reference keeps its voxel containers in voxel.py (voxel.py:28-171); here they live in voxel_containers.py (which
+    imports this module), and `from pytorch_volumetric_amd.voxel import VoxelGrid` still finds them."""
+    if name in _CONTAINERS:
+        from pytorch_volumetric_amd import voxel_containers
+        return getattr(voxel_containers, name)
+    raise AttributeError(f"module {__name__!r} has no attribute {name!r}")

@@ -340,9 +340,9 @@ REFERENCE_SURFACE = {
 
 def test_every_public_name_of_the_reference_exists_here():
     """A user of the reference switches the import and finds every function, class and method (names; signatures are pinned by
-    the tests that call them).  The containers of voxel.py live in voxel_containers.py here; both are searched."""
+    the tests that call them), under the reference's own module names (voxel.py forwards to voxel_containers.py)."""
     import importlib
-    mods = {"voxel": ("voxel", "voxel_containers")}
+    mods = {}
     missing = []
     for mod, groups in REFERENCE_SURFACE.items():
         homes = [importlib.import_module("pytorch_volumetric_amd." + m) for m in mods.get(mod, (mod,))]
@@ -372,7 +372,7 @@ def test_reference_signatures_are_kept():
     import json
     ref = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "reference_signatures.json")))
     assert len(ref) > 60
-    mods = {"voxel": ("voxel", "voxel_containers")}
+    mods = {}
     problems = []
     for key, (names, with_default) in ref.items():
         mod, *path = key.split(".")
