@@ -15,10 +15,10 @@ the RCCL all-gather in the timed step, and C5 (chamfer, 2M points -> 99,500 tria
 The LAST stdout line (rank 0) is the contract line: compact JSON, < 4 KB (tests/test_bench_launch.py asserts the size),
 built by `compact_line()` from the long record.  The long record (every leg's detail, latency percentiles, README legs) is
 written to `bench_detail.json` (--detail PATH) and to stderr, never to the contract line.  `value` / `ms_per_step` are the
-wall time of exactly the K steps asked for.  `roofline` is the dominant kernel (pvamd::cached_query_wave), 28 B/query over
-its per-launch duration: `frac` uses the committed rocprofv3 kernel-trace average of this command when there is one for
-this point count (profiles/rNN_kernel_stats.json), `frac_events` the live HIP-event figure of this run (a separate
->= 2000-launch hipGraph of the same call, so it does not depend on K).  `cpu_baseline` = the restatements on the host cores.
+wall time of exactly the K steps asked for.  `roofline` is the dominant kernel (pvamd::cached_query_direct at 1M points), 28 B/query over
+its per-launch duration: `frac` is THIS run's (HIP events on the launch stream around a separate >= 2000-launch hipGraph of the
+same call, so it does not depend on K); `frac_rocprof` is the committed rocprofv3 kernel-trace average of this command
+(profiles/rNN_kernel_stats.json), `frac_wall` the contract's own timed region.  `cpu_baseline` = the restatements on the host cores.
 """
 import argparse
 import gc
@@ -233,6 +233,16 @@ def read_traffic(P):
         except Exception:
             pass
     return None, None
+
+
+def cached_query_kernel_name(P):
+    """The kernel pvamd_cached_query launches for P points (csrc/cached.hip cq_kind, include/pvamd.h PVAMD_CQ_KERNEL_*)."""
+    from pytorch_volumetric_amd import _lib
+    names = {0: "pvamd::cached_query_scalar", 1: "pvamd::cached_query_direct<1 point per lane, 8 waves>",
+             2: "pvamd::cached_query_direct<2 points per lane, 4 waves>", 3: "pvamd::cached_query_direct<2 points per lane, 16 waves>",
+             4: "pvamd::cached_query_direct<4 points per lane, 4 waves>", 5: "pvamd::cached_query_wave",
+             6: "pvamd::cached_query_wave (streaming)"}
+    return names[int(_lib.load().pvamd_cached_query_kernel(P))]
 
 
 def read_rocprof_kernel_us(P):
@@ -494,7 +504,7 @@ def main():
                        "backend": (dist.get_backend() if use_pg else None), "gpus_requested": args.gpus},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
-                         "kernel": "pvamd::cached_query_wave", "algorithmic_bytes_per_launch": algo,
+                         "kernel": cached_query_kernel_name(P), "algorithmic_bytes_per_launch": algo,
                          "launch_us": launch_us, "launch_source": "hip events (this run)",
                          "frac_is": f"28 B x P / mean launch duration, HIP events around a hipGraph of {kg_n} launches, this run",
                          "rocprof_launch_us": rocprof_us, "rocprof_calls": rocprof_calls, "rocprof_source": rocprof_source,

@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define PVAMD_ABI_VERSION 11
+#define PVAMD_ABI_VERSION 12
 
 #define PVAMD_E_NULL      (-1)  /* a required pointer is NULL            */
 #define PVAMD_E_SHAPE     (-2)  /* a size/shape argument is out of range */
@@ -159,6 +159,17 @@ int pvamd_pack_grid(const float* val, const float* grad, int64_t n, float* out, 
  * out_oob: device [P] bytes or NULL; 1 where the point failed the range test (sdf.py:540-541).        */
 int pvamd_cached_query(const pvamd_grid_t* grid, const float* points, int64_t P,
                        float* out_val, float* out_grad, uint8_t* out_oob, void* stream);
+
+/* Host-side, pure: which kernel pvamd_cached_query launches for P points (one launch for any P; the choice depends on P
+ * only) -- for tests that want every kernel covered and for a profile that wants to name the kernel it measured.        */
+#define PVAMD_CQ_KERNEL_SCALAR     0  /* one point per lane, grid-stride                                  (P < 16,384) */
+#define PVAMD_CQ_KERNEL_DIRECT_1   1  /* cached_query_direct: no LDS, 1 point per lane,  8 waves per workgroup        */
+#define PVAMD_CQ_KERNEL_DIRECT_2   2  /*                              2 points per lane, 4 waves                      */
+#define PVAMD_CQ_KERNEL_DIRECT_2W  3  /*                              2 points per lane, 16 waves (about 1M points)   */
+#define PVAMD_CQ_KERNEL_DIRECT_4   4  /*                              4 points per lane, 4 waves                      */
+#define PVAMD_CQ_KERNEL_WAVE_TILE  5  /* cached_query_wave: 256-point tiles through LDS                               */
+#define PVAMD_CQ_KERNEL_STREAMING  6  /* cached_query_wave, streaming instantiation                      (P > 8M)    */
+int pvamd_cached_query_kernel(int64_t P);
 
 /* CachedSDF.outside_surface (sdf.py:593-602): OOB -> 1, else vox.val > level.  out: device [P] bytes. */
 int pvamd_cached_outside(const pvamd_grid_t* grid, const float* points, int64_t P, float level,

@@ -11,7 +11,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("PVAMD_LIB") or os.path.join(_HERE, "csrc", "libpvamd.so")  # PVAMD_LIB: A/B builds (tools/)
 
-ABI_VERSION = 11
+ABI_VERSION = 12
 OOB_LOOKUP_GT_SDF = 0
 OOB_BOUNDING_BOX = 1
 COMPOSED_INLINE_EXACT = 1
@@ -140,6 +140,7 @@ SIGNATURES = {
                                                      ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_int64,
                                                      ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int32,
                                                      ctypes.c_void_p]),
+    "pvamd_cached_query_kernel": (ctypes.c_int, [ctypes.c_int64]),
     "pvamd_group_chunk_points": (ctypes.c_int64, []),
     "pvamd_group_scratch_bytes": (ctypes.c_int64, [ctypes.c_int64]),
     "pvamd_group_points": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p]),

@@ -149,6 +149,70 @@ __global__ __launch_bounds__(kWavesPerBlock * 64, PVAMD_CQ_MINWAVES) void cached
     }
 }
 
+// ---- direct path (round 6): no LDS -- launches that fit the chip in about one round of resident waves (up to 8M points) ----
+// Lane l of a wave owns points l, l + 64, ... (PPL of them) of the wave's tile of 64 x PPL consecutive points and moves each with
+// 12-byte accesses at a 12-byte lane stride: every global_load_dwordx3 / global_store_dwordx3 covers a contiguous 768 B, the value
+// store a contiguous 256 B -- the same bytes per instruction slot of the address path as the 16-byte accesses of the wave-tile
+// kernel above, without the four LDS passes (12 KB per 256 points) and the wave fences that kernel's AoS <-> per-lane transposes
+// need.  One tile per wave, all PPL point loads issued before the first look-up; non-temporal stores (with plain stores the
+// 1M-point launch takes 6.9 us instead of 5.5; non-temporal LOADS cost 5-60 % while the points are cache-resident).  Against
+// the wave-tile kernel, same box, tools/cq_sweep.py (profiles/r06_cq_direct.txt): 16K-512K points 4.5-5.0 -> 2.4-3.7 us, 1M points
+// 5.56 -> 5.18 us (0.65 -> 0.71 of 8 TB/s), 4M 20.4 -> 18.9 us, 8M 36.9 -> 35.3 us (0.80 -> 0.83).  Beyond the Infinity Cache the
+// wave-tile kernel stays: 64M points 337 us against 405-460 us in this form (its 16-byte accesses and its read-ahead matter there),
+// and it keeps the sizes around 2M points where its 512 workgroups are exactly one round (9.13 against 9.3-9.5 us).
+// Any point count >= 64 x PPL and any 4-byte aligned buffers; a ragged end moves the last tile back so that it ends at the last point.
+template <bool F64, bool WRITE_OOB, int PPL, int WAVES>
+__global__ __launch_bounds__(WAVES * 64) void cached_query_direct(const pvamd_grid_t g, const float* __restrict__ pts, int64_t P,
+                                                                  float* __restrict__ val, float* __restrict__ grad,
+                                                                  uint8_t* __restrict__ oob) {
+    constexpr int kTile = 64 * PPL;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t tile = (int64_t)blockIdx.x * WAVES + wave;
+    if (tile * kTile >= P) return;  // wave-uniform
+    const int64_t o = (tile * kTile <= P - kTile ? tile * kTile : P - kTile) + lane;
+    float px[PPL], py[PPL], pz[PPL];
+#pragma unroll
+    for (int k = 0; k < PPL; ++k) {
+        const int64_t i = o + 64 * k;
+        px[k] = pts[3 * i];
+        py[k] = pts[3 * i + 1];
+        pz[k] = pts[3 * i + 2];
+    }
+#pragma unroll
+    for (int k = 0; k < PPL; ++k) {
+        const int64_t i = o + 64 * k;
+        bool valid;
+        const float4 r = cached_lookup<F64, false>(g, px[k], py[k], pz[k], valid);
+        __builtin_nontemporal_store(r.x, val + i);
+        __builtin_nontemporal_store(r.y, grad + 3 * i);
+        __builtin_nontemporal_store(r.z, grad + 3 * i + 1);
+        __builtin_nontemporal_store(r.w, grad + 3 * i + 2);
+        if constexpr (WRITE_OOB) oob[i] = valid ? 0 : 1;
+    }
+}
+
+// Which kernel serves P points (measured, profiles/r06_cq_direct.txt; one MI355X = 256 CUs x 32 resident waves):
+//   < 16,384            one point per lane, grid-stride (cached_query_scalar)
+//   .. 160K             direct, 1 point per lane, 8 waves      .. 896K   direct, 2 points per lane, 4 waves
+//   .. 1M               direct, 2 points per lane, 16 waves (8192 waves in 512 workgroups: exactly two per CU)
+//   .. 1.6M             direct, 4 points per lane, 4 waves      .. 2.25M  wave-tile kernel (512 workgroups = one round)
+//   .. 8M               direct, 4 points per lane, 4 waves      beyond    wave-tile kernel, streaming instantiation
+enum CqKind {
+    kCqScalar = PVAMD_CQ_KERNEL_SCALAR, kCqDirect1 = PVAMD_CQ_KERNEL_DIRECT_1, kCqDirect2 = PVAMD_CQ_KERNEL_DIRECT_2,
+    kCqDirect2Wide = PVAMD_CQ_KERNEL_DIRECT_2W, kCqDirect4 = PVAMD_CQ_KERNEL_DIRECT_4, kCqWaveTile = PVAMD_CQ_KERNEL_WAVE_TILE,
+    kCqStreaming = PVAMD_CQ_KERNEL_STREAMING
+};
+static inline CqKind cq_kind(int64_t P) {
+    if (P < kWaveTileMinPoints) return kCqScalar;
+    if (P <= 160 * 1024) return kCqDirect1;
+    if (P <= 896 * 1024) return kCqDirect2;
+    if (P <= 1024 * 1024) return kCqDirect2Wide;
+    if (P <= 1600 * 1024) return kCqDirect4;
+    if (P <= 2304 * 1024) return kCqWaveTile;
+    if (P <= ((int64_t)8 << 20)) return kCqDirect4;
+    return kCqStreaming;
+}
+
 // ---- one point per lane: small batches (more waves than 256-point tiles would give) ----
 template <bool F64>
 __global__ __launch_bounds__(256) void cached_query_scalar(const pvamd_grid_t g, const float* __restrict__ pts,
@@ -270,6 +334,8 @@ extern "C" int pvamd_pack_grid(const float* val, const float* grad, int64_t n, f
     return (int)hipGetLastError();
 }
 
+extern "C" int pvamd_cached_query_kernel(int64_t P) { return (int)cq_kind(P); }
+
 extern "C" int pvamd_cached_query(const pvamd_grid_t* grid, const float* points, int64_t P, float* out_val,
                                   float* out_grad, uint8_t* out_oob, void* stream) {
     if (P < 0) return PVAMD_E_SHAPE;
@@ -279,9 +345,9 @@ extern "C" int pvamd_cached_query(const pvamd_grid_t* grid, const float* points,
     if (!aligned_to(points, 4) || !aligned_to(out_val, 4) || !aligned_to(out_grad, 4)) return PVAMD_E_ALIGN;
     hipStream_t s = (hipStream_t)stream;
     const bool f64 = grid->index_f64 != 0;
-    // One launch for any P.  >= 16,384 points (64 tiles = a workgroup per four CUs): the wave-tile kernel, which finishes a
-    // partial last tile itself; fewer: one point per lane (4x the waves, nothing to amortise).
-    if (P >= kWaveTileMinPoints) {
+    // One launch for any P (cq_kind above).
+    const CqKind kind = cq_kind(P);
+    if (kind == kCqWaveTile || kind == kCqStreaming) {
         const int64_t ntiles = (P + kTilePoints - 1) / kTilePoints;
         const int64_t need = (ntiles + kWavesPerBlock - 1) / kWavesPerBlock;
 // The streaming regime (> 8M points, far beyond the 256 MB Infinity Cache), round 3 (tools/cq_sweep.py over build
@@ -300,7 +366,7 @@ extern "C" int pvamd_cached_query(const pvamd_grid_t* grid, const float* points,
 #ifndef PVAMD_CQ_BIG_BLOCKS
 #define PVAMD_CQ_BIG_BLOCKS 0
 #endif
-        const bool big = P > ((int64_t)8 << 20);  // > 8M points (96 MB of xyz): streaming regime
+        const bool big = kind == kCqStreaming;  // > 8M points (96 MB of xyz)
         const int64_t cap = big ? PVAMD_CQ_BIG_BLOCKS : PVAMD_CQ_BLOCKS;  // 0: one tile per wave, no grid-stride loop
         const dim3 grid_dim((unsigned)((cap > 0 && need > cap) ? cap : need)), block(kWavesPerBlock * 64);
 #define PVAMD_LAUNCH_CQ(F64_, OOB_)                                                                                      \
@@ -316,6 +382,24 @@ extern "C" int pvamd_cached_query(const pvamd_grid_t* grid, const float* points,
             else PVAMD_LAUNCH_CQ(false, false);
         }
 #undef PVAMD_LAUNCH_CQ
+    } else if (kind != kCqScalar) {
+#define PVAMD_LAUNCH_DIRECT(PPL_, WAVES_)                                                                               \
+    do {                                                                                                                \
+        const int64_t tiles_ = (P + 64 * PPL_ - 1) / (64 * PPL_);                                                       \
+        const dim3 grid_dim((unsigned)((tiles_ + WAVES_ - 1) / WAVES_)), block(WAVES_ * 64);                            \
+        if (f64) {                                                                                                      \
+            if (out_oob) hipLaunchKernelGGL((cached_query_direct<true, true, PPL_, WAVES_>), grid_dim, block, 0, s, *grid, points, P, out_val, out_grad, out_oob);   \
+            else hipLaunchKernelGGL((cached_query_direct<true, false, PPL_, WAVES_>), grid_dim, block, 0, s, *grid, points, P, out_val, out_grad, out_oob);        \
+        } else {                                                                                                        \
+            if (out_oob) hipLaunchKernelGGL((cached_query_direct<false, true, PPL_, WAVES_>), grid_dim, block, 0, s, *grid, points, P, out_val, out_grad, out_oob);  \
+            else hipLaunchKernelGGL((cached_query_direct<false, false, PPL_, WAVES_>), grid_dim, block, 0, s, *grid, points, P, out_val, out_grad, out_oob);       \
+        }                                                                                                               \
+    } while (0)
+        if (kind == kCqDirect1) PVAMD_LAUNCH_DIRECT(1, 8);
+        else if (kind == kCqDirect2) PVAMD_LAUNCH_DIRECT(2, 4);
+        else if (kind == kCqDirect2Wide) PVAMD_LAUNCH_DIRECT(2, 16);
+        else PVAMD_LAUNCH_DIRECT(4, 4);
+#undef PVAMD_LAUNCH_DIRECT
     } else {
         const dim3 grid_dim(stream_grid(P, 256)), block(256);
         if (f64) hipLaunchKernelGGL((cached_query_scalar<true>), grid_dim, block, 0, s, *grid, points, (int64_t)0, P, out_val, out_grad, out_oob);

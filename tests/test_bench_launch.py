@@ -91,7 +91,7 @@ def fat_record(world=8):
                        "points_per_gpu": 1048576, "oob_fraction": x, "ranks": world, "backend": "nccl", "gather": False,
                        "launch": "one hipGraph of the K steps"},
             "roofline": {"bound": "hbm", "achieved": 4690.0 + x, "peak": 8000.0, "unit": "GB/s", "frac": x, "traffic": 35736551.39 + x,
-                         "algorithmic_bytes_per_launch": 29360128, "kernel": "pvamd::cached_query_wave", "launch_us": 6 + x,
+                         "algorithmic_bytes_per_launch": 29360128, "kernel": "pvamd::cached_query_direct<2 points per lane, 16 waves>", "launch_us": 6 + x,
                          "launch_source": "hip events (this run)", "frac_rocprof": x, "frac_events": x, "launch_us_events": x,
                          "frac_wall": x, "events": "z" * 110},
             "cpu_baseline": {"value": 8.5e6 + x, "unit": "queries/s", "cores": 128, "kind": "port", "host_cpus": 256,

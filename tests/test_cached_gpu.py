@@ -409,3 +409,66 @@ def test_nan_and_inf_points_through_the_wave_tile_kernel_in_both_oob_modes(oob, 
         oval[idx], ograd[idx] = v_gt.cpu().numpy(), g_gt.cpu().numpy()
     assert np.array_equal(val.cpu().numpy(), oval, equal_nan=True)
     assert np.array_equal(grad.cpu().numpy(), ograd, equal_nan=True)
+
+
+def _kernel_boundaries():
+    """Point counts either side of every threshold of pvamd_cached_query's kernel choice (found by scanning
+    pvamd_cached_query_kernel in steps of 4096 and bisecting inside a step, so the test follows the thresholds if they are
+    retuned; a kernel may serve more than one range), plus a ragged size after each threshold."""
+    lib = pv._lib.load()
+    kind = lambda p: int(lib.pvamd_cached_query_kernel(p))
+    top = (8 << 20) + 4096
+    sizes, prev = {1, top}, 1
+    for p in range(4096, top + 1, 4096):
+        if kind(p) != kind(prev):
+            a, b = prev, p
+            while b - a > 1:  # kind(a) == kind(prev) != kind(b)
+                m = (a + b) // 2
+                a, b = (m, b) if kind(m) == kind(prev) else (a, m)
+            sizes.update({a, b, min(b + 191, top)})
+        prev = p
+    return sorted(sizes)
+
+
+@pytest.mark.parametrize("f64", [True, False])
+def test_every_kernel_of_the_size_dispatch_matches_the_oracle_bitwise(f64):
+    """Round 6: pvamd_cached_query picks one of seven kernels / instantiations by the point count (csrc/cached.hip cq_kind).  Every
+    one of them, at the first and last size it serves and at a ragged size, on buffers at odd dword offsets, with and without the
+    out-of-range mask, against the oracle: same bits."""
+    import ctypes
+    c = make_cached(f64=f64)
+    og = H.oracle_grid_from_cached(c)
+    lib = pv._lib.load()
+    sizes = _kernel_boundaries()
+    seen = {int(lib.pvamd_cached_query_kernel(p)) for p in sizes}
+    assert seen == set(range(7)), seen  # PVAMD_CQ_KERNEL_*: all seven
+    top = max(sizes)
+    lo = np.array([r[0] for r in c.ranges]) - 0.05
+    hi = np.array([r[1] for r in c.ranges]) + 0.05
+    import workloads
+    pool = workloads.uniform_points_device(top + 1, lo, hi, seed=31)  # one pool; every size reads a window at a 12-byte offset
+    pool[5, 0] = float("nan")
+    pool[77, 2] = float("inf")
+    opts = pool.cpu().numpy()
+    oval, ograd, ooob = oracle.cached_query(og, opts)
+    vbuf = torch.empty(top + 3, device="cuda")
+    gbuf = torch.empty(3 * top + 5, device="cuda")
+    obuf = torch.empty(top + 1, dtype=torch.uint8, device="cuda")
+    desc = c._grid_desc()
+    for i, P in enumerate(sizes):
+        first = 1 + (i % 2)  # windows starting at point 1 or 2: 12- and 24-byte offsets
+        if first + P > top + 1:
+            first = top + 1 - P
+        pts = pool[first:first + P]
+        val, grad = vbuf[1:1 + P], gbuf[1:1 + 3 * P]  # odd dword addresses
+        vbuf.fill_(-7.0); gbuf.fill_(-7.0); obuf.fill_(9)
+        want_oob = i % 3 != 0
+        pv._lib.check(lib.pvamd_cached_query(ctypes.byref(desc), pv._lib.ptr(pts), P, pv._lib.ptr(val), pv._lib.ptr(grad),
+                                             pv._lib.ptr(obuf) if want_oob else None, pv._lib.stream_ptr()), "pvamd_cached_query")
+        torch.cuda.synchronize()
+        assert np.array_equal(val.cpu().numpy(), oval[first:first + P], equal_nan=True), P
+        assert np.array_equal(grad.cpu().numpy().reshape(P, 3), ograd[first:first + P], equal_nan=True), P
+        assert float(vbuf[0]) == -7.0 and float(vbuf[1 + P]) == -7.0 and float(gbuf[0]) == -7.0 and float(gbuf[1 + 3 * P]) == -7.0, P
+        if want_oob:
+            assert np.array_equal(obuf[:P].cpu().numpy().astype(bool), ooob[first:first + P].astype(bool)), P
+            assert int(obuf[P]) == 9  # nothing written past the end

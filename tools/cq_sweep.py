@@ -10,13 +10,15 @@ cached = Wk.build_c2_cache()
 out = []
 margins = [float(m) for m in os.environ.get("CQ_MARGINS", "0.05").split(",")]
 sizes = [int(x) for x in os.environ.get("CQ_LOGP", "20,23,26").split(",")]
+if os.environ.get("CQ_P"):  # explicit point counts (any integer), e.g. CQ_P=1310720,1572864
+    sizes = [float(np.log2(int(x))) for x in os.environ["CQ_P"].split(",")]
 for logp in sizes:
     for margin in (margins if logp == 26 else margins[:1]):
-        P = 1 << logp
+        P = int(round(2.0 ** logp))
         pts = Wk.c2_points(cached, P, seed=99, margin=margin)
         val = torch.empty((P,), dtype=torch.float32, device="cuda")
         grad = torch.empty((P, 3), dtype=torch.float32, device="cuda")
-        reps = 2000 if logp == 20 else (200 if logp == 23 else 40)
+        reps = 2000 if logp <= 20 else (400 if logp <= 22 else (200 if logp == 23 else 40))
         for _ in range(max(60, reps // 4)):
             cached.query_into(pts, val, grad)
         g = torch.cuda.CUDAGraph()
@@ -33,7 +35,7 @@ for logp in sizes:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record(); g.replay(); e1.record(); torch.cuda.synchronize()
             best = min(best, e0.elapsed_time(e1) / reps)
-        tag = f"2^{logp}" + ("" if margin == margins[0] else f"[margin {margin}]")
+        tag = (f"2^{logp}" if float(logp).is_integer() else f"{P}") + ("" if margin == margins[0] else f"[margin {margin}]")
         out.append(f"{tag}: {best*1e3:.2f} us {28*P/best/1e6:.0f} GB/s")
         del g, pts, val, grad
 print(os.environ.get("PVAMD_LIB", "default"), " | ".join(out), flush=True)

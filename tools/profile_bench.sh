@@ -16,9 +16,13 @@ for f in glob.glob("$O/kt/**/*kernel_trace.csv", recursive=True):
         wg = r.get("Workgroup_Size_X") or r.get("Workgroup_Size") or "?"
         d = (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3
         name = r["Kernel_Name"][:96]
-        if "cached_query_wave<true, false, false, true>" in name:  # same capped grid for every size: split by duration
-            name += (" [1,048,576-point launches]" if d < 20 else " [8M-point launches of the mid_batch leg]" if d < 100 else
-                     " [64M-point launches of the large_batch leg]" if d < 420 else " [1e8-point launches of the p1e8_batch leg]")
+        # pvamd_cached_query picks the kernel by the point count (csrc/cached.hip cq_kind): one instantiation per size class of the bench
+        if "cached_query_direct<true, false, 2, 16>" in name:
+            name += " [1,048,576-point launches]"
+        elif "cached_query_direct<true, false, 4, 4>" in name:
+            name += " [8M-point launches of the mid_batch leg]"
+        elif "cached_query_wave<true, false, true, true>" in name:
+            name += " [64M-point launches of the large_batch leg]" if d < 420 else " [1e8-point launches of the p1e8_batch leg]"
         rows[(name, grid, wg)].append(d)
 total = sum(sum(v) for v in rows.values())
 print("| kernel | grid (threads) x workgroup | calls | total us | avg us | min us | max us | % |")
@@ -36,7 +40,7 @@ if dom:
               open("$O/kernel_stats.json", "w"), indent=1)
 PY
 F=$(find $O/fetch -name "*counter_collection.csv" | head -1); W=$(find $O/write -name "*counter_collection.csv" | head -1)
-[ -z "$ONLY_KT" ] && python tools/pmc_summary.py $F $W cached_query_wave 1048576 > $O/traffic.json
+[ -z "$ONLY_KT" ] && python tools/pmc_summary.py $F $W "cached_query_direct<true, false, 2, 16>" 1048576 > $O/traffic.json
 find $O -name "*.csv" -size +1M -delete
 tail -c 2500 $O/bench_k20.json | head -c 100 > /dev/null
 head -12 $O/kernel_stats.md; cat $O/traffic.json
