@@ -53,7 +53,9 @@ def test_cached_query_fuzz(seed):
     f64, far = bool(seed % 2), seed % 3 == 0
     c, r = random_cached(rng, f64, far)
     og = H.oracle_grid_from_cached(c)
-    n = int(rng.choice([1, 63, 255, 256, 257, 4097, 50_001]))
+    n = int(rng.choice([1, 63, 255, 256, 257, 4097, 16_385, 50_001, 200_001]))
+    if seed % 8 == 5:  # the larger kernels of pvamd_cached_query's size dispatch (csrc/cached.hip cq_kind), ragged sizes
+        n = int(rng.choice([950_003, 1_048_576, 1_200_001, 2_000_003, 2_500_001]))
     span = r[:, 1] - r[:, 0]
     pts = (r[:, 0] - 0.2 * span + rng.random((n, 3)) * 1.4 * span).astype(np.float32)
     # sprinkle exact voxel centres, half-voxel planes, range corners and specials
