@@ -204,12 +204,18 @@ enum CqKind {
 };
 static inline CqKind cq_kind(int64_t P) {
     if (P < kWaveTileMinPoints) return kCqScalar;
+#ifdef PVAMD_CQ_NO_DIRECT  // A/B: the round-5 choice
+    return P <= ((int64_t)8 << 20) ? kCqWaveTile : kCqStreaming;
+#endif
     if (P <= 160 * 1024) return kCqDirect1;
     if (P <= 896 * 1024) return kCqDirect2;
     if (P <= 1024 * 1024) return kCqDirect2Wide;
     if (P <= 1600 * 1024) return kCqDirect4;
     if (P <= 2304 * 1024) return kCqWaveTile;
-    if (P <= ((int64_t)8 << 20)) return kCqDirect4;
+#ifndef PVAMD_CQ_STREAM_FROM
+#define PVAMD_CQ_STREAM_FROM ((int64_t)8 << 20)
+#endif
+    if (P <= PVAMD_CQ_STREAM_FROM) return kCqDirect4;
     return kCqStreaming;
 }
 

@@ -16,6 +16,10 @@ for logp in sizes:
     for margin in (margins if logp == 26 else margins[:1]):
         P = int(round(2.0 ** logp))
         pts = Wk.c2_points(cached, P, seed=99, margin=margin)
+        # CQ_COLD_MB=N: rotate over enough distinct point buffers (N MB of xyz in total) that a launch never finds its points in the
+        # 256 MB Infinity Cache from the replay before
+        n_rot = max(1, -(-int(os.environ.get("CQ_COLD_MB", "0")) * (1 << 20) // (12 * P)))
+        rot = [pts] + [Wk.c2_points(cached, P, seed=100 + j, margin=margin) for j in range(n_rot - 1)]
         val = torch.empty((P,), dtype=torch.float32, device="cuda")
         grad = torch.empty((P, 3), dtype=torch.float32, device="cuda")
         reps = 2000 if logp <= 20 else (400 if logp <= 22 else (200 if logp == 23 else 40))
@@ -26,8 +30,8 @@ for logp in sizes:
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
             with torch.cuda.graph(g, stream=side):
-                for _ in range(reps):
-                    cached.query_into(pts, val, grad)
+                for j in range(reps):
+                    cached.query_into(rot[j % n_rot], val, grad)
         torch.cuda.current_stream().wait_stream(side)
         g.replay(); torch.cuda.synchronize()
         best = 1e9
@@ -35,7 +39,7 @@ for logp in sizes:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record(); g.replay(); e1.record(); torch.cuda.synchronize()
             best = min(best, e0.elapsed_time(e1) / reps)
-        tag = (f"2^{logp}" if float(logp).is_integer() else f"{P}") + ("" if margin == margins[0] else f"[margin {margin}]")
+        tag = ("cold " if n_rot > 1 else "") + (f"2^{logp}" if float(logp).is_integer() else f"{P}") + ("" if margin == margins[0] else f"[margin {margin}]")
         out.append(f"{tag}: {best*1e3:.2f} us {28*P/best/1e6:.0f} GB/s")
-        del g, pts, val, grad
+        del g, pts, val, grad, rot
 print(os.environ.get("PVAMD_LIB", "default"), " | ".join(out), flush=True)
