@@ -294,6 +294,32 @@ class on_device:
         return False
 
 
+_fast = False  # False: not looked for yet; None: absent / disabled
+
+
+def fastcall():
+    """The optional host-call module (csrc/fastcall.cpp -> pytorch_volumetric_amd/_pvamd_fast.so; `make -C csrc fast`,
+    built by __graft_entry__.build()): the two allocations + the C-ABI call of the drop-in fast paths without the interpreter
+    in between (cached(points) 7.4 -> 5.9 us of host time).  Plumbing only -- the same entry points of the same libpvamd.so,
+    by address; None when it has not been built or PVAMD_NO_FASTCALL=1, and the ctypes path runs instead."""
+    global _fast
+    if _fast is False:
+        _fast = None
+        if os.environ.get("PVAMD_NO_FASTCALL") != "1":
+            try:
+                from pytorch_volumetric_amd import _pvamd_fast
+                _pvamd_fast.set_error_class(PvamdError)
+                _fast = _pvamd_fast
+            except ImportError:
+                pass
+    return _fast
+
+
+def entry_address(name):
+    """Address of a libpvamd.so entry point (what _pvamd_fast calls through)."""
+    return ctypes.cast(getattr(load(), name), ctypes.c_void_p).value
+
+
 # Bumped whenever an attribute that the cached call plans of CachedSDF / ComposedSDF depend on is assigned
 # (CachedSDF.__setattr__): a plan remembers the epoch it was built in and is rebuilt when it has moved on.
 EPOCH = [0]

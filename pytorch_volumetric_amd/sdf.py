@@ -562,7 +562,9 @@ class CachedSDF(ObjectFrameSDF):
         plan = None
         if ok:
             desc = self._grid_desc()
-            plan = (dev, dev.index, ctypes.byref(desc), _lib.load().pvamd_cached_query, desc)
+            fast = _lib.fastcall()
+            plan = (dev, dev.index, ctypes.byref(desc), _lib.load().pvamd_cached_query, desc, fast,
+                    _lib.entry_address("pvamd_cached_query") if fast is not None else 0, ctypes.addressof(desc))
         object.__setattr__(self, "_plan", (_lib.EPOCH[0], plan))
         return plan
 
@@ -605,6 +607,11 @@ class CachedSDF(ObjectFrameSDF):
         # call, 5.1 us through query_into; the kernel itself takes 5.2 us for a million points, 2.4 us for 15,251)
         cached = self.__dict__.get("_plan")
         plan = cached[1] if cached is not None and cached[0] == _lib.EPOCH[0] else self._fast_plan()
+        if plan is not None and plan[5] is not None and type(p) is torch.Tensor:
+            # csrc/fastcall.cpp: the same checks, allocations and C-ABI call as the branch below, in C++ (None: not its case)
+            out = plan[5].cached_call(plan[6], plan[7], plan[1], p)
+            if out is not None:
+                return out
         if plan is not None and type(p) is torch.Tensor and p.dtype is torch.float32 and p.device == plan[0] and \
                 p.is_contiguous() and p.dim() >= 1 and p.shape[-1] == 3 and _lib.current_device_index() == plan[1]:
             # (p is float32, contiguous, on plan[0]: empty_like / new_empty give the same tensors as torch.empty(shape, dtype=,
@@ -656,6 +663,8 @@ class CachedSDF(ObjectFrameSDF):
         cached = self.__dict__.get("_plan")
         plan = cached[1] if cached is not None and cached[0] == _lib.EPOCH[0] else self._fast_plan()
         if plan is not None and type(points) is torch.Tensor and type(out_val) is torch.Tensor and type(out_grad) is torch.Tensor:
+            if plan[5] is not None and plan[5].cached_into(plan[6], plan[7], plan[1], points, out_val, out_grad):
+                return  # csrc/fastcall.cpp: the checks below and the call, in C++
             dev, f32 = plan[0], torch.float32
             if points.dtype is f32 and out_val.dtype is f32 and out_grad.dtype is f32 and points.device == dev and \
                     out_val.device == dev and out_grad.device == dev and points.dim() == 2 and points.is_contiguous() and \
@@ -958,7 +967,9 @@ class ComposedSDF(ObjectFrameSDF):
                 with _lib.on_device(dev):
                     grids = self._leaf_grids(dev)
                 if _lib.same_gpu(sdfs[0].device, dev):
-                    plan = (dev, dev.index, grids.data_ptr(), len(sdfs), _lib.load().pvamd_composed_query, grids)
+                    fast = _lib.fastcall()
+                    plan = (dev, dev.index, grids.data_ptr(), len(sdfs), _lib.load().pvamd_composed_query, grids, fast,
+                            _lib.entry_address("pvamd_composed_query") if fast is not None else 0)
         self._plan = (key, plan)
         return plan
 
@@ -983,6 +994,12 @@ class ComposedSDF(ObjectFrameSDF):
                 tfd = self._tf_dev
                 if tfd is None or tfd.device != dev:
                     tfd = self._tf_device(dev)
+                grouping = self._grouping_pays(A, P, flags)
+                if plan[6] is not None and not grouping and (batch is None or len(batch) > 0):  # csrc/fastcall.cpp: the allocations and the call below, in C++
+                    out = plan[6].composed_call(plan[7], plan[2], plan[3], tfd.data_ptr(), A, batch if batch is not None else (),
+                                                flags | (_lib.COMPOSED_NO_GROUPING if self.group_points is False else 0), plan[1], p)
+                    if out is not None:
+                        return out
                 # (p is float32 on dev: new_empty = torch.empty(shape, dtype=, device=) without the keyword parsing)
                 if batch is not None:
                     val = p.new_empty((*batch, *p.shape[:-1]))
@@ -990,7 +1007,7 @@ class ComposedSDF(ObjectFrameSDF):
                 else:
                     val = p.new_empty((P,))
                     grad = p.new_empty((P, 3))
-                if self._grouping_pays(A, P, flags):
+                if grouping:
                     scratch = _lib.group_points(p.view(-1, 3))
                     _lib.check(_lib.load().pvamd_composed_query_grouped(plan[2], plan[3], tfd.data_ptr(), A, scratch.data_ptr(), P,
                                                                         val.data_ptr(), grad.data_ptr(), None, flags,
